@@ -376,14 +376,16 @@ def gen_train_steps():
             arrs['r%d.%s' % (r, k)] = b[k]
         arrs['r%d.t_fg' % r] = li['t_fg'].numpy()
         arrs['r%d.t_bg' % r] = li['t_bg'].numpy()
-        ref_level_step(nets[0], bt, li['far'], li['fg0'], li['bg0'], 'mse', 0.1, 0.)
-        g = grads_np(nets[0])
+        net64, _, _ = ref_level_step(nets[0], bt, li['far'], li['fg0'], li['bg0'], 'mse', 0.1, 0.,
+                                     dtype=torch.float64)          # float64 run: see gen_grads
+        g = grads_np(net64)
         gsum = g if gsum is None else OrderedDict((k, gsum[k] + g[k]) for k in g)
     for k, g in gsum.items():
         g = g / 2.
         idx = sample_idx(g.size, 128)
         arrs['avg.%s.idx' % k] = idx
         arrs['avg.%s.g' % k] = g.reshape(-1)[idx]
+        arrs['avg.%s.rms' % k] = np.float64(np.sqrt((g ** 2).mean()))
     save('ddp2', **arrs)
 
 

@@ -238,4 +238,4 @@ def test_ddp_two_rank_average(golden):
     for k in acc:
         mine = (acc[k] / 2).reshape(-1)[g['avg.%s.idx' % k]]
         ref = g['avg.%s.g' % k]
-        assert np.abs(mine - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9, k
+        assert np.abs(mine - ref).max() <= 5e-2 * g['avg.%s.rms' % k] + 1e-12, k
