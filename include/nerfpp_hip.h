@@ -1,0 +1,173 @@
+/* nerfpp_hip.h -- C ABI of libnerfpp_hip.so, the MI355X (gfx950) implementation of the NeRF++
+ * depth-supervised render/train hot path of cwchenwang/outdoor-nerf-depth.
+ *
+ * The reference has no FFI: its hot path is PyTorch calls inside
+ * nerf-methods/nerfplusplus/ddp_train_nerf.py (per-cascade-level loop :432-498 training,
+ * :156-221 inference) and ddp_model.py:74-147 (NerfNet.forward).  Each entry point below names
+ * the reference call it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (float32 unless stated), sizes, and a `void* stream`
+ *     (a hipStream_t; NULL = default stream).  No torch types, no exceptions across the ABI.
+ *   - every function returns NERFPP_OK (0) or an error code; nerfpp_last_error() returns a
+ *     thread-local description.  Kernels are enqueued asynchronously on `stream`.
+ *   - the library is stateless: the caller owns every buffer (parameters, packed weights, index
+ *     tables, workspace, outputs).  Sizes come from the *_bytes / *_sizes queries.
+ *   - all arrays are dense row-major; "rows" means n_rays * n_samples in (ray, sample) order.
+ *   - network shape is fixed to the reference's only configuration: netdepth 8, netwidth 256,
+ *     skip at layer 4, max_freq_log2 10 / 4 (configs/kitti.txt:38-44).
+ */
+#ifndef NERFPP_HIP_H
+#define NERFPP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERFPP_ABI_VERSION 1
+
+#define NERFPP_OK 0
+#define NERFPP_ERR_ARG 1          /* bad argument (null pointer, size out of range) */
+#define NERFPP_ERR_HIP 2          /* a HIP runtime call / kernel launch failed */
+#define NERFPP_ERR_INTERNAL 3
+#define NERFPP_ERR_UNSUPPORTED 4
+
+/* precision of the MLP kernels */
+#define NERFPP_PREC_BF16 1        /* single-pass bf16 MFMA, f32 accumulate ("speed") */
+#define NERFPP_PREC_SPLIT_BF16 2  /* hi+lo split bf16, 3 MFMA passes, ~1e-5 rel. of float32 ("parity") */
+
+/* depth loss types (ddp_train_nerf.py:20-26; `los` / `nll` are dead code in the reference) */
+#define NERFPP_LOSS_RGB_ONLY 0
+#define NERFPP_LOSS_MSE 1
+#define NERFPP_LOSS_L1 2
+#define NERFPP_LOSS_KL 3
+
+#define NERFPP_FG_PARAMS 595844     /* MLPNet(input_ch=63, input_ch_viewdirs=27).parameters() */
+#define NERFPP_BG_PARAMS 606596     /* MLPNet(input_ch=84, ...) */
+#define NERFPP_LEVEL_PARAMS 1202440 /* NerfNet.parameters(): fg_net then bg_net, state_dict order */
+#define NERFPP_MAX_SAMPLES 256      /* samples per ray per level (reference: 64 and 64+128) */
+
+const char* nerfpp_last_error(void);
+int nerfpp_abi_version(void);
+
+/* ---------------------------------------------------------------- sampling (float32, bit-exact bins) */
+
+/* intersect_sphere(ray_o, ray_d)                                   ddp_train_nerf.py:51-66
+ * *bad_count (device int, caller zeroes it) is incremented for every ray whose closest point to
+ * the origin lies outside the unit sphere (the reference raises an Exception). */
+int nerfpp_intersect_sphere(void* stream, int n_rays, const float* ray_o, const float* ray_d,
+                            float* fg_far, int* bad_count);
+
+/* level-0 depths: fg[i] = near + i*step, bg = linspace(0,1,S), each followed by
+ * perturb_samples when t_rand_* is non-NULL                        ddp_train_nerf.py:438-449, :166-175
+ * t_rand_* [n_rays, S] replace torch.rand_like so results are reproducible from outside. */
+int nerfpp_sample_coarse(void* stream, int n_rays, int n_samples, const float* ray_o,
+                         const float* ray_d, const float* min_depth, const float* t_rand_fg,
+                         const float* t_rand_bg, float* fg_far, float* fg_z, float* bg_z,
+                         int* bad_count);
+
+/* perturb_samples(z_vals) with explicit uniforms                   ddp_train_nerf.py:69-78 */
+int nerfpp_perturb_samples(void* stream, int n_rays, int n_samples, const float* z_vals,
+                           const float* t_rand, float* out);
+
+/* sample_pdf(bins [n,M+1], weights [n,M], N_samples, det)          ddp_train_nerf.py:81-130
+ * u [n, n_new] = the uniforms, or NULL for det=True (linspace(0,1,n_new)).
+ * samples [n, n_new]; above_inds [n, n_new] int64 (may be NULL). */
+int nerfpp_sample_pdf(void* stream, int n_rays, int n_bins_m, int n_new, const float* bins,
+                      const float* weights, const float* u, float* samples, int64_t* above_inds);
+
+/* fine depths of one volume: bins = mid-points of z_old, weights = w[:, 1:-1], sample_pdf, then
+ * sort(cat(z_old, samples))                                        ddp_train_nerf.py:450-465
+ * z_old, weights [n, S_old]; z_merged [n, S_old + n_new]; samples / above_inds may be NULL. */
+int nerfpp_sample_fine(void* stream, int n_rays, int s_old, int n_new, const float* z_old,
+                       const float* weights, const float* u, float* z_merged, float* samples,
+                       int64_t* above_inds);
+
+/* ---------------------------------------------------------------- parameters */
+
+/* Index tables tying the reference's flat parameter order to the packed MFMA weight streams.
+ * Host-side, no GPU needed.  net: 0 = fg_net, 1 = bg_net. */
+int nerfpp_table_sizes(int net, int64_t* fwd_elems, int64_t* fwd_bias_elems, int64_t* bwd_elems,
+                       int64_t* slab_floats, int64_t* n_params);
+int nerfpp_build_tables(int net, int32_t* fwd_tbl, int32_t* bias_tbl, int32_t* bwd_tbl,
+                        int32_t* unpack_tbl);
+/* all tables of one level in one int32 buffer (what the device-side calls take) */
+int64_t nerfpp_level_tables_elems(void);
+int nerfpp_build_level_tables(int32_t* host_tables);
+
+/* packed weights of one level (both nets, forward + backward streams + biases) */
+int64_t nerfpp_packed_bytes(int precision);
+/* params: the level's NERFPP_LEVEL_PARAMS float32 values in NerfNet.parameters() order */
+int nerfpp_pack_level(void* stream, int precision, const float* params, const int32_t* tables,
+                      void* packed);
+
+/* ---------------------------------------------------------------- one cascade level */
+
+int64_t nerfpp_workspace_bytes(int n_rays, int n_samples, int precision, int training);
+
+typedef struct {
+  int32_t n_rays, n_samples;       /* S = 64 (level 0) or 192 (level 1) in the reference */
+  int32_t precision, training;     /* training != 0 keeps what nerfpp_level_backward needs */
+  const float* ray_o;              /* [n,3] */
+  const float* ray_d;              /* [n,3] un-normalised */
+  const float* fg_far;             /* [n]   fg_z_max */
+  const float* fg_z;               /* [n,S] */
+  const float* bg_z;               /* [n,S] ascending inverse distance */
+  const void* packed;              /* nerfpp_pack_level output */
+  void* workspace;                 /* nerfpp_workspace_bytes */
+  /* outputs: the reference's `ret` dict (ddp_model.py:136-146) */
+  float* rgb;                      /* [n,3] */
+  float* depth;                    /* [n]   */
+  float* fg_weights;               /* [n,S] */
+  float* bg_weights;               /* [n,S] (flipped order, as the reference returns it) */
+  float* fg_dists;                 /* [n,S] */
+  float* fg_rgb;                   /* [n,3] */
+  float* fg_depth;                 /* [n]   */
+  float* bg_rgb;                   /* [n,3] */
+  float* bg_depth;                 /* [n]   */
+  float* bg_lambda;                /* [n]   */
+} nerfpp_forward_args;
+
+/* ret = net(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)          ddp_model.py:74-147 */
+int nerfpp_level_forward(void* stream, const nerfpp_forward_args* args);
+
+/* loss head + its gradient                                          ddp_train_nerf.py:481-493
+ * scalars[4] = {loss, rgb_loss, depth_loss, #valid rays}; g_* are dL/d(rgb, depth, fg_weights).
+ * depth_sup may be NULL for NERFPP_LOSS_RGB_ONLY; g_fg_weights may be NULL unless KL. */
+int nerfpp_loss(void* stream, int n_rays, int n_samples, int loss_type, float lambda_depth,
+                float kl_sigma, const float* rgb, const float* rgb_gt, const float* depth,
+                const float* depth_sup, const float* fg_weights, const float* fg_z,
+                const float* fg_dists, const float* fg_far, float* scalars, float* g_rgb,
+                float* g_depth, float* g_fg_weights);
+
+typedef struct {
+  int32_t n_rays, n_samples;
+  int32_t precision, reserved;
+  const float* ray_d;
+  const float* fg_far;
+  const float* fg_z;
+  const float* bg_z;
+  const void* packed;
+  void* workspace;                 /* the SAME workspace the training-mode forward filled */
+  const int32_t* tables;           /* device copy of nerfpp_build_level_tables */
+  const float* g_rgb;              /* [n,3] dL/d rgb */
+  const float* g_depth;            /* [n]   dL/d depth */
+  const float* g_fg_weights;       /* [n,S] dL/d fg_weights or NULL */
+  float grad_scale;                /* multiplies every gradient (1/world_size pre-scaling) */
+  float* grads;                    /* [NERFPP_LEVEL_PARAMS] dL/d params, parameters() order */
+} nerfpp_backward_args;
+
+/* loss.backward() for one level (autograd in the reference)         ddp_train_nerf.py:497 */
+int nerfpp_level_backward(void* stream, const nerfpp_backward_args* args);
+
+/* torch.optim.Adam single step (ddp_train_nerf.py:324,498); step is the 1-based step count */
+int nerfpp_adam_step(void* stream, float* params, const float* grads, float* exp_avg,
+                     float* exp_avg_sq, int64_t n, int step, double lr, double beta1, double beta2,
+                     double eps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFPP_HIP_H */

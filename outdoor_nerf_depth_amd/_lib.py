@@ -1,0 +1,113 @@
+"""ctypes binding of libnerfpp_hip.so (include/nerfpp_hip.h).
+
+The HIP library IS the product path: there is no CPU / PyTorch fallback.  If the shared object is
+missing this module raises at import of the symbol table (`lib()`), loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnerfpp_hip.so')
+
+OK = 0
+PREC_BF16, PREC_SPLIT_BF16 = 1, 2
+LOSS_RGB_ONLY, LOSS_MSE, LOSS_L1, LOSS_KL = 0, 1, 2, 3
+LOSS_TYPES = {'rgbonly': LOSS_RGB_ONLY, 'mse': LOSS_MSE, 'l1': LOSS_L1, 'kl': LOSS_KL}
+FG_PARAMS, BG_PARAMS, LEVEL_PARAMS = 595844, 606596, 1202440
+MAX_SAMPLES = 256
+
+_fp = C.c_void_p      # device pointers travel as integers
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [('n_rays', C.c_int32), ('n_samples', C.c_int32), ('precision', C.c_int32),
+                ('training', C.c_int32)] + \
+               [(k, _fp) for k in ('ray_o', 'ray_d', 'fg_far', 'fg_z', 'bg_z', 'packed', 'workspace',
+                                   'rgb', 'depth', 'fg_weights', 'bg_weights', 'fg_dists', 'fg_rgb',
+                                   'fg_depth', 'bg_rgb', 'bg_depth', 'bg_lambda')]
+
+
+class BackwardArgs(C.Structure):
+    _fields_ = [('n_rays', C.c_int32), ('n_samples', C.c_int32), ('precision', C.c_int32),
+                ('reserved', C.c_int32)] + \
+               [(k, _fp) for k in ('ray_d', 'fg_far', 'fg_z', 'bg_z', 'packed', 'workspace', 'tables',
+                                   'g_rgb', 'g_depth', 'g_fg_weights')] + \
+               [('grad_scale', C.c_float), ('grads', _fp)]
+
+
+# every symbol include/nerfpp_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    'nerfpp_last_error': (C.c_char_p, []),
+    'nerfpp_abi_version': (C.c_int, []),
+    'nerfpp_intersect_sphere': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp]),
+    'nerfpp_sample_coarse': (C.c_int, [_fp, C.c_int, C.c_int] + [_fp] * 9),
+    'nerfpp_perturb_samples': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp]),
+    'nerfpp_sample_pdf': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
+    'nerfpp_sample_fine': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'nerfpp_table_sizes': (C.c_int, [C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p]),
+    'nerfpp_build_tables': (C.c_int, [C.c_int, _i32p, _i32p, _i32p, _i32p]),
+    'nerfpp_level_tables_elems': (C.c_int64, []),
+    'nerfpp_build_level_tables': (C.c_int, [_i32p]),
+    'nerfpp_packed_bytes': (C.c_int64, [C.c_int]),
+    'nerfpp_pack_level': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp]),
+    'nerfpp_workspace_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'nerfpp_level_forward': (C.c_int, [_fp, C.POINTER(ForwardArgs)]),
+    'nerfpp_loss': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [_fp] * 12),
+    'nerfpp_level_backward': (C.c_int, [_fp, C.POINTER(BackwardArgs)]),
+    'nerfpp_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_double, C.c_double,
+                                   C.c_double, C.c_double]),
+}
+
+_lib = None
+
+
+class NerfppError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library with typed prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NerfppError(
+                'libnerfpp_hip.so not found at %s -- build it with `python -c "import '
+                '__graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950). There is no '
+                'CPU fallback for the NeRF++ hot path.' % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)         # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        if handle.nerfpp_abi_version() != 1:
+            raise NerfppError('libnerfpp_hip.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != OK:
+        msg = lib().nerfpp_last_error().decode('utf-8', 'replace')
+        raise NerfppError('%s failed (code %d): %s' % (what or 'nerfpp call', rc, msg))
+
+
+def build_level_tables():
+    """Host int32 numpy array with all index tables of one cascade level."""
+    import numpy as np
+    n = lib().nerfpp_level_tables_elems()
+    out = np.empty(n, np.int32)
+    check(lib().nerfpp_build_level_tables(out.ctypes.data_as(_i32p)), 'nerfpp_build_level_tables')
+    return out
+
+
+def build_net_tables(net):
+    """(fwd_tbl, bias_tbl, bwd_tbl, unpack_tbl, slab_floats) numpy arrays of one net."""
+    import numpy as np
+    sizes = [C.c_int64() for _ in range(5)]
+    check(lib().nerfpp_table_sizes(net, *[C.byref(s) for s in sizes]), 'nerfpp_table_sizes')
+    fwd, bias, bwd, slab, npar = [s.value for s in sizes]
+    arrs = [np.empty(n, np.int32) for n in (fwd, bias, bwd, npar)]
+    check(lib().nerfpp_build_tables(net, *[a.ctypes.data_as(_i32p) for a in arrs]), 'nerfpp_build_tables')
+    return arrs[0], arrs[1], arrs[2], arrs[3], slab

@@ -1,0 +1,57 @@
+"""Build libnerfpp_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python outdoor_nerf_depth_amd/csrc/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, 'libnerfpp_hip.so')
+OBJ = os.path.join(HERE, 'build')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+          '-fhip-fp32-correctly-rounded-divide-sqrt']
+SOURCES = {
+    'nerfpp_tables.hip': [],
+    'nerfpp_render.hip': ['-ffp-contract=off'],     # bit-exact sample bins: no implicit FMA
+    'nerfpp_mlp.hip': [],
+    'nerfpp_dw.hip': [],
+    'nerfpp_optim.hip': ['-ffp-contract=off'],      # Adam rounds like torch
+    'nerfpp_api.hip': [],
+}
+HEADERS = ['nerfpp_common.h', 'nerfpp_kernels.h', os.path.join('..', '..', 'include', 'nerfpp_hip.h')]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, flags):
+    obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + [__file__]
+    if _stale(obj, deps):
+        cmd = [HIPCC] + COMMON + flags + ['-c', os.path.join(HERE, src), '-o', obj]
+        subprocess.check_call(cmd)
+    return obj
+
+
+def build(force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(lambda kv: _compile(*kv), SOURCES.items()))
+    if force or _stale(OUT, objs):
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

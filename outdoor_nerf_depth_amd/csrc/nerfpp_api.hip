@@ -1,0 +1,287 @@
+// extern "C" entry points of libnerfpp_hip.so (declared in include/nerfpp_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/nerfpp_hip.h"
+#include "nerfpp_common.h"
+#include "nerfpp_kernels.h"
+
+using namespace nerfpp;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NERFPP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return NERFPP_OK;
+}
+
+#define REQUIRE(cond, what) \
+  do { if (!(cond)) return fail(NERFPP_ERR_ARG, "%s: requirement failed: %s", __func__, what); } while (0)
+
+constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- level tables layout (int32 elements) -------------------------------------------------------
+struct TblLayout { int64_t fwd[2], bias[2], bwd[2], unpack[2], total; };
+TblLayout tbl_layout() {
+  TblLayout L{};
+  int64_t off = 0;
+  for (int net = 0; net < N_NET; ++net) {
+    L.fwd[net] = off; off += (int64_t)fwd_frags(net) * 512;
+    L.bias[net] = off; off += FWD_BIAS_FLOATS;
+    L.bwd[net] = off; off += (int64_t)BWD_FRAGS * 512;
+    L.unpack[net] = off; off += net_params(net);
+  }
+  L.total = off;
+  return L;
+}
+
+// ---- packed buffer layout (bytes) ---------------------------------------------------------------
+struct PackLayout { size_t fwd[2], bwd[2], bias[2], total; };
+PackLayout pack_layout(int P) {
+  PackLayout L{};
+  size_t off = 0;
+  for (int net = 0; net < N_NET; ++net) {
+    L.fwd[net] = off; off = align_up(off + fwd_stream_bytes(net, P), 256);
+    L.bwd[net] = off; off = align_up(off + bwd_stream_bytes(P), 256);
+    L.bias[net] = off; off = align_up(off + FWD_BIAS_FLOATS * sizeof(float), 256);
+  }
+  L.total = off;
+  return L;
+}
+
+// ---- workspace layout (bytes) -------------------------------------------------------------------
+struct WsLayout {
+  size_t tensor[2][T_COUNT], out_raw[2], depth_real, d_out[2], slabs[2], total;
+  int64_t rows, rows_padded;
+  int ksplit;
+};
+int choose_ksplit(int64_t rows) {
+  int64_t k = rows / 512;
+  if (k < 1) k = 1;
+  if (k > 12) k = 12;
+  return (int)k;
+}
+WsLayout ws_layout(int n_rays, int S, int P, bool training) {
+  WsLayout L{};
+  L.rows = (int64_t)n_rays * S;
+  L.rows_padded = (int64_t)align_up((size_t)L.rows, 256);
+  L.ksplit = choose_ksplit(L.rows);
+  size_t off = 0;
+  for (int net = 0; net < N_NET; ++net) {
+    L.out_raw[net] = off; off = align_up(off + (size_t)L.rows_padded * 16, 256);
+    if (training) {
+      L.d_out[net] = off; off = align_up(off + (size_t)L.rows_padded * 16, 256);
+      for (int t = 0; t < T_COUNT; ++t) {
+        L.tensor[net][t] = off;
+        off = align_up(off + (size_t)L.rows_padded * tensor_ld(net, t) * 2 * P, 256);
+      }
+      L.slabs[net] = off; off = align_up(off + (size_t)L.ksplit * gslab_floats(net) * 4, 256);
+    }
+  }
+  L.depth_real = off; off = align_up(off + (size_t)L.rows_padded * 4, 256);
+  L.total = off;
+  return L;
+}
+
+NetWs make_netws(char* ws, const WsLayout& L, int net) {
+  NetWs w;
+  for (int t = 0; t < T_COUNT; ++t) w.t[t] = (__bf16*)(ws + L.tensor[net][t]);
+  return w;
+}
+
+bool prec_ok(int P) { return P == NERFPP_PREC_BF16 || P == NERFPP_PREC_SPLIT_BF16; }
+
+}  // namespace
+
+extern "C" {
+
+const char* nerfpp_last_error(void) { return g_err; }
+int nerfpp_abi_version(void) { return NERFPP_ABI_VERSION; }
+
+int nerfpp_intersect_sphere(void* stream, int n_rays, const float* ray_o, const float* ray_d, float* fg_far,
+                            int* bad_count) {
+  REQUIRE(n_rays > 0 && ray_o && ray_d && fg_far, "non-null inputs, n_rays > 0");
+  launch_intersect_sphere((hipStream_t)stream, n_rays, ray_o, ray_d, fg_far, bad_count);
+  return check_launch("intersect_sphere");
+}
+
+int nerfpp_sample_coarse(void* stream, int n_rays, int n_samples, const float* ray_o, const float* ray_d,
+                         const float* min_depth, const float* t_rand_fg, const float* t_rand_bg, float* fg_far,
+                         float* fg_z, float* bg_z, int* bad_count) {
+  REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= NERFPP_MAX_SAMPLES, "2 <= n_samples <= 256");
+  REQUIRE(ray_o && ray_d && min_depth && fg_far && fg_z && bg_z, "non-null pointers");
+  launch_sample_coarse((hipStream_t)stream, n_rays, n_samples, ray_o, ray_d, min_depth, t_rand_fg, t_rand_bg,
+                       fg_far, fg_z, bg_z, bad_count);
+  return check_launch("sample_coarse");
+}
+
+int nerfpp_perturb_samples(void* stream, int n_rays, int n_samples, const float* z_vals, const float* t_rand,
+                           float* out) {
+  REQUIRE(n_rays > 0 && n_samples >= 2 && z_vals && t_rand && out, "non-null pointers");
+  launch_perturb((hipStream_t)stream, n_rays, n_samples, z_vals, t_rand, out);
+  return check_launch("perturb_samples");
+}
+
+int nerfpp_sample_pdf(void* stream, int n_rays, int n_bins_m, int n_new, const float* bins, const float* weights,
+                      const float* u, float* samples, int64_t* above_inds) {
+  REQUIRE(n_rays > 0 && n_bins_m >= 1 && n_bins_m + 1 <= 512 && n_new >= 1 && n_new <= 512, "sizes");
+  REQUIRE(bins && weights && samples, "non-null pointers");
+  launch_sample_pdf((hipStream_t)stream, false, n_rays, n_bins_m, n_new, bins, weights, u, samples, above_inds,
+                    nullptr);
+  return check_launch("sample_pdf");
+}
+
+int nerfpp_sample_fine(void* stream, int n_rays, int s_old, int n_new, const float* z_old, const float* weights,
+                       const float* u, float* z_merged, float* samples, int64_t* above_inds) {
+  REQUIRE(n_rays > 0 && s_old >= 3 && n_new >= 1 && s_old + n_new <= 512, "3 <= s_old, s_old + n_new <= 512");
+  REQUIRE(z_old && weights && z_merged, "non-null pointers");
+  launch_sample_pdf((hipStream_t)stream, true, n_rays, s_old - 2, n_new, z_old, weights, u, samples, above_inds,
+                    z_merged);
+  return check_launch("sample_fine");
+}
+
+int64_t nerfpp_level_tables_elems(void) { return tbl_layout().total; }
+
+int nerfpp_build_level_tables(int32_t* host_tables) {
+  if (!host_tables) return fail(NERFPP_ERR_ARG, "nerfpp_build_level_tables: null buffer");
+  const TblLayout L = tbl_layout();
+  for (int net = 0; net < N_NET; ++net) {
+    const int rc = nerfpp_build_tables(net, host_tables + L.fwd[net], host_tables + L.bias[net],
+                                       host_tables + L.bwd[net], host_tables + L.unpack[net]);
+    if (rc != NERFPP_OK) return fail(rc, "nerfpp_build_tables(%d) failed", net);
+  }
+  return NERFPP_OK;
+}
+
+int64_t nerfpp_packed_bytes(int precision) { return prec_ok(precision) ? (int64_t)pack_layout(precision).total : -1; }
+
+int nerfpp_pack_level(void* stream, int precision, const float* params, const int32_t* tables, void* packed) {
+  REQUIRE(prec_ok(precision), "precision must be 1 or 2");
+  REQUIRE(params && tables && packed, "non-null pointers");
+  const TblLayout T = tbl_layout();
+  const PackLayout L = pack_layout(precision);
+  hipStream_t st = (hipStream_t)stream;
+  char* out = (char*)packed;
+  for (int net = 0; net < N_NET; ++net) {
+    const float* p = params + (net == 0 ? 0 : FG_PARAMS);
+    launch_pack(st, p, tables + T.fwd[net], (int64_t)fwd_frags(net) * 512, precision, out + L.fwd[net]);
+    launch_pack(st, p, tables + T.bwd[net], (int64_t)BWD_FRAGS * 512, precision, out + L.bwd[net]);
+    launch_gather_f32(st, p, tables + T.bias[net], FWD_BIAS_FLOATS, (float*)(out + L.bias[net]));
+  }
+  return check_launch("pack_level");
+}
+
+int64_t nerfpp_workspace_bytes(int n_rays, int n_samples, int precision, int training) {
+  if (n_rays <= 0 || n_samples < 2 || n_samples > NERFPP_MAX_SAMPLES || !prec_ok(precision)) return -1;
+  return (int64_t)ws_layout(n_rays, n_samples, precision, training != 0).total;
+}
+
+int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
+  REQUIRE(a, "args");
+  REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");
+  REQUIRE(prec_ok(a->precision), "precision must be 1 or 2");
+  REQUIRE(a->ray_o && a->ray_d && a->fg_far && a->fg_z && a->bg_z && a->packed && a->workspace, "inputs");
+  REQUIRE(a->rgb && a->depth && a->fg_weights && a->bg_weights && a->fg_dists && a->fg_rgb && a->fg_depth &&
+          a->bg_rgb && a->bg_depth && a->bg_lambda, "outputs");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = a->precision;
+  const bool train = a->training != 0;
+  const WsLayout L = ws_layout(a->n_rays, a->n_samples, P, train);
+  const PackLayout PL = pack_layout(P);
+  char* ws = (char*)a->workspace;
+  const char* pk = (const char*)a->packed;
+  for (int net = 0; net < N_NET; ++net) {
+    MlpFwdArgs m{};
+    m.geom.ray_o = a->ray_o;
+    m.geom.ray_d = a->ray_d;
+    m.geom.z = net == 0 ? a->fg_z : a->bg_z;
+    m.rows = L.rows;
+    m.rows_padded = L.rows_padded;
+    m.S = a->n_samples;
+    m.w_stream = pk + PL.fwd[net];
+    m.bias = (const float*)(pk + PL.bias[net]);
+    m.out_raw = (float*)(ws + L.out_raw[net]);
+    m.depth_real = (float*)(ws + L.depth_real);
+    if (train) m.ws = make_netws(ws, L, net);
+    launch_mlp_fwd(st, net, P, train, m);
+  }
+  launch_composite_fwd(st, a->n_rays, a->n_samples, (const float*)(ws + L.out_raw[0]),
+                       (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
+                       a->fg_z, a->bg_z, a->rgb, a->depth, a->fg_weights, a->bg_weights, a->fg_dists, a->fg_rgb,
+                       a->fg_depth, a->bg_rgb, a->bg_depth, a->bg_lambda);
+  return check_launch("level_forward");
+}
+
+int nerfpp_loss(void* stream, int n_rays, int n_samples, int loss_type, float lambda_depth, float kl_sigma,
+                const float* rgb, const float* rgb_gt, const float* depth, const float* depth_sup,
+                const float* fg_weights, const float* fg_z, const float* fg_dists, const float* fg_far,
+                float* scalars, float* g_rgb, float* g_depth, float* g_fg_weights) {
+  REQUIRE(n_rays > 0 && loss_type >= 0 && loss_type <= 3, "loss_type in 0..3");
+  REQUIRE(rgb && rgb_gt && scalars && g_rgb && g_depth, "non-null pointers");
+  if (loss_type != NERFPP_LOSS_RGB_ONLY) REQUIRE(depth && depth_sup, "depth loss needs depth and depth_sup");
+  if (loss_type == NERFPP_LOSS_KL)
+    REQUIRE(fg_weights && fg_z && fg_dists && fg_far && g_fg_weights && kl_sigma > 0.f, "KL inputs");
+  launch_loss((hipStream_t)stream, n_rays, n_samples, loss_type, lambda_depth, kl_sigma, rgb, rgb_gt, depth,
+              depth_sup, fg_weights, fg_z, fg_dists, fg_far, scalars, g_rgb, g_depth, g_fg_weights);
+  return check_launch("loss");
+}
+
+int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
+  REQUIRE(a, "args");
+  REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");
+  REQUIRE(prec_ok(a->precision), "precision must be 1 or 2");
+  REQUIRE(a->ray_d && a->fg_far && a->fg_z && a->bg_z && a->packed && a->workspace && a->tables, "inputs");
+  REQUIRE(a->g_rgb && a->g_depth && a->grads, "gradients");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = a->precision;
+  const WsLayout L = ws_layout(a->n_rays, a->n_samples, P, true);
+  const PackLayout PL = pack_layout(P);
+  const TblLayout T = tbl_layout();
+  char* ws = (char*)a->workspace;
+  const char* pk = (const char*)a->packed;
+  launch_composite_bwd(st, a->n_rays, a->n_samples, (const float*)(ws + L.out_raw[0]),
+                       (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
+                       a->fg_z, a->bg_z, a->g_rgb, a->g_depth, a->g_fg_weights, (float*)(ws + L.d_out[0]),
+                       (float*)(ws + L.d_out[1]));
+  DwArgs dw{};
+  for (int net = 0; net < N_NET; ++net) {
+    MlpBwdArgs m{};
+    m.rows = L.rows;
+    m.rows_padded = L.rows_padded;
+    m.w_stream = pk + PL.bwd[net];
+    m.d_out = (const float*)(ws + L.d_out[net]);
+    m.ws = make_netws(ws, L, net);
+    launch_mlp_bwd(st, net, P, m);
+    dw.ws[net] = m.ws;
+    dw.slabs[net] = (float*)(ws + L.slabs[net]);
+  }
+  dw.rows = L.rows;
+  dw.rows_padded = L.rows_padded;
+  dw.ksplit = L.ksplit;
+  launch_dw(st, P, dw);
+  for (int net = 0; net < N_NET; ++net)
+    launch_unpack_grads(st, dw.slabs[net], L.ksplit, gslab_floats(net), a->tables + T.unpack[net],
+                        net_params(net), a->grad_scale, a->grads + (net == 0 ? 0 : FG_PARAMS));
+  return check_launch("level_backward");
+}
+
+int nerfpp_adam_step(void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                     int64_t n, int step, double lr, double beta1, double beta2, double eps) {
+  REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "non-null pointers, step >= 1");
+  launch_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps);
+  return check_launch("adam_step");
+}
+
+}  // extern "C"

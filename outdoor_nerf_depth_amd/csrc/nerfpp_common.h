@@ -1,0 +1,193 @@
+// Internal layouts shared by the HIP kernels and the host-side table builders.
+//
+// Network: the NeRF++ MLPNet of nerf-methods/nerfplusplus/nerf_network.py:70-142 with
+// D=8, W=256, skip at layer 4 (the only configuration the reference's configs use).
+//
+// Execution model of the fused MLP kernels ("samples on lanes"):
+//   every layer is computed as  H_out^T [features x samples] = W [out x in] * H_in^T  with
+//   v_mfma_f32_32x32x16_bf16.  A wave owns 32 samples; MFMA lane l = (j = l & 31, hi = l >> 5)
+//   holds sample j.  The accumulator (C/D) layout of the 32x32 MFMA gives lane (j, hi), register
+//   r of out-block ob the feature  ob*32 + (r&3) + 8*(r>>2) + 4*hi  of sample j.  Registers
+//   8h..8h+7 of an out-block, converted to bf16, ARE the B operand of the next layer's k-chunk
+//   2*ob+h -- with slot t of lane-half hi meaning input feature
+//        f = 16*c + 8*(t>>2) + 4*hi + (t&3)                                   (kslot map)
+//   instead of the natural 16*c + 8*hi + t.  The contraction does not care as long as the A
+//   operand (the weights) uses the same map, so the weights are pre-packed that way and
+//   activations chain from layer to layer in registers with no LDS/HBM round trip.
+//
+// Packed weight stream (per net, per direction): a flat sequence of 1-KiB "fragments", one per
+// (k-chunk kc, out-block ob) in order [stage][kc][ob]; fragment byte 16*l.. holds lane l's 8 bf16
+//   W_eff[ob*32 + (l&31)][kslot(kc, l>>5, t)],  t = 0..7.
+// With P = 2 (split-bf16 "parity" precision) every fragment is followed by its `lo` twin
+// (w - bf16(w) rounded to bf16).  Stages are padded so each has a multiple of BLK_FRAGS fragments;
+// kernels stream the fragments through a double-buffered LDS ring in blocks of BLK_FRAGS.
+#pragma once
+#include <stdint.h>
+
+namespace nerfpp {
+
+constexpr int WIDTH = 256;
+constexpr int FRAG_BYTES = 1024;
+constexpr int BLK_FRAGS = 16;
+constexpr int DIR_REF = 27;        // view-direction encoding width (3 + 3*2*4)
+constexpr int DIRW = 32;           // padded internal width (2 k-chunks)
+constexpr int N_NET = 2;           // 0 = foreground (3-D points), 1 = background (x,y,z,1/r)
+
+__host__ __device__ constexpr int pe_dim(int net) { return net == 0 ? 3 : 4; }
+__host__ __device__ constexpr int pe_ref_ch(int net) { return net == 0 ? 63 : 84; }
+__host__ __device__ constexpr int kpe(int net) { return net == 0 ? 4 : 6; }       // k-chunks
+__host__ __device__ constexpr int kpew(int net) { return kpe(net) * 16; }        // 64 / 96
+
+// ---- reference parameter layout of one MLPNet (state_dict / parameters() order) --------------
+// base_layers.{0..7}.0.{weight,bias}, sigma_layers.0.*, base_remap_layers.0.*, rgb_layers.0.*,
+// rgb_layers.2.*
+enum RefTensor { RT_L0 = 0, RT_SIGMA = 8, RT_REMAP = 9, RT_RGB0 = 10, RT_RGB1 = 11, RT_COUNT = 12 };
+__host__ __device__ constexpr int ref_out(int t) {
+  return t < 8 ? 256 : t == RT_SIGMA ? 1 : t == RT_REMAP ? 256 : t == RT_RGB0 ? 128 : 3;
+}
+__host__ __device__ constexpr int ref_in(int net, int t) {
+  return t == 0 ? pe_ref_ch(net) : t == 5 ? pe_ref_ch(net) + 256 : t < 8 ? 256
+       : t == RT_SIGMA ? 256 : t == RT_REMAP ? 256 : t == RT_RGB0 ? 256 + DIR_REF : 128;
+}
+__host__ __device__ constexpr int ref_w_off(int net, int t) {       // offset of tensor t's weight
+  int off = 0;
+  for (int i = 0; i < t; ++i) off += ref_out(i) * ref_in(net, i) + ref_out(i);
+  return off;
+}
+__host__ __device__ constexpr int ref_b_off(int net, int t) {
+  return ref_w_off(net, t) + ref_out(t) * ref_in(net, t);
+}
+__host__ __device__ constexpr int net_params(int net) { return ref_w_off(net, RT_COUNT); }
+constexpr int FG_PARAMS = net_params(0);      // 595 844
+constexpr int BG_PARAMS = net_params(1);      // 606 596
+constexpr int LEVEL_PARAMS = FG_PARAMS + BG_PARAMS;   // 1 202 440
+static_assert(FG_PARAMS == 595844 && BG_PARAMS == 606596, "reference parameter count");
+
+// ---- forward stages ---------------------------------------------------------------------------
+enum FwdStage { FS_L0 = 0, FS_L5 = 5, FS_REMAP = 8, FS_SIG = 9, FS_RGB0 = 10, FS_RGB1 = 11, FS_COUNT = 12 };
+__host__ __device__ constexpr int fs_nob(int s) { return s <= FS_REMAP ? 8 : s == FS_RGB0 ? 4 : 1; }
+__host__ __device__ constexpr int fs_nkc(int net, int s) {
+  return s == FS_L0 ? kpe(net) : s == FS_L5 ? kpe(net) + 16 : s <= FS_REMAP ? 16
+       : s == FS_SIG ? 16 : s == FS_RGB0 ? 20 : 16;
+}
+__host__ __device__ constexpr int fs_frags(int net, int s) { return fs_nob(s) * fs_nkc(net, s); }
+__host__ __device__ constexpr int fs_frag_off(int net, int s) {
+  int off = 0;
+  for (int i = 0; i < s; ++i) off += fs_frags(net, i);
+  return off;
+}
+__host__ __device__ constexpr int fs_bias_off(int s) {              // in floats, D-layout order
+  int off = 0;
+  for (int i = 0; i < s; ++i) off += fs_nob(i) * 32;
+  return off;
+}
+__host__ __device__ constexpr int fwd_frags(int net) { return fs_frag_off(net, FS_COUNT); }
+constexpr int FWD_BIAS_FLOATS = fs_bias_off(FS_COUNT);
+static_assert(fwd_frags(0) % BLK_FRAGS == 0 && fwd_frags(1) % BLK_FRAGS == 0, "block aligned");
+
+// ---- backward (dX chain) stages -----------------------------------------------------------------
+// B0: dG = Wrgb1^T dP | B1: dR = Wrgb0[:, :256]^T dG | B2: dH7 = Wremap^T dR + wsig dsig |
+// B3..B9: dH_{l-1} = W_l^T dZ_l for l = 7..1 (l = 5 uses only the hidden-input columns)
+enum BwdStage { BS_DG = 0, BS_DR = 1, BS_DH7 = 2, BS_COUNT = 10 };
+__host__ __device__ constexpr int bs_nob(int s) { return s == BS_DG ? 4 : 8; }
+__host__ __device__ constexpr int bs_nkc(int s) { return s == BS_DG ? 4 : s == BS_DR ? 8 : s == BS_DH7 ? 18 : 16; }
+__host__ __device__ constexpr int bs_frags(int s) { return bs_nob(s) * bs_nkc(s); }
+__host__ __device__ constexpr int bs_frag_off(int s) {
+  int off = 0;
+  for (int i = 0; i < s; ++i) off += bs_frags(i);
+  return off;
+}
+constexpr int BWD_FRAGS = bs_frag_off(BS_COUNT);
+static_assert(BWD_FRAGS % BLK_FRAGS == 0, "block aligned");
+__host__ __device__ constexpr int bs_layer(int s) { return 10 - s; }     // s = 3..9 -> l = 7..1
+
+// packed stream sizes in bytes for precision P (1 = bf16, 2 = split bf16 hi+lo)
+__host__ __device__ constexpr size_t fwd_stream_bytes(int net, int P) { return (size_t)fwd_frags(net) * FRAG_BYTES * P; }
+__host__ __device__ constexpr size_t bwd_stream_bytes(int P) { return (size_t)BWD_FRAGS * FRAG_BYTES * P; }
+
+// the kslot map: feature index of slot t of lane-half hi in k-chunk c
+__host__ __device__ constexpr int kslot(int c, int hi, int t) { return 16 * c + 8 * (t >> 2) + 4 * hi + (t & 3); }
+// feature index of accumulator register r of lane-half hi in out-block ob (32x32 MFMA C/D layout)
+__host__ __device__ constexpr int dfeat(int ob, int hi, int r) { return ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---- positional-encoding internal order --------------------------------------------------------
+// Lane-half hi of a sample computes frequencies [5*hi, 5*hi+5) of every input dimension plus two
+// identity terms; its m-th value (m = 8*c + t over its k-chunks) is, for m < 10*D,
+//   freq k = 5*hi + m/(2D), dim d = (m % 2D)/2, sin if m even else cos,
+// then (m = 10D, 10D+1) the raw inputs 2*hi, 2*hi+1 (if < D), then zero padding.
+// Returns the index in the reference Embedder output (nerf_network.py:42-60) or -1.
+__host__ __device__ constexpr int pe_ref_of_lane_slot(int D, int hi, int m) {
+  const int nf = 10 * D;
+  if (m < nf) {
+    const int k = 5 * hi + m / (2 * D), d = (m % (2 * D)) / 2, s = m & 1;
+    return D + k * 2 * D + s * D + d;
+  }
+  const int id = 2 * hi + (m - nf);
+  return (m - nf) < 2 && id < D ? id : -1;
+}
+// view-direction encoding: lane-half hi computes frequencies 2hi, 2hi+1 (12 values), then raw
+// inputs 2hi, 2hi+1 (if < 3), then padding; 16 values per lane-half.
+__host__ __device__ constexpr int dir_ref_of_lane_slot(int hi, int m) {
+  if (m < 12) {
+    const int k = 2 * hi + m / 6, d = (m % 6) / 2, s = m & 1;
+    return 3 + k * 6 + s * 3 + d;
+  }
+  const int id = 2 * hi + (m - 12);
+  return (m - 12) < 2 && id < 3 ? id : -1;
+}
+// internal feature f (column of the saved X / DIRX tensors, kslot order) -> (hi, m)
+__host__ __device__ constexpr int feat_hi(int f) { return ((f % 16) / 4) % 2; }
+__host__ __device__ constexpr int feat_m(int f) { return 8 * (f / 16) + 4 * ((f % 16) / 8) + (f % 4); }
+__host__ __device__ constexpr int pe_ref_of_feat(int net, int f) { return pe_ref_of_lane_slot(pe_dim(net), feat_hi(f), feat_m(f)); }
+__host__ __device__ constexpr int dir_ref_of_feat(int f) { return dir_ref_of_lane_slot(feat_hi(f), feat_m(f)); }
+
+// ---- saved tensors (training): row-major [rows_padded][ld] bf16, one plane per precision part ---
+enum Tensor {
+  T_X = 0, T_H0 = 1, /* .. T_H7 = 8 */ T_R = 9, T_G = 10, T_DIRX = 11,
+  T_DZ0 = 12, /* .. T_DZ7 = 19 */ T_DR = 20, T_DS = 21, T_DG = 22, T_DP = 23, T_COUNT = 24
+};
+__host__ __device__ constexpr int tensor_ld(int net, int t) {
+  return t == T_X ? kpew(net) : (t >= T_H0 && t <= T_R) ? 256 : t == T_G ? 128 : t == T_DIRX ? 32
+       : (t >= T_DZ0 && t <= T_DR) ? 256 : t == T_DS ? 32 : t == T_DG ? 128 : 32;
+}
+__host__ __device__ constexpr int tensor_off_cols(int net, int t) {   // column offset in a row "super-struct"
+  int off = 0;
+  for (int i = 0; i < t; ++i) off += tensor_ld(net, i);
+  return off;
+}
+__host__ __device__ constexpr int ws_cols(int net) { return tensor_off_cols(net, T_COUNT); }
+
+// ---- weight-gradient GEMMs: GW[stage] = dZ^T * input --------------------------------------------
+// one entry per forward stage with parameters; I spans 1 or 2 input tensors
+__host__ __device__ constexpr int gw_O(int s) { return s <= FS_REMAP ? 256 : s == FS_SIG ? 32 : s == FS_RGB0 ? 128 : 32; }
+__host__ __device__ constexpr int gw_I(int net, int s) {
+  return s == FS_L0 ? kpew(net) : s == FS_L5 ? kpew(net) + 256 : s <= FS_SIG ? 256 : s == FS_RGB0 ? 256 + DIRW : 128;
+}
+__host__ __device__ constexpr int gw_off(int net, int s) {            // floats
+  int off = 0;
+  for (int i = 0; i < s; ++i) off += gw_O(i) * gw_I(net, i);
+  return off;
+}
+__host__ __device__ constexpr int gw_floats(int net) { return gw_off(net, FS_COUNT); }
+__host__ __device__ constexpr int gb_off(int s) {
+  int off = 0;
+  for (int i = 0; i < s; ++i) off += gw_O(i);
+  return off;
+}
+constexpr int GB_FLOATS = gb_off(FS_COUNT);
+__host__ __device__ constexpr int gslab_floats(int net) { return gw_floats(net) + GB_FLOATS; }
+__host__ __device__ constexpr int gw_dz_tensor(int s) {
+  return s < 8 ? T_DZ0 + s : s == FS_REMAP ? T_DR : s == FS_SIG ? T_DS : s == FS_RGB0 ? T_DG : T_DP;
+}
+
+struct DwJob {       // one 128x128 (or smaller) output tile of one weight-gradient GEMM
+  int16_t a_tensor, b_tensor;     // dZ tensor, input tensor
+  int16_t o0, i0;                 // first column in each tensor
+  int16_t n_o, n_i;               // valid columns (multiples of 32, <= 128)
+  int32_t gw_off;                 // offset of element (o0, i_global0) in the slab
+  int16_t gw_ld;                  // row stride of this stage's GW block
+  int16_t gb_off;                 // offset of bias o0 in the slab's bias part, or -1
+};
+constexpr int MAX_DW_JOBS = 64;
+
+}  // namespace nerfpp

@@ -1,0 +1,79 @@
+// Kernel argument structs and host launcher prototypes (internal to the shared library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nerfpp_common.h"
+
+namespace nerfpp {
+
+struct MlpGeom {                 // per-ray inputs + per-sample depths of ONE volume (fg or bg)
+  const float* ray_o;            // [n_rays, 3]
+  const float* ray_d;            // [n_rays, 3]
+  const float* z;                // [n_rays * S]
+};
+
+struct NetWs {                   // saved tensors of one net (nerfpp_common.h: enum Tensor)
+  __bf16* t[T_COUNT];            // hi plane; lo plane (P = 2) follows at +rows_padded*ld elements
+};
+
+struct MlpFwdArgs {
+  MlpGeom geom;
+  int64_t rows, rows_padded;     // rows = n_rays * S
+  int S;
+  const void* w_stream;          // packed forward weight stream of this net
+  const float* bias;             // packed forward bias stream of this net
+  float* out_raw;                // [rows, 4] (r, g, b, sigma_raw)
+  float* depth_real;             // [rows] (background only)
+  NetWs ws;
+};
+
+struct MlpBwdArgs {
+  int64_t rows, rows_padded;
+  const void* w_stream;          // packed backward (transposed) weight stream
+  const float* d_out;            // [rows, 4] (d rgb_pre[3], d sigma_raw)
+  NetWs ws;
+};
+
+struct DwArgs {
+  NetWs ws[N_NET];
+  int64_t rows, rows_padded;
+  int ksplit;
+  float* slabs[N_NET];           // [ksplit][gslab_floats(net)]
+};
+
+}  // namespace nerfpp
+
+// nerfpp_render.hip
+void launch_intersect_sphere(hipStream_t st, int n, const float* o, const float* d, float* far, int* bad);
+void launch_sample_coarse(hipStream_t st, int n, int S, const float* o, const float* d, const float* min_depth,
+                          const float* t_fg, const float* t_bg, float* far, float* fg_z, float* bg_z, int* bad);
+void launch_perturb(hipStream_t st, int n, int S, const float* z, const float* t, float* out);
+void launch_sample_pdf(hipStream_t st, bool fused, int n, int M, int S_new, const float* bins_or_zold,
+                       const float* weights, const float* u, float* samples, int64_t* above, float* merged);
+void launch_composite_fwd(hipStream_t st, int n, int S, const float* raw_fg, const float* raw_bg,
+                          const float* depth_real_bg, const float* ray_d, const float* fg_far,
+                          const float* fg_z, const float* bg_z, float* rgb, float* depth, float* fg_weights,
+                          float* bg_weights, float* fg_dists, float* fg_rgb, float* fg_depth, float* bg_rgb,
+                          float* bg_depth, float* bg_lambda);
+void launch_composite_bwd(hipStream_t st, int n, int S, const float* raw_fg, const float* raw_bg,
+                          const float* depth_real_bg, const float* ray_d, const float* fg_far,
+                          const float* fg_z, const float* bg_z, const float* g_rgb, const float* g_depth,
+                          const float* g_fg_weights, float* dout_fg, float* dout_bg);
+void launch_loss(hipStream_t st, int n, int S, int type, float lambda_depth, float kl_sigma, const float* rgb,
+                 const float* rgb_gt, const float* depth, const float* depth_sup, const float* fg_weights,
+                 const float* fg_z, const float* fg_dists, const float* fg_far, float* scalars, float* g_rgb,
+                 float* g_depth, float* g_fg_weights);
+// nerfpp_mlp.hip
+void launch_mlp_fwd(hipStream_t st, int net, int P, bool train, const nerfpp::MlpFwdArgs& a);
+void launch_mlp_bwd(hipStream_t st, int net, int P, const nerfpp::MlpBwdArgs& a);
+int mlp_tile_rows(int P);
+// nerfpp_dw.hip
+void launch_dw(hipStream_t st, int P, const nerfpp::DwArgs& a);
+int dw_jobs_total();
+// nerfpp_optim.hip
+void launch_pack(hipStream_t st, const float* params, const int32_t* tbl, int64_t n_elems, int P, void* out);
+void launch_gather_f32(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, float* out);
+void launch_unpack_grads(hipStream_t st, const float* slabs, int ksplit, int64_t slab_floats,
+                         const int32_t* tbl, int64_t n_params, float scale, float* grads);
+void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
+                 double beta1, double beta2, double eps);

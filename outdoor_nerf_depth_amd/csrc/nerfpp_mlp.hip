@@ -1,0 +1,475 @@
+// Fused NeRF++ MLP kernels for gfx950 (see nerfpp_common.h for the execution model).
+//
+//   mlp_fwd_kernel : positional encoding (+ inverted-sphere parametrisation for the background)
+//                    -> 8x256 trunk with skip -> sigma / remap / colour heads, activations chained
+//                    in registers, weights streamed L2 -> LDS (global_load_lds, double-buffered
+//                    16-fragment blocks) -> v_mfma_f32_32x32x16_bf16.
+//                    Reference: nerf_network.py:42-60,120-142; ddp_model.py:16-45,86-94,107-120.
+//   mlp_bwd_kernel : the dX chain of the same network (closed-form backward of the above; the
+//                    reference relies on autograd), again chained in registers; writes every dZ
+//                    for the weight-gradient GEMMs (nerfpp_dw.hip).
+//
+// Precision P: 1 = single-pass bf16 operands / f32 accumulate ("speed" mode);
+//              2 = split-bf16 (x = hi + lo, 3 MFMA passes hi*hi + hi*lo + lo*hi), which holds
+//                  ~1e-5 relative error against the float32 reference ("parity" mode).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "nerfpp_common.h"
+#include "nerfpp_kernels.h"
+
+namespace nerfpp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int P> struct Frag { bf16x8 v[P]; };
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// ---- weight stream pipe: blocks of BLK_FRAGS*P KiB, double-buffered in LDS ----------------------
+template <int P, int NW>
+struct WeightPipe {
+  static constexpr int BLK_BYTES = BLK_FRAGS * P * FRAG_BYTES;
+  const char* g;
+  int nblk, cur, wave, lane;
+  __device__ __forceinline__ void init(const void* stream, int nblk_, int wave_, int lane_) {
+    g = (const char*)stream; nblk = nblk_; cur = 0; wave = wave_; lane = lane_;
+    issue(0);
+  }
+  __device__ __forceinline__ void issue(int blk) {
+    if (blk < nblk) {
+      const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
+      char* dst = smem + (blk & 1) * BLK_BYTES;
+#pragma unroll
+      for (int f = 0; f < BLK_FRAGS * P / NW; ++f) {
+        const int fi = f * NW + wave;
+        glds16(src + fi * FRAG_BYTES, dst + fi * FRAG_BYTES);
+      }
+    }
+  }
+  // make block `cur` readable, start fetching block cur+1, return LDS address of block cur
+  __device__ __forceinline__ const char* acquire() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue(cur + 1);
+    const char* l = smem + (cur & 1) * BLK_BYTES + lane * 16;
+    ++cur;
+    return l;
+  }
+};
+
+template <int P>
+__device__ __forceinline__ void mfma_p(f32x16& acc, const char* lfrag, const Frag<P>& b) {
+  const bf16x8 a_hi = *(const bf16x8*)(lfrag);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.v[0], acc, 0, 0, 0);
+  if constexpr (P == 2) {
+    const bf16x8 a_lo = *(const bf16x8*)(lfrag + FRAG_BYTES);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.v[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b.v[0], acc, 0, 0, 0);
+  }
+}
+
+// acc[ob] += W_stage[ob-block, :] * B   for one stage of NKC k-chunks x NOB out-blocks
+template <int NOB, int NKC, int P, int NW>
+__device__ __forceinline__ void stage_gemm(WeightPipe<P, NW>& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC]) {
+  constexpr int KPB = BLK_FRAGS / NOB;            // k-chunks per block
+  static_assert(NKC % KPB == 0, "stage must be block aligned");
+#pragma unroll
+  for (int blk = 0; blk < NKC / KPB; ++blk) {
+    const char* l = pipe.acquire();
+#pragma unroll
+    for (int kl = 0; kl < KPB; ++kl) {
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+        mfma_p<P>(acc[ob], l + (kl * NOB + ob) * P * FRAG_BYTES, b[blk * KPB + kl]);
+    }
+  }
+}
+
+template <int P>
+__device__ __forceinline__ void set_slot(Frag<P>& f, int t, float v) {
+  const __bf16 h = (__bf16)v;
+  f.v[0][t] = h;
+  if constexpr (P == 2) f.v[1][t] = (__bf16)(v - (float)h);
+}
+template <int P>
+__device__ __forceinline__ Frag<P> zero_frag() {
+  Frag<P> f;
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f.v[p][t] = (__bf16)0.f;
+  return f;
+}
+
+enum { ACT_NONE = 0, ACT_RELU = 1 };
+
+// accumulator (C/D layout) -> B operand fragments of the next stage
+template <int NOB, int P, int ACT>
+__device__ __forceinline__ void acc_to_frags(const f32x16 (&acc)[NOB], Frag<P> (&h)[2 * NOB]) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v = acc[ob][8 * hh + t];
+        if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+        set_slot<P>(h[2 * ob + hh], t, v);
+      }
+}
+
+template <int NOB>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NOB], const float* __restrict__ bias, int hi) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    const float4* p = (const float4*)(bias + ob * 32 + hi * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = p[q];
+      acc[ob][4 * q] = v.x; acc[ob][4 * q + 1] = v.y; acc[ob][4 * q + 2] = v.z; acc[ob][4 * q + 3] = v.w;
+    }
+  }
+}
+template <int NOB>
+__device__ __forceinline__ void init_zero(f32x16 (&acc)[NOB]) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
+}
+
+// fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements)
+template <int NCH, int P>
+__device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t row, int hi, bool valid,
+                                           const Frag<P> (&h)[NCH]) {
+  if (!valid) return;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    __bf16* r = base + p * plane + row * ld + 4 * hi;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint4 bits = *(const uint4*)&h[c].v[p];
+      *(uint2*)(r + 16 * c) = make_uint2(bits.x, bits.y);
+      *(uint2*)(r + 16 * c + 8) = make_uint2(bits.z, bits.w);
+    }
+  }
+}
+
+// dH (accumulators) * [saved activation > 0] -> dZ fragments
+template <int NOB, int P>
+__device__ __forceinline__ void mask_to_frags(const f32x16 (&acc)[NOB], const __bf16* act_base, int ld, size_t row,
+                                              int hi, Frag<P> (&dz)[2 * NOB]) {
+  const __bf16* r = act_base + row * ld + 4 * hi;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = 2 * ob + hh;
+      const uint2 m0 = *(const uint2*)(r + 16 * c);
+      const uint2 m1 = *(const uint2*)(r + 16 * c + 8);
+      const uint32_t w[4] = {m0.x, m0.y, m1.x, m1.y};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t bits = (w[t >> 1] >> (16 * (t & 1))) & 0x7fffu;
+        const float v = bits != 0 ? acc[ob][8 * hh + t] : 0.f;
+        set_slot<P>(dz[c], t, v);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// input geometry + encodings for one sample (one lane-half)
+// ------------------------------------------------------------------------------------------------
+template <int NET>
+__device__ __forceinline__ void sample_point(const MlpGeom& gm, size_t row, int S, float (&x)[4], float (&vd)[3],
+                                             float* depth_real) {
+  const int ray = (int)(row / S);
+  const float ox = gm.ray_o[ray * 3], oy = gm.ray_o[ray * 3 + 1], oz = gm.ray_o[ray * 3 + 2];
+  const float dx = gm.ray_d[ray * 3], dy = gm.ray_d[ray * 3 + 1], dz = gm.ray_d[ray * 3 + 2];
+  const float z = gm.z[row];
+  const float dd = dx * dx + dy * dy + dz * dz;
+  const float inv_n = 1.f / sqrtf(dd);
+  vd[0] = dx * inv_n; vd[1] = dy * inv_n; vd[2] = dz * inv_n;       // ddp_model.py:82-83
+  if (NET == 0) {
+    x[0] = ox + z * dx; x[1] = oy + z * dy; x[2] = oz + z * dz; x[3] = 0.f;   // ddp_model.py:91
+    *depth_real = 0.f;
+  } else {                                                           // ddp_model.py:16-45
+    const float d1 = -(dx * ox + dy * oy + dz * oz) / dd;
+    const float mx = ox + d1 * dx, my = oy + d1 * dy, mz = oz + d1 * dz;
+    const float pmn = sqrtf(mx * mx + my * my + mz * mz);
+    const float d2 = sqrtf(1.f - pmn * pmn) * inv_n;
+    const float sx = ox + (d1 + d2) * dx, sy = oy + (d1 + d2) * dy, sz = oz + (d1 + d2) * dz;
+    float ax = oy * sz - oz * sy, ay = oz * sx - ox * sz, az = ox * sy - oy * sx;
+    const float an = 1.f / sqrtf(ax * ax + ay * ay + az * az);
+    ax *= an; ay *= an; az *= an;
+    const float phi = asinf(pmn), theta = asinf(pmn * z);
+    float sn, cs;
+    sincosf(phi - theta, &sn, &cs);
+    const float cx = ay * sz - az * sy, cy = az * sx - ax * sz, cz = ax * sy - ay * sx;
+    const float dt = (ax * sx + ay * sy + az * sz) * (1.f - cs);
+    float nx = sx * cs + cx * sn + ax * dt, ny = sy * cs + cy * sn + ay * dt, nz = sz * cs + cz * sn + az * dt;
+    const float nn = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
+    x[0] = nx * nn; x[1] = ny * nn; x[2] = nz * nn; x[3] = z;
+    *depth_real = 1.f / (z + 1e-6f) * cosf(theta) * inv_n + d1;
+  }
+}
+
+// positional encoding of this lane-half's share (nerfpp_common.h: pe_ref_of_lane_slot)
+template <int NET, int P>
+__device__ __forceinline__ void encode_point(const float (&x)[4], int hi, Frag<P> (&pe)[kpe(NET)]) {
+  constexpr int D = pe_dim(NET), NV = kpe(NET) * 8;
+  float v[NV];
+#pragma unroll
+  for (int kk = 0; kk < 5; ++kk) {
+    const float scale = __int_as_float((127 + 5 * hi + kk) << 23);       // 2^(5hi+kk), exact
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      float sn, cs;
+      sincosf(x[d] * scale, &sn, &cs);
+      v[(kk * D + d) * 2] = sn;
+      v[(kk * D + d) * 2 + 1] = cs;
+    }
+  }
+  v[10 * D] = hi ? x[2] : x[0];
+  v[10 * D + 1] = hi ? (D == 4 ? x[3] : 0.f) : x[1];
+#pragma unroll
+  for (int m = 10 * D + 2; m < NV; ++m) v[m] = 0.f;
+#pragma unroll
+  for (int c = 0; c < kpe(NET); ++c)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) set_slot<P>(pe[c], t, v[8 * c + t]);
+}
+
+template <int P>
+__device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P> (&df)[2]) {
+  float v[16];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const float scale = __int_as_float((127 + 2 * hi + kk) << 23);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float sn, cs;
+      sincosf(vd[d] * scale, &sn, &cs);
+      v[(kk * 3 + d) * 2] = sn;
+      v[(kk * 3 + d) * 2 + 1] = cs;
+    }
+  }
+  v[12] = hi ? vd[2] : vd[0];
+  v[13] = hi ? 0.f : vd[1];
+  v[14] = 0.f; v[15] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) set_slot<P>(df[c], t, v[8 * c + t]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int NET, int P, int NW, bool TRAIN>
+__global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
+  constexpr int KPE = kpe(NET);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5;
+  const size_t row_raw = (size_t)blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
+  const bool valid = row_raw < (size_t)a.rows;
+  const size_t row = valid ? row_raw : (size_t)a.rows - 1;
+  const size_t plane_rows = a.rows_padded;
+
+  WeightPipe<P, NW> pipe;
+  pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
+
+  float x[4], vd[3], depth_real;
+  sample_point<NET>(a.geom, row, a.S, x, vd, &depth_real);
+  Frag<P> pe[KPE];
+  encode_point<NET, P>(x, hi, pe);
+  if (TRAIN) save_frags<KPE, P>(a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), row, hi, valid, pe);
+
+  f32x16 acc[8];
+  Frag<P> h[16];
+  // L0
+  init_bias<8>(acc, a.bias + fs_bias_off(FS_L0), hi);
+  stage_gemm<8, KPE, P, NW>(pipe, acc, pe);
+  acc_to_frags<8, P, ACT_RELU>(acc, h);
+  if (TRAIN) save_frags<16, P>(a.ws.t[T_H0], plane_rows * 256, 256, row, hi, valid, h);
+  // L1..L4
+  for (int l = 1; l <= 4; ++l) {
+    init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
+    stage_gemm<8, 16, P, NW>(pipe, acc, h);
+    acc_to_frags<8, P, ACT_RELU>(acc, h);
+    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row, hi, valid, h);
+  }
+  // L5: input = cat(encoded point, h4)                                 nerf_network.py:127-129
+  {
+    Frag<P> in5[KPE + 16];
+#pragma unroll
+    for (int c = 0; c < KPE; ++c) in5[c] = pe[c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) in5[KPE + c] = h[c];
+    init_bias<8>(acc, a.bias + fs_bias_off(FS_L5), hi);
+    stage_gemm<8, KPE + 16, P, NW>(pipe, acc, in5);
+    acc_to_frags<8, P, ACT_RELU>(acc, h);
+    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + 5], plane_rows * 256, 256, row, hi, valid, h);
+  }
+  // L6, L7
+  for (int l = 6; l <= 7; ++l) {
+    init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
+    stage_gemm<8, 16, P, NW>(pipe, acc, h);
+    acc_to_frags<8, P, ACT_RELU>(acc, h);
+    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row, hi, valid, h);
+  }
+  // remap (no activation) and sigma, both from h7                       nerf_network.py:131-136
+  Frag<P> rm[16];
+  init_bias<8>(acc, a.bias + fs_bias_off(FS_REMAP), hi);
+  stage_gemm<8, 16, P, NW>(pipe, acc, h);
+  acc_to_frags<8, P, ACT_NONE>(acc, rm);
+  if (TRAIN) save_frags<16, P>(a.ws.t[T_R], plane_rows * 256, 256, row, hi, valid, rm);
+  f32x16 acc1[1];
+  init_bias<1>(acc1, a.bias + fs_bias_off(FS_SIG), hi);
+  stage_gemm<1, 16, P, NW>(pipe, acc1, h);
+  const float sigma_raw = acc1[0][0];
+  // colour head                                                         nerf_network.py:137-138
+  Frag<P> g[8];
+  {
+    Frag<P> in[20];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) in[c] = rm[c];
+    Frag<P> df[2];
+    encode_dir<P>(vd, hi, df);
+    if (TRAIN) save_frags<2, P>(a.ws.t[T_DIRX], plane_rows * 32, 32, row, hi, valid, df);
+    in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
+    f32x16 acc4[4];
+    init_bias<4>(acc4, a.bias + fs_bias_off(FS_RGB0), hi);
+    stage_gemm<4, 20, P, NW>(pipe, acc4, in);
+    acc_to_frags<4, P, ACT_RELU>(acc4, g);
+    if (TRAIN) save_frags<8, P>(a.ws.t[T_G], plane_rows * 128, 128, row, hi, valid, g);
+  }
+  {
+    Frag<P> in[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) in[c] = g[c];
+#pragma unroll
+    for (int c = 8; c < 16; ++c) in[c] = zero_frag<P>();
+    init_bias<1>(acc1, a.bias + fs_bias_off(FS_RGB1), hi);
+    stage_gemm<1, 16, P, NW>(pipe, acc1, in);
+  }
+  if (valid && hi == 0) {
+    float4 o;
+    o.x = 1.f / (1.f + expf(-acc1[0][0]));
+    o.y = 1.f / (1.f + expf(-acc1[0][1]));
+    o.z = 1.f / (1.f + expf(-acc1[0][2]));
+    o.w = sigma_raw;
+    ((float4*)a.out_raw)[row] = o;
+    if (NET == 1) a.depth_real[row] = depth_real;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (dX chain).  d_out[row] = (d rgb_pre-sigmoid[3], d sigma_raw)
+// ------------------------------------------------------------------------------------------------
+template <int NET, int P, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5;
+  const size_t row_raw = (size_t)blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
+  const bool valid = row_raw < (size_t)a.rows;
+  const size_t row = valid ? row_raw : (size_t)a.rows - 1;
+  const size_t plane_rows = a.rows_padded;
+
+  WeightPipe<P, NW> pipe;
+  pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
+
+  float4 d = ((const float4*)a.d_out)[row];
+  if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // B0: dG = Wrgb1^T dP, masked by G > 0
+  Frag<P> dg[8];
+  {
+    Frag<P> in[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) in[c] = zero_frag<P>();
+    if (hi == 0) { set_slot<P>(in[0], 0, d.x); set_slot<P>(in[0], 1, d.y); set_slot<P>(in[0], 2, d.z); }
+    {
+      Frag<P> dp[2] = {in[0], in[1]};
+      save_frags<2, P>(a.ws.t[T_DP], plane_rows * 32, 32, row, hi, valid, dp);
+    }
+    f32x16 acc4[4];
+    init_zero<4>(acc4);
+    stage_gemm<4, 4, P, NW>(pipe, acc4, in);
+    mask_to_frags<4, P>(acc4, a.ws.t[T_G], 128, row, hi, dg);
+    save_frags<8, P>(a.ws.t[T_DG], plane_rows * 128, 128, row, hi, valid, dg);
+  }
+  f32x16 acc[8];
+  Frag<P> dz[16];
+  // B1: dR = Wrgb0[:, :256]^T dG  (no activation on the remap layer)
+  init_zero<8>(acc);
+  stage_gemm<8, 8, P, NW>(pipe, acc, dg);
+  acc_to_frags<8, P, ACT_NONE>(acc, dz);
+  save_frags<16, P>(a.ws.t[T_DR], plane_rows * 256, 256, row, hi, valid, dz);
+  // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
+  {
+    Frag<P> in[18];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) in[c] = dz[c];
+    in[16] = zero_frag<P>(); in[17] = zero_frag<P>();
+    if (hi == 0) set_slot<P>(in[16], 0, d.w);
+    {
+      Frag<P> ds[2] = {in[16], in[17]};
+      save_frags<2, P>(a.ws.t[T_DS], plane_rows * 32, 32, row, hi, valid, ds);
+    }
+    init_zero<8>(acc);
+    stage_gemm<8, 18, P, NW>(pipe, acc, in);
+    mask_to_frags<8, P>(acc, a.ws.t[T_H0 + 7], 256, row, hi, dz);
+    save_frags<16, P>(a.ws.t[T_DZ0 + 7], plane_rows * 256, 256, row, hi, valid, dz);
+  }
+  // B3..B9: dH_{l-1} = W_l^T dZ_l, l = 7..1
+  for (int l = 7; l >= 1; --l) {
+    init_zero<8>(acc);
+    stage_gemm<8, 16, P, NW>(pipe, acc, dz);
+    mask_to_frags<8, P>(acc, a.ws.t[T_H0 + l - 1], 256, row, hi, dz);
+    save_frags<16, P>(a.ws.t[T_DZ0 + l - 1], plane_rows * 256, 256, row, hi, valid, dz);
+  }
+}
+
+}  // namespace nerfpp
+
+using namespace nerfpp;
+
+template <int NET, int P, bool TRAIN>
+static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
+  constexpr int NW = (P == 1) ? 8 : 4;
+  const int tile = NW * 32;
+  const int grid = (int)((a.rows + tile - 1) / tile);
+  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES;
+  hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
+}
+template <int NET, int P>
+static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a) {
+  constexpr int NW = (P == 1) ? 8 : 4;
+  const int tile = NW * 32;
+  const int grid = (int)((a.rows + tile - 1) / tile);
+  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES;
+  hipLaunchKernelGGL((mlp_bwd_kernel<NET, P, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
+}
+
+void launch_mlp_fwd(hipStream_t st, int net, int P, bool train, const MlpFwdArgs& a) {
+  if (net == 0) {
+    if (P == 1) { if (train) launch_fwd_t<0, 1, true>(st, a); else launch_fwd_t<0, 1, false>(st, a); }
+    else        { if (train) launch_fwd_t<0, 2, true>(st, a); else launch_fwd_t<0, 2, false>(st, a); }
+  } else {
+    if (P == 1) { if (train) launch_fwd_t<1, 1, true>(st, a); else launch_fwd_t<1, 1, false>(st, a); }
+    else        { if (train) launch_fwd_t<1, 2, true>(st, a); else launch_fwd_t<1, 2, false>(st, a); }
+  }
+}
+void launch_mlp_bwd(hipStream_t st, int net, int P, const MlpBwdArgs& a) {
+  if (net == 0) { if (P == 1) launch_bwd_t<0, 1>(st, a); else launch_bwd_t<0, 2>(st, a); }
+  else          { if (P == 1) launch_bwd_t<1, 1>(st, a); else launch_bwd_t<1, 2>(st, a); }
+}
+int mlp_tile_rows(int P) { return ((P == 1) ? 8 : 4) * 32; }

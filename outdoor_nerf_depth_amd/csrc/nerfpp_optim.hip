@@ -1,0 +1,84 @@
+// Parameter-side kernels: weight packing into MFMA fragment streams, gradient un-packing
+// (deterministic sum over the split-K slabs + internal -> reference order), Adam.
+// Adam follows torch.optim.Adam's single-tensor update exactly (lr 5e-4, betas (0.9, 0.999),
+// eps 1e-8 in the reference: ddp_train_nerf.py:324).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nerfpp_common.h"
+#include "nerfpp_kernels.h"
+
+namespace nerfpp {
+
+template <int P>
+__global__ void pack_kernel(const float* __restrict__ params, const int32_t* __restrict__ tbl, int64_t n,
+                            __bf16* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int32_t src = tbl[e];
+  const float v = src >= 0 ? params[src] : 0.f;
+  const int64_t F = e >> 9, within = e & 511;
+  const __bf16 h = (__bf16)v;
+  out[(F * P) * 512 + within] = h;
+  if (P == 2) out[(F * P + 1) * 512 + within] = (__bf16)(v - (float)h);
+}
+
+__global__ void gather_f32_kernel(const float* __restrict__ params, const int32_t* __restrict__ tbl, int64_t n,
+                                  float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int32_t src = tbl[e];
+  out[e] = src >= 0 ? params[src] : 0.f;
+}
+
+__global__ void unpack_grads_kernel(const float* __restrict__ slabs, int ksplit, int64_t slab_floats,
+                                    const int32_t* __restrict__ tbl, int64_t n, float scale,
+                                    float* __restrict__ grads) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t src = tbl[i];
+  float acc = 0.f;
+  for (int s = 0; s < ksplit; ++s) acc += slabs[(size_t)s * slab_floats + src];
+  grads[i] = acc * scale;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
+                            float step_size, float sqrt_bias2, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float mi = m[i], vi = v[i];
+  mi = mi + (gi - mi) * one_minus_b1;                   // exp_avg.lerp_(grad, 1 - beta1)
+  vi = vi * b2 + one_minus_b2 * gi * gi;                // exp_avg_sq.mul_(beta2).addcmul_(...)
+  const float denom = sqrtf(vi) / sqrt_bias2 + eps;      // (sqrt(v) / sqrt(bias2)).add_(eps)
+  p[i] = p[i] - step_size * (mi / denom);
+  m[i] = mi;
+  v[i] = vi;
+}
+
+}  // namespace nerfpp
+
+using namespace nerfpp;
+
+void launch_pack(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, int P, void* out) {
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (P == 1) hipLaunchKernelGGL(pack_kernel<1>, grid, block, 0, st, params, tbl, n, (__bf16*)out);
+  else hipLaunchKernelGGL(pack_kernel<2>, grid, block, 0, st, params, tbl, n, (__bf16*)out);
+}
+void launch_gather_f32(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, float* out) {
+  hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, tbl, n, out);
+}
+void launch_unpack_grads(hipStream_t st, const float* slabs, int ksplit, int64_t slab_floats, const int32_t* tbl,
+                         int64_t n_params, float scale, float* grads) {
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, slabs,
+                     ksplit, slab_floats, tbl, n_params, scale, grads);
+}
+void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
+                 double beta1, double beta2, double eps) {
+  const double bias1 = 1.0 - pow(beta1, step), bias2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bias1);
+  const float sqrt_bias2 = (float)sqrt(bias2);
+  // 1 - beta is formed in double like Python does, then rounded once (1.f - 0.9f != (float)0.1)
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, sqrt_bias2, (float)eps);
+}

