@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: NeRF++ training ray-steps per second on synthetic KITTI-shaped batches.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one optimisation step of nerf-methods/nerfplusplus/ddp_train_nerf.py:417-498 for
+N_rand rays per GPU: stratified + inverse-CDF sampling, both cascade levels (64 and 64+128 samples
+per ray, fg + bg networks), loss (depth_sup_type=gt, depth_loss_type=mse, lambda_depth=0.1 =
+BASELINE config 2), backward, gradient all-reduce (N > 1) and Adam.  Ray batches are resident in HBM
+before the timed region.  Prints ONE JSON line (rank 0).
+
+value            : single-pass bf16 MFMA (the arithmetic north_star names), rays/s over all GPUs
+parity_mode      : the same step in split-bf16 precision (3 MFMA passes), the mode the 1e-4 parity
+                   tests run in -- both numbers come from the same invocation
+roofline         : dominant kernel of the bf16 run, timed live with HIP events on its stream
+cpu_baseline     : the numpy oracle (a port of the reference's PyTorch path) on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--n_rand', type=int, default=1024, help='rays per GPU per step (reference forces 1024)')
+    p.add_argument('--precision', choices=['both', 'bf16', 'split'], default='both')
+    p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--cpu_rays', type=int, default=128)
+    return p.parse_args()
+
+
+def run_mode(args, precision, rank, world, device, batches):
+    import torch
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer, ALGO_MACS
+    from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
+
+    scale = float(SyntheticKitti().depth_scale)
+    tr = NerfppTrainer(device, precision=precision, use_depth=True, depth_loss_type='mse', lambda_depth=0.1,
+                       depth_scale=scale, world_size=world)
+    K, W = args.steps, args.warmup
+    mk = lambda: torch.cuda.Event(enable_timing=True)
+    events = []
+    for _ in range(K):
+        per_level = []
+        for _m in range(2):
+            ev = {'fwd': (mk(), mk()), 'bwd': (mk(), mk(), mk(), mk())}
+            for e in ev['fwd'] + ev['bwd']:
+                e.record()                       # materialise the hipEvent_t handles
+            per_level.append(ev)
+        events.append(per_level)
+    for i in range(W):
+        tr.train_step(batches[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(K):
+        last = tr.train_step(batches[W + i], events=events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = [float(s[0]) for s in last]
+    assert all(np.isfinite(loss)), 'non-finite loss %r' % (loss,)
+
+    # live per-kernel timing (ms) of the level-1 foreground kernels + the weight-gradient GEMM
+    n, S1 = args.n_rand, 192
+    rows = n * S1
+    med = lambda xs: float(np.median(xs))
+    fwd_ms = med([events[i][1]['fwd'][0].elapsed_time(events[i][1]['fwd'][1]) for i in range(K)])
+    bwd_ms = med([events[i][1]['bwd'][0].elapsed_time(events[i][1]['bwd'][1]) for i in range(K)])
+    dw_ms = med([events[i][1]['bwd'][2].elapsed_time(events[i][1]['bwd'][3]) for i in range(K)])
+    kernels = {
+        'mlp_fwd_fg_L1': dict(ms=fwd_ms, flop=2.0 * ALGO_MACS['fwd'][0] * rows),
+        'mlp_bwd_fg_L1': dict(ms=bwd_ms, flop=2.0 * ALGO_MACS['dx'][0] * rows),
+        'dw_both_L1': dict(ms=dw_ms, flop=2.0 * (ALGO_MACS['fwd'][0] + ALGO_MACS['fwd'][1]) * rows),
+    }
+    for k in kernels.values():
+        k['tflops'] = k['flop'] / (k['ms'] * 1e-3) / 1e12
+    # per-step share: fwd and bwd kernels run for fg and bg at both levels, dw once per level
+    share = {'mlp_fwd_fg_L1': fwd_ms * 2 * (1 + 64.0 / 192), 'mlp_bwd_fg_L1': bwd_ms * 2 * (1 + 64.0 / 192),
+             'dw_both_L1': dw_ms * (1 + 64.0 / 192)}
+    dominant = max(share, key=share.get)
+    return dict(elapsed=elapsed, ms_per_step=1e3 * elapsed / K, value=n * K * world / elapsed, loss=loss,
+                kernels=kernels, dominant=dominant, share_ms=share)
+
+
+def cpu_baseline(args):
+    """The numpy oracle (a port of the reference's PyTorch-CPU path, validated against it in
+    tests/test_oracle_golden.py) on a bounded sample: cpu_rays rays, both levels, fwd+bwd+Adam."""
+    from oracle import nerfpp_oracle as O
+    from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
+    n = args.cpu_rays
+    levels = O.init_params_like_reference(2)
+    opt = O.new_opt_state(levels)
+    scene = SyntheticKitti(depth_sup_type='gt')
+    rng = np.random.RandomState(777)
+    times = []
+    for step in range(1, 4):
+        b = scene.random_batch(n, rng)
+        uni = dict(t_fg=rng.rand(n, 64).astype(np.float32), t_bg=rng.rand(n, 64).astype(np.float32),
+                   u_fg=rng.rand(n, 128).astype(np.float32), u_bg=rng.rand(n, 128).astype(np.float32))
+        t0 = time.perf_counter()
+        O.train_step(levels, opt, step, b, uni, use_depth=True, depth_loss_type='mse', lambda_depth=0.1)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return dict(value=n / t, unit='rays/s', cores=os.cpu_count(), kind='port',
+                sample='%d rays/step, 1 warm-up + 2 timed steps, both levels fwd+bwd+Adam, float32 numpy '
+                       '(OpenBLAS threads = all host cores)' % n)
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the NeRF++ hot path has no CPU fallback'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
+    from outdoor_nerf_depth_amd.trainer import batch_to_device
+    from outdoor_nerf_depth_amd import _lib as L
+    scene = SyntheticKitti(depth_sup_type='gt')
+    rng = np.random.RandomState((rank + 1) * 777)                 # ddp_train_nerf.py:406
+    torch.manual_seed((rank + 1) * 777)                           # :408
+    batches = [batch_to_device(scene.random_batch(args.n_rand, rng), device)
+               for _ in range(args.steps + args.warmup)]
+
+    res = {}
+    if args.precision in ('both', 'bf16'):
+        res['bf16'] = run_mode(args, L.PREC_BF16, rank, world, device, batches)
+    if args.precision in ('both', 'split'):
+        res['split'] = run_mode(args, L.PREC_SPLIT_BF16, rank, world, device, batches)
+    if rank != 0:
+        return
+    main_key = 'bf16' if 'bf16' in res else 'split'
+    r = res[main_key]
+    dom = r['kernels'][r['dominant']]
+    out = {
+        'metric': 'train rays/sec, KITTI 375x1242, 64+128 samples/ray',
+        'value': r['value'], 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16 MFMA operands, f32 accumulate / f32 master weights' if main_key == 'bf16'
+                 else 'split-bf16 (hi+lo, 3 MFMA passes), f32 accumulate',
+        'data': 'synthetic',
+        'config': {'workload': 'NeRF++ KITTI seq00-shaped (295 fr, 375x1242), depth_sup_type=gt, '
+                               'depth_loss_type=mse, lambda_depth=0.1, N_rand=%d rays/GPU/step, cascade 64+128, '
+                               'both levels fwd+bwd+Adam' % args.n_rand,
+                   'n_rand_per_gpu': args.n_rand, 'parallelism': 'dp%d (ray batches, RCCL grad all-reduce)' % world},
+        'roofline': {'bound': 'mfma', 'kernel': r['dominant'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None,
+                     'launch_ms': dom['ms'],
+                     'all_kernels': {k: {'ms': round(v['ms'], 4), 'tflops': round(v['tflops'], 2)}
+                                     for k, v in r['kernels'].items()}},
+        'final_loss': r['loss'],
+    }
+    if 'split' in res and main_key != 'split':
+        s = res['split']
+        out['parity_mode'] = {'dtype': 'split-bf16 (hi+lo, 3 MFMA passes): the precision the 1e-4 parity tests use',
+                              'value': s['value'], 'ms_per_step': s['ms_per_step'],
+                              'kernels': {k: {'ms': round(v['ms'], 4), 'tflops': round(v['tflops'], 2)}
+                                          for k, v in s['kernels'].items()}}
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -128,6 +128,10 @@ typedef struct {
   float* bg_rgb;                   /* [n,3] */
   float* bg_depth;                 /* [n]   */
   float* bg_lambda;                /* [n]   */
+  /* optional profiling taps: hipEvent_t handles (or NULL) recorded on `stream` immediately before
+   * and after the foreground-net MLP kernel, so a caller can time that kernel live */
+  void* ev_mlp_begin;
+  void* ev_mlp_end;
 } nerfpp_forward_args;
 
 /* ret = net(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)          ddp_model.py:74-147 */
@@ -157,6 +161,12 @@ typedef struct {
   const float* g_fg_weights;       /* [n,S] dL/d fg_weights or NULL */
   float grad_scale;                /* multiplies every gradient (1/world_size pre-scaling) */
   float* grads;                    /* [NERFPP_LEVEL_PARAMS] dL/d params, parameters() order */
+  /* optional profiling taps (hipEvent_t or NULL): around the foreground dX-chain kernel and around
+   * the weight-gradient GEMM kernel */
+  void* ev_bwd_begin;
+  void* ev_bwd_end;
+  void* ev_dw_begin;
+  void* ev_dw_end;
 } nerfpp_backward_args;
 
 /* loss.backward() for one level (autograd in the reference)         ddp_train_nerf.py:497 */

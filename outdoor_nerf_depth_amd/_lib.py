@@ -26,7 +26,8 @@ class ForwardArgs(C.Structure):
                 ('training', C.c_int32)] + \
                [(k, _fp) for k in ('ray_o', 'ray_d', 'fg_far', 'fg_z', 'bg_z', 'packed', 'workspace',
                                    'rgb', 'depth', 'fg_weights', 'bg_weights', 'fg_dists', 'fg_rgb',
-                                   'fg_depth', 'bg_rgb', 'bg_depth', 'bg_lambda')]
+                                   'fg_depth', 'bg_rgb', 'bg_depth', 'bg_lambda', 'ev_mlp_begin',
+                                   'ev_mlp_end')]
 
 
 class BackwardArgs(C.Structure):
@@ -34,7 +35,8 @@ class BackwardArgs(C.Structure):
                 ('reserved', C.c_int32)] + \
                [(k, _fp) for k in ('ray_d', 'fg_far', 'fg_z', 'bg_z', 'packed', 'workspace', 'tables',
                                    'g_rgb', 'g_depth', 'g_fg_weights')] + \
-               [('grad_scale', C.c_float), ('grads', _fp)]
+               [('grad_scale', C.c_float), ('grads', _fp)] + \
+               [(k, _fp) for k in ('ev_bwd_begin', 'ev_bwd_end', 'ev_dw_begin', 'ev_dw_end')]
 
 
 # every symbol include/nerfpp_hip.h declares: name -> (restype, argtypes)

@@ -215,7 +215,9 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     m.out_raw = (float*)(ws + L.out_raw[net]);
     m.depth_real = (float*)(ws + L.depth_real);
     if (train) m.ws = make_netws(ws, L, net);
+    if (net == 0 && a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
     launch_mlp_fwd(st, net, P, train, m);
+    if (net == 0 && a->ev_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_mlp_end, st);
   }
   launch_composite_fwd(st, a->n_rays, a->n_samples, (const float*)(ws + L.out_raw[0]),
                        (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
@@ -263,14 +265,18 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
     m.w_stream = pk + PL.bwd[net];
     m.d_out = (const float*)(ws + L.d_out[net]);
     m.ws = make_netws(ws, L, net);
+    if (net == 0 && a->ev_bwd_begin) (void)hipEventRecord((hipEvent_t)a->ev_bwd_begin, st);
     launch_mlp_bwd(st, net, P, m);
+    if (net == 0 && a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);
     dw.ws[net] = m.ws;
     dw.slabs[net] = (float*)(ws + L.slabs[net]);
   }
   dw.rows = L.rows;
   dw.rows_padded = L.rows_padded;
   dw.ksplit = L.ksplit;
+  if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
   launch_dw(st, P, dw);
+  if (a->ev_dw_end) (void)hipEventRecord((hipEvent_t)a->ev_dw_end, st);
   for (int net = 0; net < N_NET; ++net)
     launch_unpack_grads(st, dw.slabs[net], L.ksplit, gslab_floats(net), a->tables + T.unpack[net],
                         net_params(net), a->grad_scale, a->grads + (net == 0 ? 0 : FG_PARAMS));

@@ -172,7 +172,7 @@ class LevelEngine(object):
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self.workspace
 
-    def forward(self, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, training=False):
+    def forward(self, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, training=False, events=None):
         """ret = net(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)      ddp_model.py:74-147"""
         ray_o, ray_d = _f32(ray_o), _f32(ray_d)
         n = ray_o.shape[0]
@@ -193,12 +193,14 @@ class LevelEngine(object):
         a.workspace = self._workspace(n, S, training).data_ptr()
         for k in RET_KEYS:
             setattr(a, k, out[k].data_ptr())
+        if events is not None:          # (begin, end) torch.cuda.Event pair around the fg MLP kernel
+            a.ev_mlp_begin, a.ev_mlp_end = events[0].cuda_event, events[1].cuda_event
         L.check(L.lib().nerfpp_level_forward(_stream(), C.byref(a)), 'nerfpp_level_forward')
         if training:
             self._fwd = (n, S, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
         return out
 
-    def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None):
+    def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None, events=None):
         """Gradient of the loss w.r.t. the flat parameters given dL/d rgb, dL/d depth and (KL)
         dL/d fg_weights, for the last training-mode forward."""
         if self._fwd is None:
@@ -215,6 +217,8 @@ class LevelEngine(object):
         a.g_fg_weights = g_fg_weights.data_ptr() if g_fg_weights is not None else None
         a.grad_scale = float(grad_scale)
         a.grads = grads.data_ptr()
+        if events is not None:          # (bwd begin, bwd end, dw begin, dw end)
+            a.ev_bwd_begin, a.ev_bwd_end, a.ev_dw_begin, a.ev_dw_end = [e.cuda_event for e in events]
         L.check(L.lib().nerfpp_level_backward(_stream(), C.byref(a)), 'nerfpp_level_backward')
         return grads
 

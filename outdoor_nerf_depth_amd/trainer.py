@@ -1,0 +1,127 @@
+"""Per-rank optimisation step of the NeRF++ path on the HIP library.
+
+Mirrors the per-cascade-level loop of nerf-methods/nerfplusplus/ddp_train_nerf.py:432-498:
+level 0 draws stratified depths, level 1 re-samples from level 0's (detached) weights; each level
+has its own net, its own Adam state and its own gradient all-reduce (DDP averages gradients,
+:323); the depth term is added when --use_depth (:486-493).
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .model import init_level_params
+
+ALGO_MACS = {            # dense MACs per sample (SURVEY.md 8a / BASELINE.md section 2)
+    'fwd': (593408, 604160),         # fg, bg forward (= weight-gradient MACs)
+    'dx': (557696, 557696),          # backward dX chain (no dX for L0, raw-input part of L5, dirs)
+}
+
+
+class NerfppTrainer(object):
+    def __init__(self, device, precision=L.PREC_SPLIT_BF16, cascade_samples=(64, 128), lrate=5e-4,
+                 use_depth=True, depth_loss_type='mse', lambda_depth=0.1, depth_sigma=0.01, depth_scale=1.0,
+                 world_size=1, level_params=None, overlap_allreduce=True):
+        self.device = torch.device(device)
+        self.precision = precision
+        self.cascade_samples = tuple(cascade_samples)
+        self.lrate = lrate
+        self.loss_type = depth_loss_type if use_depth else 'rgbonly'
+        if self.loss_type not in L.LOSS_TYPES:
+            raise ValueError("depth_loss_type %r: only mse / l1 / kl exist in the reference "
+                             "('los' and 'nll' are dead code there)" % depth_loss_type)
+        self.lambda_depth = lambda_depth
+        self.kl_sigma = depth_sigma * depth_scale           # ddp_train_nerf.py:489
+        self.world_size = world_size
+        if level_params is None:
+            level_params = init_level_params(len(self.cascade_samples))   # manual_seed(777), :308
+        self.engines = [ops.LevelEngine(p.to(self.device), precision) for p in level_params]
+        self.exp_avg = [torch.zeros_like(e.params) for e in self.engines]
+        self.exp_avg_sq = [torch.zeros_like(e.params) for e in self.engines]
+        self.grads = [torch.empty_like(e.params) for e in self.engines]
+        self.step_count = 0
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (world_size > 1 and overlap_allreduce) else None
+        self._pending = None
+
+    # -- distributed -------------------------------------------------------------------------------
+    def _allreduce_begin(self, m):
+        """Average gradients over ranks (DDP semantics).  grads were pre-scaled by 1/world_size in
+        the backward kernel, so a SUM all-reduce yields the mean.  Runs on a side stream so level
+        0's reduction overlaps level 1's sampling + forward."""
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+        if self.comm_stream is None:
+            dist.all_reduce(self.grads[m])
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(self.grads[m])
+            done = torch.cuda.Event()
+            done.record()
+        self._pending = (m, done)
+
+    def _allreduce_end(self, m):
+        if self._pending is not None and self._pending[0] == m:
+            torch.cuda.current_stream().wait_event(self._pending[1])
+            self._pending = None
+
+    def _apply(self, m):
+        self._allreduce_end(m)
+        eng = self.engines[m]
+        ops.adam_step(eng.params, self.grads[m], self.exp_avg[m], self.exp_avg_sq[m], self.step_count,
+                      lr=self.lrate)
+        eng.repack()
+
+    # -- one optimisation step ----------------------------------------------------------------------
+    def train_step(self, batch, uniforms=None, events=None):
+        """batch: dict of device tensors ray_o, ray_d, rgb, min_depth, [depth_sup].
+        uniforms: optional dict t_fg, t_bg [N,S0], u_fg, u_bg [N,S1] (replay); else torch.rand in the
+        reference's call order.  events: optional per-level dict of torch.cuda.Event taps.
+        Returns per-level scalar tensors [loss, rgb_loss, depth_loss, n_valid] (device, no sync)."""
+        self.step_count += 1
+        ray_o, ray_d = batch['ray_o'], batch['ray_d']
+        n = ray_o.shape[0]
+        S0, S1 = self.cascade_samples[0], self.cascade_samples[1] if len(self.cascade_samples) > 1 else 0
+        dev = self.device
+        u = uniforms or {}
+        t_fg = u['t_fg'] if 't_fg' in u else torch.rand(n, S0, device=dev)
+        t_bg = u['t_bg'] if 't_bg' in u else torch.rand(n, S0, device=dev)
+        far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, batch['min_depth'], S0, t_fg, t_bg, check=False)
+        depth_sup = batch.get('depth_sup') if self.loss_type != 'rgbonly' else None
+        scalars = []
+        ret = None
+        deferred = None
+        for m, eng in enumerate(self.engines):
+            if m > 0:
+                u_fg = u['u_fg'] if 'u_fg' in u else torch.rand(n, S1, device=dev)
+                u_bg = u['u_bg'] if 'u_bg' in u else torch.rand(n, S1, device=dev)
+                fg_z = ops.sample_fine(fg_z, ret['fg_weights'], S1, u=u_fg)
+                bg_z = ops.sample_fine(bg_z, ret['bg_weights'], S1, u=u_bg)
+            ev = events[m] if events is not None else None
+            ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True,
+                              events=ev['fwd'] if ev else None)
+            sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, batch['rgb'], depth_sup, self.loss_type,
+                                                         self.lambda_depth, self.kl_sigma, fg_z, far)
+            eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m],
+                         events=ev['bwd'] if ev else None)
+            scalars.append(sc)
+            if deferred is not None:              # level m-1's Adam after level m's work was queued
+                self._apply(deferred)
+                deferred = None
+            self._allreduce_begin(m)
+            if self.world_size > 1 and self.comm_stream is not None and m + 1 < len(self.engines):
+                deferred = m                      # overlap this level's all-reduce with the next level
+            else:
+                self._apply(m)
+        return scalars
+
+
+def batch_to_device(b, device):
+    out = {}
+    for k, v in b.items():
+        if isinstance(v, np.ndarray):
+            out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device)
+    return out

@@ -187,8 +187,11 @@ def test_losses_match_reference(ops, golden):
 
 
 # ----------------------------------------------------------------------------------------- backward
-GRAD_TOL = {2: 5e-2, 1: 0.25}      # max |diff| / RMS of the tensor (float32 reference noise is ~1e-1, see
-                                   # tests/test_oracle_golden.py::test_level_gradients)
+# max |diff| / RMS of the tensor, and relative L2 error over the sampled entries.  The float32
+# reference itself is ~1e-1*RMS noisy on these cancelling sums (tests/test_oracle_golden.py::
+# test_level_gradients), so the comparison is against the float64 run of the reference.  Single-pass
+# bf16 (8 mantissa bits) is expected to be ~10x noisier than split-bf16.
+GRAD_TOL = {2: (5e-2, 2e-2), 1: (1.5, 0.25)}
 
 
 @pytest.mark.parametrize('prec', [2, 1])
@@ -211,7 +214,12 @@ def test_level_gradients_match_reference(ops, golden, levels, mode, prec):
             ref64 = g['L%d.%s.g64' % (m, k)]
             rms = g['L%d.%s.norm64' % (m, k)] / np.sqrt(grads[k].size) + 1e-12
             err = np.abs(mine - ref64).max() / rms
-            assert err <= GRAD_TOL[prec], (k, m, err)
+            rel_l2 = np.linalg.norm(mine - ref64) / (np.linalg.norm(ref64) + 1e-30)
+            assert err <= GRAD_TOL[prec][0], (k, m, err)
+            # 1- and 3-element tensors (sigma / rgb biases) are single cancelling sums: the oracle
+            # itself is 3e-2 off there (tests/test_oracle_golden.py), allow 3x the bound
+            l2_tol = GRAD_TOL[prec][1] * (3 if mine.size <= 3 else 1)
+            assert rel_l2 <= l2_tol or err <= 1e-3, (k, m, rel_l2)
             n_mine = np.linalg.norm(grads[k].astype(np.float64))
             assert abs(n_mine - g['L%d.%s.norm64' % (m, k)]) <= (0.06 if prec == 2 else 0.3) * g['L%d.%s.norm64' % (m, k)] + 1e-12, k
 
@@ -230,7 +238,9 @@ def test_backward_matches_oracle_elementwise(ops, golden, levels):
     grads = unflat(N(eng.backward(T(o_rgb), T(o_depth), None)))
     for k in O.param_order():
         rms = np.sqrt((g_o[k].astype(np.float64) ** 2).mean()) + 1e-12
-        assert np.abs(grads[k] - g_o[k]).max() <= 3e-2 * rms, k
+        assert np.abs(grads[k] - g_o[k]).max() <= 8e-2 * rms, (k, np.abs(grads[k] - g_o[k]).max() / rms)
+        rel = np.linalg.norm(grads[k] - g_o[k]) / (np.linalg.norm(g_o[k]) + 1e-30)
+        assert rel <= (6e-2 if grads[k].size <= 3 else 1e-2), (k, rel)
     # linearity of the backward in the upstream gradients
     g2 = unflat(N(eng.backward(T(2 * o_rgb), T(2 * o_depth), None)))
     for k in ('fg_net.base_layers.3.0.weight', 'bg_net.rgb_layers.0.weight'):
