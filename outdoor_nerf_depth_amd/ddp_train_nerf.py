@@ -1,0 +1,378 @@
+#!/usr/bin/env python
+"""Drop-in entry point for nerf-methods/nerfplusplus/ddp_train_nerf.py on MI355X.
+
+    python -m outdoor_nerf_depth_amd.ddp_train_nerf --config configs/kitti.txt \
+        --use_depth --depth_sup_type gt --depth_loss_type mse --lambda_depth 0.1 --trainskip 4 ...
+
+Same flags and defaults as the reference's `config_parser` (:657-727), same outputs under
+{basedir}/{expname}/ (args.txt, config.txt, model_{step:06d}.pth with the reference's state-dict
+keys, render_test_{step:06d}/ + psnr_/rmse_/absrel_*.txt), same log scalars
+(`level_m/{rgb_loss,pnsr,loss_depth}`, `iter_time`, `resolution`).  The per-step work runs on the
+HIP library (trainer.py); one process per GPU, RCCL all-reduce of the flat gradients.
+
+Extra flags: --sample_every (the README's name for --trainskip), --precision {bf16,split},
+--synthetic (KITTI-shaped procedural scene instead of --datadir), --N_rand_override.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+logger = logging.getLogger(__package__ or 'outdoor_nerf_depth_amd')
+TINY_NUMBER = 1e-6
+mse2psnr = lambda x: -10. * np.log(x + TINY_NUMBER) / np.log(10.)           # utils.py:31
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+def setup_logger():
+    lg = logging.getLogger(__package__ or 'outdoor_nerf_depth_amd')
+    lg.setLevel(logging.INFO)
+    if not lg.handlers:
+        ch = logging.StreamHandler()
+        ch.setFormatter(logging.Formatter('%(asctime)s [%(levelname)s] %(name)s: %(message)s'))
+        lg.addHandler(ch)
+
+
+class ConfigFileParser(argparse.ArgumentParser):
+    """argparse + the `key = value` config file of configargparse (--config, command line wins)."""
+
+    def parse_args(self, args=None, namespace=None):
+        args = list(sys.argv[1:] if args is None else args)
+        pre, _ = argparse.ArgumentParser(add_help=False).parse_known_args([])
+        cfg = None
+        for i, a in enumerate(args):
+            if a == '--config' and i + 1 < len(args):
+                cfg = args[i + 1]
+            elif a.startswith('--config='):
+                cfg = a.split('=', 1)[1]
+        file_args = []
+        if cfg and cfg != 'None':
+            known = {a.dest: a for a in self._actions}
+            for line in open(cfg):
+                line = line.split('#', 1)[0].strip()
+                if not line or '=' not in line:
+                    continue
+                k, v = [x.strip() for x in line.split('=', 1)]
+                if k == 'config' or k not in known or v == 'None':
+                    continue
+                act = known[k]
+                if isinstance(act, argparse._StoreTrueAction):
+                    if v.lower() in ('true', '1', 'yes'):
+                        file_args.append('--' + k)
+                else:
+                    file_args += ['--' + k, v]
+        return super().parse_args(file_args + args, namespace)
+
+
+def config_parser():
+    """Flag for flag the reference's parser (ddp_train_nerf.py:657-727)."""
+    p = ConfigFileParser()
+    p.add_argument('--config', type=str, default=None, help='config file path')
+    p.add_argument('--expname', type=str, help='experiment name')
+    p.add_argument('--basedir', type=str, default='./logs/', help='where to store ckpts and logs')
+    p.add_argument('--datadir', type=str, default=None, help='input data directory')
+    p.add_argument('--scene', type=str, default=None, help='scene name')
+    p.add_argument('--testskip', type=int, default=8)
+    p.add_argument('--trainskip', '--sample_every', dest='trainskip', type=int, default=1,
+                   help='will load 1/N images from train sets for sparse inputs')
+    p.add_argument('--netdepth', type=int, default=8)
+    p.add_argument('--netwidth', type=int, default=256)
+    p.add_argument('--use_viewdirs', action='store_true')
+    p.add_argument('--no_reload', action='store_true')
+    p.add_argument('--ckpt_path', type=str, default=None)
+    p.add_argument('--N_rand', type=int, default=32 * 32 * 2)
+    p.add_argument('--chunk_size', type=int, default=1024 * 8)
+    p.add_argument('--N_iters', type=int, default=250001)
+    p.add_argument('--render_splits', type=str, default='test')
+    p.add_argument('--cascade_level', type=int, default=2)
+    p.add_argument('--cascade_samples', type=str, default='64,64')
+    p.add_argument('--world_size', type=int, default=-1)
+    p.add_argument('--optim_autoexpo', action='store_true')
+    p.add_argument('--lambda_autoexpo', type=float, default=1.)
+    p.add_argument('--lrate', type=float, default=5e-4)
+    p.add_argument('--lrate_decay_factor', type=float, default=0.1)      # parsed, never read (as upstream)
+    p.add_argument('--lrate_decay_steps', type=int, default=5000)        # parsed, never read
+    p.add_argument('--det', action='store_true')                         # parsed, never read
+    p.add_argument('--max_freq_log2', type=int, default=10)
+    p.add_argument('--max_freq_log2_viewdirs', type=int, default=4)
+    p.add_argument('--load_min_depth', action='store_true')
+    p.add_argument('--i_print', type=int, default=100)
+    p.add_argument('--i_img', type=int, default=500)                     # parsed, never read
+    p.add_argument('--i_weights', type=int, default=10000)
+    p.add_argument('--use_depth', action='store_true')
+    p.add_argument('--lambda_depth', type=float, default=1.0)
+    p.add_argument('--depth_loss_type', choices=['mse', 'kl', 'los', 'l1', 'nll'], default='mse')
+    p.add_argument('--depth_sup_type', type=str, default='gt')
+    p.add_argument('--depth_sigma', type=float, default=0.01)
+    p.add_argument('--port', type=int, default=12345)
+    # --- additions of this implementation
+    p.add_argument('--precision', choices=['bf16', 'split'], default='split',
+                   help='MLP arithmetic: single-pass bf16 MFMA or split-bf16 (1e-4 parity with float32)')
+    p.add_argument('--synthetic', action='store_true', help='KITTI-shaped procedural scene, no datadir')
+    p.add_argument('--synthetic_hw', type=str, default=None, help="'H,W' of the synthetic frames (default 375,1242)")
+    p.add_argument('--synthetic_frames', type=int, default=295)
+    p.add_argument('--N_rand_override', type=int, default=None,
+                   help='the reference overrides N_rand to 1024 on >14 GB GPUs; this overrides that')
+    p.add_argument('--i_test', type=int, default=50000, help='test-set render period (hard-coded 50000 upstream)')
+    return p
+
+
+def validate_args(args):
+    if args.netdepth != 8 or args.netwidth != 256:
+        raise SystemExit('only netdepth=8 / netwidth=256 (the reference configs) are implemented in HIP')
+    if args.max_freq_log2 != 10 or args.max_freq_log2_viewdirs != 4:
+        raise SystemExit('only max_freq_log2=10 / max_freq_log2_viewdirs=4 are implemented in HIP')
+    if args.optim_autoexpo:
+        raise SystemExit('--optim_autoexpo is not implemented (unused by every KITTI/Argoverse config)')
+    if args.use_depth and args.depth_loss_type in ('los', 'nll'):
+        raise SystemExit("depth_loss_type '%s' is dead code in the reference (depth_loss.py:46-76)" %
+                         args.depth_loss_type)
+    if args.cascade_level != 2:
+        raise SystemExit('cascade_level must be 2')
+
+
+# ------------------------------------------------------------------------------------------------
+def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size):
+    """ddp_train_nerf.py:133-249: deterministic sampling, no perturbation, chunked, sharded over ranks
+    (ragged last shard instead of raising when H*W % world_size != 0)."""
+    import torch
+    from . import ops
+    from .dist_utils import shard_sizes, gather_ragged
+    b = ray_sampler.get_all()
+    n = b['ray_d'].shape[0]
+    sizes = shard_sizes(n, world_size)
+    lo = sum(sizes[:rank])
+    dev = trainer.device
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:lo + sizes[rank]])).to(dev)
+    ray_o, ray_d, min_depth = T(b['ray_o']), T(b['ray_d']), T(b['min_depth'])
+    S0, S1 = trainer.cascade_samples
+    keys = ('rgb', 'fg_rgb', 'bg_rgb', 'fg_depth', 'bg_depth', 'bg_lambda', 'depth')
+    out = [OrderedDict((k, []) for k in keys) for _ in range(2)]
+    for s in range(0, sizes[rank], chunk_size):
+        o, d, md = ray_o[s:s + chunk_size], ray_d[s:s + chunk_size], min_depth[s:s + chunk_size]
+        far, fg_z, bg_z = ops.sample_coarse(o, d, md, S0, perturb=False, check=(s == 0))
+        ret = None
+        for m, eng in enumerate(trainer.engines):
+            if m > 0:
+                fg_z = ops.sample_fine(fg_z, ret['fg_weights'], S1, det=True)
+                bg_z = ops.sample_fine(bg_z, ret['bg_weights'], S1, det=True)
+            ret = eng.forward(o, d, far, fg_z, bg_z, training=False)
+            for k in keys:
+                out[m][k].append(ret[k])
+    merged = []
+    for m in range(2):
+        lvl = OrderedDict()
+        for k in keys:
+            t = gather_ragged(torch.cat(out[m][k], 0), sizes, rank, world_size)
+            if rank == 0:
+                lvl[k] = t.cpu().reshape((ray_sampler.H, ray_sampler.W, -1)).squeeze()
+        merged.append(lvl)
+    return merged if rank == 0 else None
+
+
+def save_checkpoint(path, trainer, global_step):
+    """{net_m: state_dict (DDP-prefixed keys), optim_m: Adam state_dict}   ddp_train_nerf.py:642-652"""
+    import torch
+    from .model import state_dict_from_flat, adam_state_dict
+    to_save = OrderedDict()
+    for m, eng in enumerate(trainer.engines):
+        to_save['net_%d' % m] = OrderedDict((k, v.clone().cpu()) for k, v in
+                                            state_dict_from_flat(eng.params).items())
+        to_save['optim_%d' % m] = adam_state_dict(trainer.exp_avg[m].cpu(), trainer.exp_avg_sq[m].cpu(),
+                                                  trainer.step_count, trainer.lrate)
+    torch.save(to_save, path)
+
+
+def load_checkpoint(path, trainer):
+    import torch
+    from .model import load_state_dict_into_flat, load_adam_state_dict
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    for m, eng in enumerate(trainer.engines):
+        load_state_dict_into_flat(eng.params, ck['net_%d' % m])
+        if 'optim_%d' % m in ck:
+            trainer.step_count = load_adam_state_dict(trainer.exp_avg[m], trainer.exp_avg_sq[m], ck['optim_%d' % m])
+        eng.repack()
+
+
+def find_latest_checkpoint(args):
+    """ddp_train_nerf.py:329-352: explicit --ckpt_path, else the newest model_*.pth by trailing integer."""
+    def path2iter(path):
+        tmp = os.path.basename(path)[:-4]
+        return int(tmp[tmp.rfind('_') + 1:])
+    if args.ckpt_path is not None and os.path.isfile(args.ckpt_path):
+        ckpts = [args.ckpt_path]
+    else:
+        d = os.path.join(args.basedir, args.expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith('.pth')] if os.path.isdir(d) else []
+    ckpts = sorted(ckpts, key=path2iter)
+    if ckpts and not args.no_reload:
+        return ckpts[-1], path2iter(ckpts[-1])
+    return None, -1
+
+
+def depth_metrics(pred_depth, sampler):
+    """ddp_train_nerf.py:566-600: cap 80 m, valid 1e-3 < gt < 80, metres = value / depth_scale."""
+    scale = sampler.get_depth_scale()
+    gt = sampler.get_gt_depth_img() / scale
+    pred = pred_depth / scale
+    valid = (gt < 80) & (gt > 1e-3)
+    vg, vp = gt[valid].clip(1e-3, 80), pred[valid].clip(1e-3, 80)
+    return float(np.sqrt(np.mean((vg - vp) ** 2))), float(np.mean(np.abs(vg - vp) / vg))
+
+
+def ddp_train_nerf(rank, args):
+    import torch
+    from .trainer import NerfppTrainer, batch_to_device
+    from .data_loader_split import load_data_split, synthetic_ray_samplers
+    from . import _lib as L
+    setup_logger()
+    world = args.world_size
+    torch.cuda.set_device(rank)
+    device = torch.device('cuda', rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ['MASTER_PORT'] = str(args.port)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL (gloo upstream, :298)
+
+    # batch sizes by GPU memory                                      ddp_train_nerf.py:364-373
+    if torch.cuda.get_device_properties(rank).total_memory / 1e9 > 14:
+        args.N_rand, args.chunk_size = 1024, 8192
+    else:
+        args.N_rand, args.chunk_size = 512, 4096
+    if args.N_rand_override:
+        args.N_rand = args.N_rand_override
+        args.chunk_size = max(args.chunk_size, 8 * args.N_rand_override)
+
+    exp_dir = os.path.join(args.basedir, args.expname)
+    if rank == 0:                                                   # :376-386
+        os.makedirs(exp_dir, exist_ok=True)
+        with open(os.path.join(exp_dir, 'args.txt'), 'w') as f:
+            for arg in sorted(vars(args)):
+                f.write('{} = {}\n'.format(arg, getattr(args, arg)))
+        if args.config is not None:
+            with open(os.path.join(exp_dir, 'config.txt'), 'w') as f:
+                f.write(open(args.config, 'r').read())
+    if world > 1:
+        dist.barrier()
+
+    if args.synthetic:
+        hw = [int(x) for x in args.synthetic_hw.split(',')] if args.synthetic_hw else [None, None]
+        ray_samplers = synthetic_ray_samplers('train', args.trainskip, args.depth_sup_type,
+                                              args.synthetic_frames, hw[0], hw[1])
+        val_ray_samplers = synthetic_ray_samplers('test', args.testskip, args.depth_sup_type,
+                                                  args.synthetic_frames, hw[0], hw[1])
+    else:
+        ray_samplers = load_data_split(args.datadir, args.scene, split='train', skip=args.trainskip,
+                                       depth_sup_type=args.depth_sup_type)
+        val_ray_samplers = load_data_split(args.datadir, args.scene, split='test', skip=args.testskip,
+                                           depth_sup_type=args.depth_sup_type)
+    depth_scale = ray_samplers[0].get_depth_scale() or 1.0
+
+    cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
+    trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,
+                            cascade_samples=cascade, lrate=args.lrate, use_depth=args.use_depth,
+                            depth_loss_type=args.depth_loss_type, lambda_depth=args.lambda_depth,
+                            depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world)
+    ckpt, start = find_latest_checkpoint(args)
+    if ckpt is not None:
+        logger.info('Reloading from: {}'.format(ckpt))
+        load_checkpoint(ckpt, trainer)
+
+    np.random.seed((rank + 1) * 777)                                # :406
+    torch.manual_seed((rank + 1) * 777)                             # :408
+    writer = None
+    if rank == 0:
+        try:
+            from tensorboardX import SummaryWriter
+            writer = SummaryWriter(os.path.join(args.basedir, 'summaries', args.expname))
+        except ImportError:
+            logger.info('tensorboardX not installed: scalars go to the console only')
+
+    for global_step in range(start + 1, start + 1 + args.N_iters):
+        time0 = time.time()
+        i = np.random.randint(low=0, high=len(ray_samplers))
+        ray_batch = batch_to_device(ray_samplers[i].random_sample(args.N_rand, center_crop=False), device)
+        scalars = trainer.train_step(ray_batch)
+        log_now = rank == 0 and (global_step % args.i_print == 0 or global_step < 10)
+        if log_now:
+            scalars_to_log = OrderedDict([('resolution', ray_samplers[0].resolution_level)])
+            for m, sc in enumerate(scalars):
+                sc = sc.cpu().numpy()
+                if args.use_depth:
+                    scalars_to_log['level_{}/loss_depth'.format(m)] = float(sc[2])
+                scalars_to_log['level_{}/rgb_loss'.format(m)] = float(sc[1])
+                scalars_to_log['level_{}/pnsr'.format(m)] = float(mse2psnr(float(sc[1])))
+            scalars_to_log['iter_time'] = time.time() - time0
+            logstr = '{} step: {} '.format(args.expname, global_step)
+            for k, v in scalars_to_log.items():
+                logstr += ' {}: {:.6f}'.format(k, v)
+                if writer is not None:
+                    writer.add_scalar(k, v, global_step)
+            logger.info(logstr)
+
+        if (global_step % args.i_test == 0) and global_step != 0:   # :539-640
+            out_dir = os.path.join(exp_dir, 'render_{}_{:06d}'.format('test', global_step))
+            if rank == 0:
+                os.makedirs(out_dir, exist_ok=True)
+            psnrs, rmses, abs_rels = [], [], []
+            for idx, sampler in enumerate(val_ray_samplers):
+                ret = render_single_image(rank, world, trainer, sampler, args.chunk_size)
+                if rank != 0:
+                    continue
+                from PIL import Image
+                fname = '{:06d}.png'.format(idx)
+                im = ret[-1]['rgb'].numpy()
+                if sampler.get_img() is not None:
+                    gt_im = sampler.get_img()
+                    psnrs.append(float(mse2psnr(np.mean((gt_im - im) * (gt_im - im)))))
+                if sampler.get_gt_depth_img() is not None:
+                    rmse, absrel = depth_metrics(ret[-1]['depth'].numpy(), sampler)
+                    rmses.append(rmse)
+                    abs_rels.append(absrel)
+                    d16 = ((ret[-1]['depth'].numpy() / sampler.get_depth_scale()).clip(1e-3, 80) * 256.0)
+                    Image.fromarray(d16.astype(np.uint16)).save(os.path.join(out_dir, 'depth_' + fname))
+                Image.fromarray(to8b(im)).save(os.path.join(out_dir, fname))
+                Image.fromarray(to8b(ret[-1]['fg_rgb'].numpy())).save(os.path.join(out_dir, 'fg_' + fname))
+                Image.fromarray(to8b(ret[-1]['bg_rgb'].numpy())).save(os.path.join(out_dir, 'bg_' + fname))
+            if rank == 0:
+                for name, vals in (('psnr', psnrs), ('rmse', rmses), ('absrel', abs_rels)):
+                    if vals:
+                        vals = vals + [float(np.mean(vals))]
+                        with open(os.path.join(out_dir, '%s_%06d.txt' % (name, global_step)), 'w') as f:
+                            f.write('\n'.join(str(p) for p in vals))
+                        if writer is not None:
+                            writer.add_scalar('test_' + name, vals[-1], global_step)
+                        logger.info('test_%s: %s' % (name, vals[-1]))
+
+        if rank == 0 and (global_step % args.i_weights == 0 and global_step > 0):   # :642-652
+            save_checkpoint(os.path.join(exp_dir, 'model_{:06d}.pth'.format(global_step)), trainer, global_step)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def train(argv=None):
+    import torch
+    parser = config_parser()
+    args = parser.parse_args(argv)
+    validate_args(args)
+    if os.path.exists(os.path.join(args.basedir, args.expname)):     # :733-735
+        print('already trained, exiting...')
+        sys.exit(0)
+    if args.world_size == -1:
+        args.world_size = torch.cuda.device_count()
+    if args.world_size <= 1:
+        args.world_size = 1
+        ddp_train_nerf(0, args)
+    else:
+        torch.multiprocessing.spawn(ddp_train_nerf, args=(args,), nprocs=args.world_size, join=True)
+
+
+if __name__ == '__main__':
+    setup_logger()
+    train()

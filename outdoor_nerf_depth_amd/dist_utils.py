@@ -1,0 +1,49 @@
+"""Backend-agnostic distributed helpers (RCCL on GPUs, gloo in the CPU tests)."""
+import torch
+
+
+def allreduce_mean_(flat, world_size, prescaled=False):
+    """DDP gradient semantics (ddp_train_nerf.py:323): every rank ends with the average.
+    prescaled=True means the caller already multiplied by 1/world_size (the HIP backward does)."""
+    if world_size <= 1:
+        return flat
+    import torch.distributed as dist
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if not prescaled:
+        flat.div_(world_size)
+    return flat
+
+
+def rank_seeds(rank):
+    """ddp_train_nerf.py:406-408: numpy and torch are both seeded with (rank+1)*777 so every rank
+    draws a different frame, different rays and different depth perturbations."""
+    return (rank + 1) * 777
+
+
+def shard_sizes(n_items, world_size, allow_ragged=True):
+    """Contiguous split of a frame's rays over ranks (ddp_train_nerf.py:142-143).  The reference
+    raises unless n_items % world_size == 0 (:137-139); 375*1242 is not divisible by 4 or 8, so the
+    default here gives the remainder to the last rank (documented divergence)."""
+    base = n_items // world_size
+    if base * world_size != n_items and not allow_ragged:
+        raise Exception('Number of pixels in the image is not divisible by the number of GPUs!\n\t'
+                        '# pixels: {}\n\t# GPUs: {}'.format(n_items, world_size))
+    sizes = [base] * world_size
+    sizes[-1] = n_items - base * (world_size - 1)
+    return sizes
+
+
+def gather_ragged(t, sizes, rank, world_size):
+    """Gather per-rank [sizes[r], ...] tensors to rank 0 (ddp_train_nerf.py:229-243 with ragged
+    shards): pads to the largest shard, all_gather, trims."""
+    if world_size <= 1:
+        return t
+    import torch.distributed as dist
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    outs = [torch.empty_like(pad) for _ in range(world_size)]
+    dist.all_gather(outs, pad)
+    if rank != 0:
+        return None
+    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)

@@ -1,0 +1,185 @@
+"""CPU tests of the host side: CLI surface, parameter/checkpoint layout, dataset reader, and the
+N > 1 path (world_size 2, gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfpp_oracle as O
+from outdoor_nerf_depth_amd import model as M
+from outdoor_nerf_depth_amd import dist_utils as D
+from outdoor_nerf_depth_amd import ddp_train_nerf as T
+from outdoor_nerf_depth_amd import data_loader_split as DL
+
+# defaults of the reference parser (nerf-methods/nerfplusplus/ddp_train_nerf.py:657-727)
+REF_DEFAULTS = dict(basedir='./logs/', datadir=None, scene=None, testskip=8, trainskip=1, netdepth=8, netwidth=256,
+                    use_viewdirs=False, no_reload=False, ckpt_path=None, N_rand=2048, chunk_size=8192,
+                    N_iters=250001, render_splits='test', cascade_level=2, cascade_samples='64,64', world_size=-1,
+                    optim_autoexpo=False, lambda_autoexpo=1., lrate=5e-4, lrate_decay_factor=0.1,
+                    lrate_decay_steps=5000, det=False, max_freq_log2=10, max_freq_log2_viewdirs=4,
+                    load_min_depth=False, i_print=100, i_img=500, i_weights=10000, use_depth=False,
+                    lambda_depth=1.0, depth_loss_type='mse', depth_sup_type='gt', depth_sigma=0.01, port=12345)
+
+
+def test_cli_flags_and_defaults_match_reference():
+    args = T.config_parser().parse_args(['--expname', 'x'])
+    for k, v in REF_DEFAULTS.items():
+        assert getattr(args, k) == v, k
+    a = T.config_parser().parse_args(['--expname', 'x', '--sample_every', '8', '--use_depth', '--depth_loss_type',
+                                      'kl', '--depth_sup_type', 'mono_crop', '--lambda_depth', '0.1'])
+    assert a.trainskip == 8 and a.use_depth and a.depth_loss_type == 'kl' and a.depth_sup_type == 'mono_crop'
+    with pytest.raises(SystemExit):
+        T.config_parser().parse_args(['--depth_loss_type', 'huber'])
+
+
+def test_config_file_then_command_line_override(tmp_path):
+    cfg = tmp_path / 'kitti.txt'
+    cfg.write_text('### INPUT\nscene = seq00\ndepth_sup_type = gt\nexpname = debug_only\ntrainskip = 2\n'
+                   'config = None\nckpt_path = None\nno_reload = False\nuse_depth = False\nlambda_depth = 1\n'
+                   'N_rand = 1024\nlrate = 0.0005\ncascade_samples = 64,128\nuse_viewdirs = True\ni_weights = 10000\n')
+    a = T.config_parser().parse_args(['--config', str(cfg), '--trainskip', '4', '--use_depth', '--expname', 'run1'])
+    assert a.scene == 'seq00' and a.cascade_samples == '64,128' and a.use_viewdirs and a.N_rand == 1024
+    assert a.trainskip == 4 and a.use_depth and a.expname == 'run1' and a.ckpt_path is None
+    T.validate_args(a)
+    for bad in (['--netwidth', '128'], ['--optim_autoexpo'], ['--use_depth', '--depth_loss_type', 'nll']):
+        with pytest.raises(SystemExit):
+            T.validate_args(T.config_parser().parse_args(['--expname', 'x'] + bad))
+
+
+def test_parameter_layout_and_init_match_reference(golden):
+    g = golden('params_seed777')
+    levels = M.init_level_params(2)
+    specs = M.level_param_specs()
+    assert [k for k, _ in specs] == ['nerf_net.' + k for k in O.param_order()]
+    assert sum(int(np.prod(s)) for _, s in specs) == 1202440
+    for m, flat in enumerate(levels):
+        sd = M.state_dict_from_flat(flat)
+        assert list(sd.keys())[0] == 'module.nerf_net.fg_net.base_layers.0.0.weight'      # DDP prefix, :646
+        for k in O.param_order():
+            v = sd['module.nerf_net.' + k].numpy()
+            np.testing.assert_array_equal(v.reshape(-1)[g['L%d.%s.idx' % (m, k)]], g['L%d.%s.val' % (m, k)])
+
+
+def test_checkpoint_round_trip_with_torch_adam(tmp_path):
+    flat = M.init_level_params(1)[0]
+    sd = M.state_dict_from_flat(flat)
+    # a torch module with the reference's parameter shapes loads our optimiser state
+    params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    ea, eas = torch.rand_like(flat), torch.rand_like(flat)
+    opt.load_state_dict(M.adam_state_dict(ea, eas, step=7))
+    assert float(opt.state[params[3]]['step']) == 7
+    off = sum(p.numel() for p in params[:3])
+    np.testing.assert_array_equal(opt.state[params[3]]['exp_avg'].reshape(-1).numpy(),
+                                  ea[off:off + params[3].numel()].numpy())
+    ea2, eas2 = torch.zeros_like(flat), torch.zeros_like(flat)
+    assert M.load_adam_state_dict(ea2, eas2, opt.state_dict()) == 7
+    assert torch.equal(ea, ea2) and torch.equal(eas, eas2)
+    flat2 = torch.zeros_like(flat)
+    M.load_state_dict_into_flat(flat2, {k[len('module.'):]: v for k, v in sd.items()})     # un-prefixed too
+    assert torch.equal(flat, flat2)
+    torch.save({'net_0': sd}, tmp_path / 'model_000010.pth')
+    M.load_state_dict_into_flat(flat2.zero_(), torch.load(tmp_path / 'model_000010.pth')['net_0'])
+    assert torch.equal(flat, flat2)
+
+
+def test_ray_generation_and_dataset_reader(golden, tmp_path):
+    from PIL import Image
+    g = golden('rays')
+    o, d, depth = DL.get_rays_single_image(4, 6, g['K'], g['c2w'])
+    np.testing.assert_allclose(o, g['rays_o'], rtol=1e-6)
+    np.testing.assert_allclose(d, g['rays_d'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(depth, g['depth'], rtol=1e-6)
+    root = tmp_path / 'data' / 'scene'
+    rs = np.random.RandomState(0)
+    for split, n in (('train', 3), ('test', 1)):
+        for sub in ('rgb', 'pose', 'intrinsics', 'depth', 'depth_mono_crop'):
+            os.makedirs(root / split / sub)
+        for i in range(n):
+            Image.fromarray(rs.randint(0, 255, (4, 6, 3), dtype=np.uint8)).save(root / split / 'rgb' / ('%03d.png' % i))
+            dep = rs.randint(0, 80 * 256, (4, 6)).astype(np.uint16)
+            Image.fromarray(dep).save(root / split / 'depth' / ('%03d.png' % i))
+            Image.fromarray(dep).save(root / split / 'depth_mono_crop' / ('%03d.png' % i))
+            np.savetxt(root / split / 'pose' / ('%03d.txt' % i), g['c2w'].reshape(1, 16))
+            np.savetxt(root / split / 'intrinsics' / ('%03d.txt' % i), g['K'].reshape(1, 16))
+    (root / 'scale').write_text('0.005\n')
+    samplers = DL.load_data_split(str(tmp_path / 'data'), 'scene', 'train', skip=2, depth_sup_type='mono_crop')
+    assert len(samplers) == 2 and samplers[0].H == 4 and samplers[0].W == 6
+    np.random.seed(1)
+    b = samplers[0].random_sample(5)
+    assert set(b.keys()) >= {'ray_o', 'ray_d', 'depth', 'rgb', 'min_depth', 'img_name', 'depth_gt', 'depth_sup'}
+    assert b['ray_d'].shape == (5, 3) and b['rgb'].dtype == np.float32 and np.all(b['min_depth'] == np.float32(1e-4))
+    full = samplers[0].get_all()
+    np.testing.assert_allclose(full['ray_d'], g['rays_d'], rtol=1e-5, atol=1e-6)
+    raw = np.array(Image.open(root / 'train' / 'depth' / '000.png')).astype(np.float32).reshape(-1)
+    np.testing.assert_allclose(full['depth_gt'], 0.005 * raw / 256.0, rtol=1e-6)
+
+
+def test_shard_sizes_ragged_and_reference_behaviour():
+    n = 375 * 1242
+    assert D.shard_sizes(n, 2) == [n // 2, n // 2]
+    s8 = D.shard_sizes(n, 8)
+    assert sum(s8) == n and len(set(s8[:-1])) == 1 and s8[-1] - s8[0] == n % 8
+    with pytest.raises(Exception, match='not divisible'):
+        D.shard_sizes(n, 4, allow_ragged=False)
+    assert D.rank_seeds(0) == 777 and D.rank_seeds(3) == 4 * 777
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, golden_path, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = np.load(golden_path)
+    levels = O.init_params_like_reference(1)
+    far = O.intersect_sphere(g['r%d.ray_o' % rank], g['r%d.ray_d' % rank])
+    fg, bg = O.coarse_depths(g['r%d.min_depth' % rank], far, 64)
+    fg, bg = O.perturb_samples(fg, g['r%d.t_fg' % rank]), O.perturb_samples(bg, g['r%d.t_bg' % rank])
+    cache = {}
+    ret = O.nerf_forward(levels[0], g['r%d.ray_o' % rank], g['r%d.ray_d' % rank], far, fg, bg, cache=cache)
+    _, _, _, g_rgb, g_depth, g_w = O.loss_and_grads(ret, fg, far, g['r%d.rgb' % rank], g['r%d.depth_sup' % rank],
+                                                    True, 'mse', 0.1, 0.)
+    grads = O.nerf_backward(cache, g_rgb, g_depth, g_w)
+    flat = torch.from_numpy(np.concatenate([grads[k].reshape(-1) for k in O.param_order()]))
+    flat = flat * (1.0 / world)                              # the HIP backward pre-scales by 1/world
+    D.allreduce_mean_(flat, world, prescaled=True)
+    # ragged gather of a per-rank shard
+    sizes = D.shard_sizes(7, world)
+    lo = sum(sizes[:rank])
+    shard = torch.arange(lo, lo + sizes[rank], dtype=torch.float32).reshape(-1, 1) * torch.ones(1, 3)
+    full = D.gather_ragged(shard, sizes, rank, world)
+    if rank == 0:
+        np.save(out, flat.numpy())
+        assert full.shape == (7, 3) and torch.equal(full[:, 0], torch.arange(7, dtype=torch.float32))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): per-rank gradients, pre-scaled SUM all-reduce == DDP's average,
+    checked against the reference's 2-rank emulation (tests/golden/ddp2.npz)."""
+    import torch.multiprocessing as mp
+    gp = os.path.join(os.path.dirname(__file__), 'golden', 'ddp2.npz')
+    out = str(tmp_path / 'avg.npy')
+    mp.spawn(_ddp_worker, args=(2, _free_port(), gp, out), nprocs=2, join=True)
+    avg = np.load(out)
+    g = np.load(gp)
+    off = 0
+    shapes = {}
+    for net, in_ch in (('fg_net', 63), ('bg_net', 84)):
+        for k, s in O.mlp_param_shapes(in_ch, 27).items():
+            shapes['%s.%s' % (net, k)] = s
+    for k in O.param_order():
+        n = int(np.prod(shapes[k]))
+        mine = avg[off:off + n][g['avg.%s.idx' % k]]
+        assert np.abs(mine - g['avg.%s.g' % k]).max() <= 5e-2 * g['avg.%s.rms' % k] + 1e-12, k
+        off += n
