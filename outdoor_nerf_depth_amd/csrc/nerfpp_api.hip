@@ -70,7 +70,7 @@ struct WsLayout {
 int choose_ksplit(int64_t rows) {
   int64_t k = rows / 512;
   if (k < 1) k = 1;
-  if (k > 12) k = 12;
+  if (k > 16) k = 16;
   return (int)k;
 }
 WsLayout ws_layout(int n_rays, int S, int P, bool training) {

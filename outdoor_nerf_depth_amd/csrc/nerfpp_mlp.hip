@@ -146,16 +146,18 @@ __device__ __forceinline__ void init_zero(f32x16 (&acc)[NOB]) {
 }
 
 // fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements)
+// `row` is the UNCLAMPED tile row (< rows_padded): rows past the end of the batch are written as
+// zeros so the weight-gradient GEMMs can run over whole 32-row chunks without masking.
 template <int NCH, int P>
 __device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t row, int hi, bool valid,
                                            const Frag<P> (&h)[NCH]) {
-  if (!valid) return;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     __bf16* r = base + p * plane + row * ld + 4 * hi;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const uint4 bits = *(const uint4*)&h[c].v[p];
+      uint4 bits = *(const uint4*)&h[c].v[p];
+      if (!valid) bits = make_uint4(0, 0, 0, 0);
       *(uint2*)(r + 16 * c) = make_uint2(bits.x, bits.y);
       *(uint2*)(r + 16 * c + 8) = make_uint2(bits.z, bits.w);
     }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
   sample_point<NET>(a.geom, row, a.S, x, vd, &depth_real);
   Frag<P> pe[KPE];
   encode_point<NET, P>(x, hi, pe);
-  if (TRAIN) save_frags<KPE, P>(a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), row, hi, valid, pe);
+  if (TRAIN) save_frags<KPE, P>(a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), row_raw, hi, valid, pe);
 
   f32x16 acc[8];
   Frag<P> h[16];
@@ -298,13 +300,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
   init_bias<8>(acc, a.bias + fs_bias_off(FS_L0), hi);
   stage_gemm<8, KPE, P, NW>(pipe, acc, pe);
   acc_to_frags<8, P, ACT_RELU>(acc, h);
-  if (TRAIN) save_frags<16, P>(a.ws.t[T_H0], plane_rows * 256, 256, row, hi, valid, h);
+  if (TRAIN) save_frags<16, P>(a.ws.t[T_H0], plane_rows * 256, 256, row_raw, hi, valid, h);
   // L1..L4
   for (int l = 1; l <= 4; ++l) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
     stage_gemm<8, 16, P, NW>(pipe, acc, h);
     acc_to_frags<8, P, ACT_RELU>(acc, h);
-    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row, hi, valid, h);
+    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row_raw, hi, valid, h);
   }
   // L5: input = cat(encoded point, h4)                                 nerf_network.py:127-129
   {
@@ -316,21 +318,21 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L5), hi);
     stage_gemm<8, KPE + 16, P, NW>(pipe, acc, in5);
     acc_to_frags<8, P, ACT_RELU>(acc, h);
-    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + 5], plane_rows * 256, 256, row, hi, valid, h);
+    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + 5], plane_rows * 256, 256, row_raw, hi, valid, h);
   }
   // L6, L7
   for (int l = 6; l <= 7; ++l) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
     stage_gemm<8, 16, P, NW>(pipe, acc, h);
     acc_to_frags<8, P, ACT_RELU>(acc, h);
-    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row, hi, valid, h);
+    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row_raw, hi, valid, h);
   }
   // remap (no activation) and sigma, both from h7                       nerf_network.py:131-136
   Frag<P> rm[16];
   init_bias<8>(acc, a.bias + fs_bias_off(FS_REMAP), hi);
   stage_gemm<8, 16, P, NW>(pipe, acc, h);
   acc_to_frags<8, P, ACT_NONE>(acc, rm);
-  if (TRAIN) save_frags<16, P>(a.ws.t[T_R], plane_rows * 256, 256, row, hi, valid, rm);
+  if (TRAIN) save_frags<16, P>(a.ws.t[T_R], plane_rows * 256, 256, row_raw, hi, valid, rm);
   f32x16 acc1[1];
   init_bias<1>(acc1, a.bias + fs_bias_off(FS_SIG), hi);
   stage_gemm<1, 16, P, NW>(pipe, acc1, h);
@@ -343,13 +345,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int c = 0; c < 16; ++c) in[c] = rm[c];
     Frag<P> df[2];
     encode_dir<P>(vd, hi, df);
-    if (TRAIN) save_frags<2, P>(a.ws.t[T_DIRX], plane_rows * 32, 32, row, hi, valid, df);
+    if (TRAIN) save_frags<2, P>(a.ws.t[T_DIRX], plane_rows * 32, 32, row_raw, hi, valid, df);
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
     init_bias<4>(acc4, a.bias + fs_bias_off(FS_RGB0), hi);
     stage_gemm<4, 20, P, NW>(pipe, acc4, in);
     acc_to_frags<4, P, ACT_RELU>(acc4, g);
-    if (TRAIN) save_frags<8, P>(a.ws.t[T_G], plane_rows * 128, 128, row, hi, valid, g);
+    if (TRAIN) save_frags<8, P>(a.ws.t[T_G], plane_rows * 128, 128, row_raw, hi, valid, g);
   }
   {
     Frag<P> in[16];
@@ -398,13 +400,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
     if (hi == 0) { set_slot<P>(in[0], 0, d.x); set_slot<P>(in[0], 1, d.y); set_slot<P>(in[0], 2, d.z); }
     {
       Frag<P> dp[2] = {in[0], in[1]};
-      save_frags<2, P>(a.ws.t[T_DP], plane_rows * 32, 32, row, hi, valid, dp);
+      save_frags<2, P>(a.ws.t[T_DP], plane_rows * 32, 32, row_raw, hi, valid, dp);
     }
     f32x16 acc4[4];
     init_zero<4>(acc4);
     stage_gemm<4, 4, P, NW>(pipe, acc4, in);
     mask_to_frags<4, P>(acc4, a.ws.t[T_G], 128, row, hi, dg);
-    save_frags<8, P>(a.ws.t[T_DG], plane_rows * 128, 128, row, hi, valid, dg);
+    save_frags<8, P>(a.ws.t[T_DG], plane_rows * 128, 128, row_raw, hi, valid, dg);
   }
   f32x16 acc[8];
   Frag<P> dz[16];
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
   init_zero<8>(acc);
   stage_gemm<8, 8, P, NW>(pipe, acc, dg);
   acc_to_frags<8, P, ACT_NONE>(acc, dz);
-  save_frags<16, P>(a.ws.t[T_DR], plane_rows * 256, 256, row, hi, valid, dz);
+  save_frags<16, P>(a.ws.t[T_DR], plane_rows * 256, 256, row_raw, hi, valid, dz);
   // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
   {
     Frag<P> in[18];
@@ -422,19 +424,19 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
     if (hi == 0) set_slot<P>(in[16], 0, d.w);
     {
       Frag<P> ds[2] = {in[16], in[17]};
-      save_frags<2, P>(a.ws.t[T_DS], plane_rows * 32, 32, row, hi, valid, ds);
+      save_frags<2, P>(a.ws.t[T_DS], plane_rows * 32, 32, row_raw, hi, valid, ds);
     }
     init_zero<8>(acc);
     stage_gemm<8, 18, P, NW>(pipe, acc, in);
     mask_to_frags<8, P>(acc, a.ws.t[T_H0 + 7], 256, row, hi, dz);
-    save_frags<16, P>(a.ws.t[T_DZ0 + 7], plane_rows * 256, 256, row, hi, valid, dz);
+    save_frags<16, P>(a.ws.t[T_DZ0 + 7], plane_rows * 256, 256, row_raw, hi, valid, dz);
   }
   // B3..B9: dH_{l-1} = W_l^T dZ_l, l = 7..1
   for (int l = 7; l >= 1; --l) {
     init_zero<8>(acc);
     stage_gemm<8, 16, P, NW>(pipe, acc, dz);
     mask_to_frags<8, P>(acc, a.ws.t[T_H0 + l - 1], 256, row, hi, dz);
-    save_frags<16, P>(a.ws.t[T_DZ0 + l - 1], plane_rows * 256, 256, row, hi, valid, dz);
+    save_frags<16, P>(a.ws.t[T_DZ0 + l - 1], plane_rows * 256, 256, row_raw, hi, valid, dz);
   }
 }
 
