@@ -63,7 +63,7 @@ PackLayout pack_layout(int P) {
 
 // ---- workspace layout (bytes) -------------------------------------------------------------------
 struct WsLayout {
-  size_t tensor[2][T_COUNT], out_raw[2], depth_real, d_out[2], slabs[2], total;
+  size_t tensor[2][T_COUNT], out_raw[2], depth_real, d_out[2], slabs[2], masks[2], total;
   int64_t rows, rows_padded;
   int ksplit;
 };
@@ -88,6 +88,7 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
         off = align_up(off + (size_t)L.rows_padded * tensor_ld(net, t) * 2 * P, 256);
       }
       L.slabs[net] = off; off = align_up(off + (size_t)L.ksplit * gslab_floats(net) * 4, 256);
+      L.masks[net] = off; off = align_up(off + (size_t)9 * (L.rows_padded / 32) * 64 * 16, 256);
     }
   }
   L.depth_real = off; off = align_up(off + (size_t)L.rows_padded * 4, 256);
@@ -214,7 +215,7 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     m.bias = (const float*)(pk + PL.bias[net]);
     m.out_raw = (float*)(ws + L.out_raw[net]);
     m.depth_real = (float*)(ws + L.depth_real);
-    if (train) m.ws = make_netws(ws, L, net);
+    if (train) { m.ws = make_netws(ws, L, net); m.masks = (uint4*)(ws + L.masks[net]); }
     if (net == 0 && a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
     launch_mlp_fwd(st, net, P, train, m);
     if (net == 0 && a->ev_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_mlp_end, st);
@@ -265,6 +266,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
     m.w_stream = pk + PL.bwd[net];
     m.d_out = (const float*)(ws + L.d_out[net]);
     m.ws = make_netws(ws, L, net);
+    m.masks = (const uint4*)(ws + L.masks[net]);
     if (net == 0 && a->ev_bwd_begin) (void)hipEventRecord((hipEvent_t)a->ev_bwd_begin, st);
     launch_mlp_bwd(st, net, P, m);
     if (net == 0 && a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);

@@ -25,6 +25,7 @@ struct MlpFwdArgs {
   float* out_raw;                // [rows, 4] (r, g, b, sigma_raw)
   float* depth_real;             // [rows] (background only)
   NetWs ws;
+  uint4* masks;                  // ReLU sign bits [9 stages][rows_padded/32][64 lanes] (training)
 };
 
 struct MlpBwdArgs {
@@ -32,6 +33,7 @@ struct MlpBwdArgs {
   const void* w_stream;          // packed backward (transposed) weight stream
   const float* d_out;            // [rows, 4] (d rgb_pre[3], d sigma_raw)
   NetWs ws;
+  const uint4* masks;
 };
 
 struct DwArgs {

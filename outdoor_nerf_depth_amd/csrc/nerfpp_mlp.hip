@@ -145,45 +145,81 @@ __device__ __forceinline__ void init_zero(f32x16 (&acc)[NOB]) {
     for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
 }
 
-// fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements)
-// `row` is the UNCLAMPED tile row (< rows_padded): rows past the end of the batch are written as
-// zeros so the weight-gradient GEMMs can run over whole 32-row chunks without masking.
+// fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements).
+// The accumulator layout gives every lane 8-byte pieces of 32 DIFFERENT rows, so the tile is first
+// transposed through a per-wave LDS staging area ([32 rows][<=128 cols], row stride 272 B) and then
+// written with 16 B per lane, whole 128..256-byte row segments per instruction.
+// Rows past the end of the batch (tile tail, < rows_padded) are written as zeros so the
+// weight-gradient GEMMs can run over whole 32-row chunks without masking.
+constexpr int STAGE_ROW = 272;                      // 256 B of data + 16 B pad (keeps 16-B alignment)
+constexpr int STAGE_BYTES = 32 * STAGE_ROW;         // per wave
+
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int NCH, int P>
-__device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t row, int hi, bool valid,
-                                           const Frag<P> (&h)[NCH]) {
+__device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t plane, int ld, size_t wave_row0,
+                                           int lane, bool valid, const Frag<P> (&h)[NCH]) {
+  const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    __bf16* r = base + p * plane + row * ld + 4 * hi;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      uint4 bits = *(const uint4*)&h[c].v[p];
-      if (!valid) bits = make_uint4(0, 0, 0, 0);
-      *(uint2*)(r + 16 * c) = make_uint2(bits.x, bits.y);
-      *(uint2*)(r + 16 * c + 8) = make_uint2(bits.z, bits.w);
+    for (int c0 = 0; c0 < NCH; c0 += 8) {
+      constexpr int dummy = 0; (void)dummy;
+      const int nc = NCH - c0 < 8 ? NCH - c0 : 8;           // chunks in this pass (compile-time after unroll)
+      char* w = stage + j * STAGE_ROW + 8 * hi;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < nc) {
+          uint4 bits = *(const uint4*)&h[c0 + c].v[p];
+          if (!valid) bits = make_uint4(0, 0, 0, 0);
+          *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
+          *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
+        }
+      }
+      lds_wave_sync();
+      const int lpr = 2 * nc;                               // 16-byte pieces per row
+      char* g = (char*)(base + p * plane + wave_row0 * ld + c0 * 16);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane;
+        if (it * 64 < 32 * lpr && idx < 32 * lpr) {
+          const int row = idx / lpr, piece = idx - row * lpr;
+          const uint4 v = *(const uint4*)(stage + row * STAGE_ROW + piece * 16);
+          *(uint4*)(g + (size_t)row * ld * 2 + piece * 16) = v;
+        }
+      }
+      lds_wave_sync();
     }
   }
 }
 
-// dH (accumulators) * [saved activation > 0] -> dZ fragments
-template <int NOB, int P>
-__device__ __forceinline__ void mask_to_frags(const f32x16 (&acc)[NOB], const __bf16* act_base, int ld, size_t row,
-                                              int hi, Frag<P> (&dz)[2 * NOB]) {
-  const __bf16* r = act_base + row * ld + 4 * hi;
+// ReLU sign bits of one stage: bit ob*16 + r  <->  acc[ob][r] > 0
+template <int NOB>
+__device__ __forceinline__ uint4 relu_bits(const f32x16 (&acc)[NOB]) {
+  uint32_t m[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int c = 2 * ob + hh;
-      const uint2 m0 = *(const uint2*)(r + 16 * c);
-      const uint2 m1 = *(const uint2*)(r + 16 * c + 8);
-      const uint32_t w[4] = {m0.x, m0.y, m1.x, m1.y};
+    for (int r = 0; r < 16; ++r) m[ob >> 1] |= (acc[ob][r] > 0.f ? 1u : 0u) << ((ob & 1) * 16 + r);
+  return make_uint4(m[0], m[1], m[2], m[3]);
+}
+
+// dH (accumulators) * [forward activation > 0] -> dZ fragments
+template <int NOB, int P>
+__device__ __forceinline__ void mask_to_frags(const f32x16 (&acc)[NOB], const uint4 bits, Frag<P> (&dz)[2 * NOB]) {
+  const uint32_t m[4] = {bits.x, bits.y, bits.z, bits.w};
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const uint32_t bits = (w[t >> 1] >> (16 * (t & 1))) & 0x7fffu;
-        const float v = bits != 0 ? acc[ob][8 * hh + t] : 0.f;
-        set_slot<P>(dz[c], t, v);
+        const bool on = (m[ob >> 1] >> ((ob & 1) * 16 + 8 * hh + t)) & 1u;
+        set_slot<P>(dz[2 * ob + hh], t, on ? acc[ob][8 * hh + t] : 0.f);
       }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,7 +312,7 @@ __device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P>
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int NET, int P, int NW, bool TRAIN>
-__global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
+__global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpFwdArgs a) {
   constexpr int KPE = kpe(NET);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
@@ -284,6 +320,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
   const bool valid = row_raw < (size_t)a.rows;
   const size_t row = valid ? row_raw : (size_t)a.rows - 1;
   const size_t plane_rows = a.rows_padded;
+  const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;          // this wave's first tile row
+  char* stage = smem + 2 * BLK_FRAGS * P * FRAG_BYTES + wave * STAGE_BYTES;
+  const size_t nblk32 = a.rows_padded / 32;
+  uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
   WeightPipe<P, NW> pipe;
   pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
@@ -292,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
   sample_point<NET>(a.geom, row, a.S, x, vd, &depth_real);
   Frag<P> pe[KPE];
   encode_point<NET, P>(x, hi, pe);
-  if (TRAIN) save_frags<KPE, P>(a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), row_raw, hi, valid, pe);
+  if (TRAIN) save_frags<KPE, P>(stage, a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), wrow0, lane, valid, pe);
 
   f32x16 acc[8];
   Frag<P> h[16];
@@ -300,13 +340,19 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
   init_bias<8>(acc, a.bias + fs_bias_off(FS_L0), hi);
   stage_gemm<8, KPE, P, NW>(pipe, acc, pe);
   acc_to_frags<8, P, ACT_RELU>(acc, h);
-  if (TRAIN) save_frags<16, P>(a.ws.t[T_H0], plane_rows * 256, 256, row_raw, hi, valid, h);
+  if (TRAIN) {
+    mask_out[0] = relu_bits<8>(acc);
+    save_frags<16, P>(stage, a.ws.t[T_H0], plane_rows * 256, 256, wrow0, lane, valid, h);
+  }
   // L1..L4
   for (int l = 1; l <= 4; ++l) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
     stage_gemm<8, 16, P, NW>(pipe, acc, h);
     acc_to_frags<8, P, ACT_RELU>(acc, h);
-    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row_raw, hi, valid, h);
+    if (TRAIN) {
+      mask_out[(size_t)l * nblk32 * 64] = relu_bits<8>(acc);
+      save_frags<16, P>(stage, a.ws.t[T_H0 + l], plane_rows * 256, 256, wrow0, lane, valid, h);
+    }
   }
   // L5: input = cat(encoded point, h4)                                 nerf_network.py:127-129
   {
@@ -318,21 +364,27 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L5), hi);
     stage_gemm<8, KPE + 16, P, NW>(pipe, acc, in5);
     acc_to_frags<8, P, ACT_RELU>(acc, h);
-    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + 5], plane_rows * 256, 256, row_raw, hi, valid, h);
+    if (TRAIN) {
+      mask_out[(size_t)5 * nblk32 * 64] = relu_bits<8>(acc);
+      save_frags<16, P>(stage, a.ws.t[T_H0 + 5], plane_rows * 256, 256, wrow0, lane, valid, h);
+    }
   }
   // L6, L7
   for (int l = 6; l <= 7; ++l) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
     stage_gemm<8, 16, P, NW>(pipe, acc, h);
     acc_to_frags<8, P, ACT_RELU>(acc, h);
-    if (TRAIN) save_frags<16, P>(a.ws.t[T_H0 + l], plane_rows * 256, 256, row_raw, hi, valid, h);
+    if (TRAIN) {
+      mask_out[(size_t)l * nblk32 * 64] = relu_bits<8>(acc);
+      save_frags<16, P>(stage, a.ws.t[T_H0 + l], plane_rows * 256, 256, wrow0, lane, valid, h);
+    }
   }
   // remap (no activation) and sigma, both from h7                       nerf_network.py:131-136
   Frag<P> rm[16];
   init_bias<8>(acc, a.bias + fs_bias_off(FS_REMAP), hi);
   stage_gemm<8, 16, P, NW>(pipe, acc, h);
   acc_to_frags<8, P, ACT_NONE>(acc, rm);
-  if (TRAIN) save_frags<16, P>(a.ws.t[T_R], plane_rows * 256, 256, row_raw, hi, valid, rm);
+  if (TRAIN) save_frags<16, P>(stage, a.ws.t[T_R], plane_rows * 256, 256, wrow0, lane, valid, rm);
   f32x16 acc1[1];
   init_bias<1>(acc1, a.bias + fs_bias_off(FS_SIG), hi);
   stage_gemm<1, 16, P, NW>(pipe, acc1, h);
@@ -345,13 +397,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int c = 0; c < 16; ++c) in[c] = rm[c];
     Frag<P> df[2];
     encode_dir<P>(vd, hi, df);
-    if (TRAIN) save_frags<2, P>(a.ws.t[T_DIRX], plane_rows * 32, 32, row_raw, hi, valid, df);
+    if (TRAIN) save_frags<2, P>(stage, a.ws.t[T_DIRX], plane_rows * 32, 32, wrow0, lane, valid, df);
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
     init_bias<4>(acc4, a.bias + fs_bias_off(FS_RGB0), hi);
     stage_gemm<4, 20, P, NW>(pipe, acc4, in);
     acc_to_frags<4, P, ACT_RELU>(acc4, g);
-    if (TRAIN) save_frags<8, P>(a.ws.t[T_G], plane_rows * 128, 128, row_raw, hi, valid, g);
+    if (TRAIN) {
+      mask_out[(size_t)8 * nblk32 * 64] = relu_bits<4>(acc4);
+      save_frags<8, P>(stage, a.ws.t[T_G], plane_rows * 128, 128, wrow0, lane, valid, g);
+    }
   }
   {
     Frag<P> in[16];
@@ -377,13 +432,17 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(MlpFwdArgs a) {
 // backward (dX chain).  d_out[row] = (d rgb_pre-sigmoid[3], d sigma_raw)
 // ------------------------------------------------------------------------------------------------
 template <int NET, int P, int NW>
-__global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
+__global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
   const size_t row_raw = (size_t)blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
   const bool valid = row_raw < (size_t)a.rows;
   const size_t row = valid ? row_raw : (size_t)a.rows - 1;
   const size_t plane_rows = a.rows_padded;
+  const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;
+  char* stage = smem + 2 * BLK_FRAGS * P * FRAG_BYTES + wave * STAGE_BYTES;
+  const size_t nblk32 = a.rows_padded / 32;
+  const uint4* mask_in = a.masks + (wrow0 / 32) * 64 + lane;
 
   WeightPipe<P, NW> pipe;
   pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
@@ -400,13 +459,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
     if (hi == 0) { set_slot<P>(in[0], 0, d.x); set_slot<P>(in[0], 1, d.y); set_slot<P>(in[0], 2, d.z); }
     {
       Frag<P> dp[2] = {in[0], in[1]};
-      save_frags<2, P>(a.ws.t[T_DP], plane_rows * 32, 32, row_raw, hi, valid, dp);
+      save_frags<2, P>(stage, a.ws.t[T_DP], plane_rows * 32, 32, wrow0, lane, valid, dp);
     }
     f32x16 acc4[4];
     init_zero<4>(acc4);
     stage_gemm<4, 4, P, NW>(pipe, acc4, in);
-    mask_to_frags<4, P>(acc4, a.ws.t[T_G], 128, row, hi, dg);
-    save_frags<8, P>(a.ws.t[T_DG], plane_rows * 128, 128, row_raw, hi, valid, dg);
+    mask_to_frags<4, P>(acc4, mask_in[(size_t)8 * nblk32 * 64], dg);
+    save_frags<8, P>(stage, a.ws.t[T_DG], plane_rows * 128, 128, wrow0, lane, valid, dg);
   }
   f32x16 acc[8];
   Frag<P> dz[16];
@@ -414,7 +473,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
   init_zero<8>(acc);
   stage_gemm<8, 8, P, NW>(pipe, acc, dg);
   acc_to_frags<8, P, ACT_NONE>(acc, dz);
-  save_frags<16, P>(a.ws.t[T_DR], plane_rows * 256, 256, row_raw, hi, valid, dz);
+  save_frags<16, P>(stage, a.ws.t[T_DR], plane_rows * 256, 256, wrow0, lane, valid, dz);
   // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
   {
     Frag<P> in[18];
@@ -424,19 +483,19 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
     if (hi == 0) set_slot<P>(in[16], 0, d.w);
     {
       Frag<P> ds[2] = {in[16], in[17]};
-      save_frags<2, P>(a.ws.t[T_DS], plane_rows * 32, 32, row_raw, hi, valid, ds);
+      save_frags<2, P>(stage, a.ws.t[T_DS], plane_rows * 32, 32, wrow0, lane, valid, ds);
     }
     init_zero<8>(acc);
     stage_gemm<8, 18, P, NW>(pipe, acc, in);
-    mask_to_frags<8, P>(acc, a.ws.t[T_H0 + 7], 256, row, hi, dz);
-    save_frags<16, P>(a.ws.t[T_DZ0 + 7], plane_rows * 256, 256, row_raw, hi, valid, dz);
+    mask_to_frags<8, P>(acc, mask_in[(size_t)7 * nblk32 * 64], dz);
+    save_frags<16, P>(stage, a.ws.t[T_DZ0 + 7], plane_rows * 256, 256, wrow0, lane, valid, dz);
   }
   // B3..B9: dH_{l-1} = W_l^T dZ_l, l = 7..1
   for (int l = 7; l >= 1; --l) {
     init_zero<8>(acc);
     stage_gemm<8, 16, P, NW>(pipe, acc, dz);
-    mask_to_frags<8, P>(acc, a.ws.t[T_H0 + l - 1], 256, row, hi, dz);
-    save_frags<16, P>(a.ws.t[T_DZ0 + l - 1], plane_rows * 256, 256, row_raw, hi, valid, dz);
+    mask_to_frags<8, P>(acc, mask_in[(size_t)(l - 1) * nblk32 * 64], dz);
+    save_frags<16, P>(stage, a.ws.t[T_DZ0 + l - 1], plane_rows * 256, 256, wrow0, lane, valid, dz);
   }
 }
 
@@ -444,20 +503,25 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(MlpBwdArgs a) {
 
 using namespace nerfpp;
 
+#ifndef NERFPP_WAVES_P1
+#define NERFPP_WAVES_P1 8
+#endif
+#define MLP_WAVES(P) ((P) == 1 ? NERFPP_WAVES_P1 : 4)
+
 template <int NET, int P, bool TRAIN>
 static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
-  constexpr int NW = (P == 1) ? 8 : 4;
+  constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES;
+  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0);
   hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 template <int NET, int P>
 static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a) {
-  constexpr int NW = (P == 1) ? 8 : 4;
+  constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES;
+  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES + NW * STAGE_BYTES;
   hipLaunchKernelGGL((mlp_bwd_kernel<NET, P, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 
@@ -474,4 +538,4 @@ void launch_mlp_bwd(hipStream_t st, int net, int P, const MlpBwdArgs& a) {
   if (net == 0) { if (P == 1) launch_bwd_t<0, 1>(st, a); else launch_bwd_t<0, 2>(st, a); }
   else          { if (P == 1) launch_bwd_t<1, 1>(st, a); else launch_bwd_t<1, 2>(st, a); }
 }
-int mlp_tile_rows(int P) { return ((P == 1) ? 8 : 4) * 32; }
+int mlp_tile_rows(int P) { return MLP_WAVES(P) * 32; }
