@@ -145,7 +145,7 @@ __device__ __forceinline__ void compute_chunk(const char* buf, int wo, int wi, i
           acc[bo][bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[bo][1], fb[bi][0], acc[bo][bi], 0, 0, 0);
         }
       }
-      if (do_bias) {
+      if (do_bias && bo == wi) {                 // the 4 wi-waves of a wo share the A fragments: split the sums
         bsum[bo] += bf16_sum8(fa[bo][0]);
         if constexpr (P == 2) bsum[bo] += bf16_sum8(fa[bo][1]);
       }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, int njobs0, int dbg) 
   nbo = nbo < 0 ? 0 : (nbo > 4 ? 4 : nbo);
   nbi = nbi < 0 ? 0 : (nbi > 2 ? 2 : nbi);
   const bool active = nbo > 0 && nbi > 0;
-  const bool do_bias = job.gb_off >= 0 && wi == 0 && nbo > 0;
+  const bool do_bias = job.gb_off >= 0 && wi < nbo;       // wave wi owns the bias of its out-block 4wo+wi
   f32x16 acc[4][2];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, int njobs0, int dbg) 
         slab[job.gw_off + o * job.gw_ld + ib + li] = acc[bo][bi][r];
       }
     }
-    if (do_bias) {                                   // lane (li, hi) holds feature ob + li, half of the samples
+    if (do_bias && bo == wi) {                       // lane (li, hi) holds feature ob + li, half of the samples
       const float tot = bsum[bo] + __shfl_xor(bsum[bo], 32, 64);
       if (hi == 0) slab[gw_floats(net) + job.gb_off + ob + li] = tot;
     }

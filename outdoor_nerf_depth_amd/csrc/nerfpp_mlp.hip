@@ -125,6 +125,40 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 (&acc)[NOB], Frag<P> (
       }
 }
 
+// The encoded point is needed again by layer 5 (skip connection): park its fragments in LDS
+// (lane-linear 16-byte slots, conflict-free) instead of holding 16-24 VGPRs through layers 1-4.
+template <int N, int P>
+__device__ __forceinline__ void stash_frags(char* base, int lane, const Frag<P> (&f)[N]) {
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int p = 0; p < P; ++p) *(uint4*)(base + ((c * P + p) * 64 + lane) * 16) = *(const uint4*)&f[c].v[p];
+}
+template <int N, int P>
+__device__ __forceinline__ void unstash_frags(const char* base, int lane, Frag<P> (&f)[N]) {
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int p = 0; p < P; ++p) *(uint4*)&f[c].v[p] = *(const uint4*)(base + ((c * P + p) * 64 + lane) * 16);
+}
+
+// ReLU + conversion + sign bits in one pass over the accumulators (bit ob*16 + r <-> acc[ob][r] > 0)
+template <int NOB, int P>
+__device__ __forceinline__ uint4 acc_to_frags_relu_bits(const f32x16 (&acc)[NOB], Frag<P> (&h)[2 * NOB]) {
+  uint32_t m[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float v = acc[ob][8 * hh + t];
+        m[ob >> 1] |= (v > 0.f ? 1u : 0u) << ((ob & 1) * 16 + 8 * hh + t);
+        set_slot<P>(h[2 * ob + hh], t, fmaxf(v, 0.f));
+      }
+  return make_uint4(m[0], m[1], m[2], m[3]);
+}
+
 template <int NOB>
 __device__ __forceinline__ void init_bias(f32x16 (&acc)[NOB], const float* __restrict__ bias, int hi) {
 #pragma unroll
@@ -333,39 +367,45 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   Frag<P> pe[KPE];
   encode_point<NET, P>(x, hi, pe);
   if (TRAIN) save_frags<KPE, P>(stage, a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), wrow0, lane, valid, pe);
+  char* pe_stash = smem + 2 * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0) + wave * (KPE * P * 1024);
+  stash_frags<KPE, P>(pe_stash, lane, pe);
 
   f32x16 acc[8];
   Frag<P> h[16];
   // L0
   init_bias<8>(acc, a.bias + fs_bias_off(FS_L0), hi);
   stage_gemm<8, KPE, P, NW>(pipe, acc, pe);
-  acc_to_frags<8, P, ACT_RELU>(acc, h);
+  const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
   if (TRAIN) {
-    mask_out[0] = relu_bits<8>(acc);
+    mask_out[0] = bits;
     save_frags<16, P>(stage, a.ws.t[T_H0], plane_rows * 256, 256, wrow0, lane, valid, h);
   }
   // L1..L4
   for (int l = 1; l <= 4; ++l) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
     stage_gemm<8, 16, P, NW>(pipe, acc, h);
-    acc_to_frags<8, P, ACT_RELU>(acc, h);
+    const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     if (TRAIN) {
-      mask_out[(size_t)l * nblk32 * 64] = relu_bits<8>(acc);
+      mask_out[(size_t)l * nblk32 * 64] = bits;
       save_frags<16, P>(stage, a.ws.t[T_H0 + l], plane_rows * 256, 256, wrow0, lane, valid, h);
     }
   }
   // L5: input = cat(encoded point, h4)                                 nerf_network.py:127-129
   {
     Frag<P> in5[KPE + 16];
+    {
+      Frag<P> pe2[KPE];
+      unstash_frags<KPE, P>(pe_stash, lane, pe2);
 #pragma unroll
-    for (int c = 0; c < KPE; ++c) in5[c] = pe[c];
+      for (int c = 0; c < KPE; ++c) in5[c] = pe2[c];
+    }
 #pragma unroll
     for (int c = 0; c < 16; ++c) in5[KPE + c] = h[c];
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L5), hi);
     stage_gemm<8, KPE + 16, P, NW>(pipe, acc, in5);
-    acc_to_frags<8, P, ACT_RELU>(acc, h);
+    const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     if (TRAIN) {
-      mask_out[(size_t)5 * nblk32 * 64] = relu_bits<8>(acc);
+      mask_out[(size_t)5 * nblk32 * 64] = bits;
       save_frags<16, P>(stage, a.ws.t[T_H0 + 5], plane_rows * 256, 256, wrow0, lane, valid, h);
     }
   }
@@ -373,9 +413,9 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   for (int l = 6; l <= 7; ++l) {
     init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
     stage_gemm<8, 16, P, NW>(pipe, acc, h);
-    acc_to_frags<8, P, ACT_RELU>(acc, h);
+    const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     if (TRAIN) {
-      mask_out[(size_t)l * nblk32 * 64] = relu_bits<8>(acc);
+      mask_out[(size_t)l * nblk32 * 64] = bits;
       save_frags<16, P>(stage, a.ws.t[T_H0 + l], plane_rows * 256, 256, wrow0, lane, valid, h);
     }
   }
@@ -402,9 +442,9 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     f32x16 acc4[4];
     init_bias<4>(acc4, a.bias + fs_bias_off(FS_RGB0), hi);
     stage_gemm<4, 20, P, NW>(pipe, acc4, in);
-    acc_to_frags<4, P, ACT_RELU>(acc4, g);
+    const uint4 bits = acc_to_frags_relu_bits<4, P>(acc4, g);
     if (TRAIN) {
-      mask_out[(size_t)8 * nblk32 * 64] = relu_bits<4>(acc4);
+      mask_out[(size_t)8 * nblk32 * 64] = bits;
       save_frags<8, P>(stage, a.ws.t[T_G], plane_rows * 128, 128, wrow0, lane, valid, g);
     }
   }
@@ -513,7 +553,7 @@ static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0);
+  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0) + NW * kpe(NET) * P * 1024;
   hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 template <int NET, int P>
