@@ -100,7 +100,7 @@ constexpr int OPER_BYTES = 16 * SEG;          // 32 rows x 512 B + padding
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)l);
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 __device__ __forceinline__ bf16x8 tr_frag(const char* p) {

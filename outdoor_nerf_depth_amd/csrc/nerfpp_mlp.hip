@@ -222,7 +222,9 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
         if (it * 64 < 32 * lpr && idx < 32 * lpr) {
           const int row = idx / lpr, piece = idx - row * lpr;
           const uint4 v = *(const uint4*)(stage + row * STAGE_ROW + piece * 16);
-          *(uint4*)(g + (size_t)row * ld * 2 + piece * 16) = v;
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 vv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(vv, (u32x4*)(g + (size_t)row * ld * 2 + piece * 16));
         }
       }
       lds_wave_sync();
