@@ -28,6 +28,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s measured copy ceiling)
+# algorithmic bytes per sample row read by the weight-gradient GEMMs (every operand once per job):
+# sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
+DW_BYTES_PER_ROW = (5728 + 5792) * 2
 
 
 def parse():
@@ -91,19 +95,41 @@ def run_mode(args, precision, rank, world, device, batches):
     fwd_ms = med([events[i][1]['fwd'][0].elapsed_time(events[i][1]['fwd'][1]) for i in range(K)])
     bwd_ms = med([events[i][1]['bwd'][0].elapsed_time(events[i][1]['bwd'][1]) for i in range(K)])
     dw_ms = med([events[i][1]['bwd'][2].elapsed_time(events[i][1]['bwd'][3]) for i in range(K)])
+    P = 1 if precision == 1 else 2
     kernels = {
-        'mlp_fwd_fg_L1': dict(ms=fwd_ms, flop=2.0 * ALGO_MACS['fwd'][0] * rows),
-        'mlp_bwd_fg_L1': dict(ms=bwd_ms, flop=2.0 * ALGO_MACS['dx'][0] * rows),
-        'dw_both_L1': dict(ms=dw_ms, flop=2.0 * (ALGO_MACS['fwd'][0] + ALGO_MACS['fwd'][1]) * rows),
+        'mlp_fwd_fg_L1': dict(ms=fwd_ms, flop=2.0 * ALGO_MACS['fwd'][0] * rows, bound='mfma'),
+        'mlp_bwd_fg_L1': dict(ms=bwd_ms, flop=2.0 * ALGO_MACS['dx'][0] * rows, bound='mfma'),
+        'dw_both_L1': dict(ms=dw_ms, flop=2.0 * (ALGO_MACS['fwd'][0] + ALGO_MACS['fwd'][1]) * rows, bound='hbm',
+                           bytes=float(DW_BYTES_PER_ROW) * P * rows),
     }
     for k in kernels.values():
         k['tflops'] = k['flop'] / (k['ms'] * 1e-3) / 1e12
+        if 'bytes' in k:
+            k['gbs'] = k['bytes'] / (k['ms'] * 1e-3) / 1e9
     # per-step share: fwd and bwd kernels run for fg and bg at both levels, dw once per level
     share = {'mlp_fwd_fg_L1': fwd_ms * 2 * (1 + 64.0 / 192), 'mlp_bwd_fg_L1': bwd_ms * 2 * (1 + 64.0 / 192),
              'dw_both_L1': dw_ms * (1 + 64.0 / 192)}
     dominant = max(share, key=share.get)
     return dict(elapsed=elapsed, ms_per_step=1e3 * elapsed / K, value=n * K * world / elapsed, loss=loss,
                 kernels=kernels, dominant=dominant, share_ms=share)
+
+
+def roofline(r):
+    """Dominant kernel (largest share of the step) against the roof that bounds it: the fused MLP
+    kernels against dense bf16 MFMA, the weight-gradient GEMM (split-K over the samples, every
+    operand streamed once) against HBM.  Durations are HIP-event times recorded by the library on the
+    launch stream inside the timed region."""
+    dom = r['kernels'][r['dominant']]
+    allk = {k: {kk: round(vv, 4) for kk, vv in v.items() if kk in ('ms', 'tflops', 'gbs')}
+            for k, v in r['kernels'].items()}
+    if dom['bound'] == 'hbm':
+        return {'bound': 'hbm', 'kernel': r['dominant'], 'achieved': dom['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': dom['gbs'] / PEAK_HBM_GBS, 'traffic': None, 'launch_ms': dom['ms'],
+                'mfma_tflops_of_same_kernel': dom['tflops'], 'all_kernels': allk,
+                'share_ms_per_step': {k: round(v, 4) for k, v in r['share_ms'].items()}}
+    return {'bound': 'mfma', 'kernel': r['dominant'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None, 'launch_ms': dom['ms'],
+            'all_kernels': allk, 'share_ms_per_step': {k: round(v, 4) for k, v in r['share_ms'].items()}}
 
 
 def cpu_baseline(args):
@@ -175,19 +201,14 @@ def main():
                                'depth_loss_type=mse, lambda_depth=0.1, N_rand=%d rays/GPU/step, cascade 64+128, '
                                'both levels fwd+bwd+Adam' % args.n_rand,
                    'n_rand_per_gpu': args.n_rand, 'parallelism': 'dp%d (ray batches, RCCL grad all-reduce)' % world},
-        'roofline': {'bound': 'mfma', 'kernel': r['dominant'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None,
-                     'launch_ms': dom['ms'],
-                     'all_kernels': {k: {'ms': round(v['ms'], 4), 'tflops': round(v['tflops'], 2)}
-                                     for k, v in r['kernels'].items()}},
+        'roofline': roofline(r),
         'final_loss': r['loss'],
     }
     if 'split' in res and main_key != 'split':
         s = res['split']
         out['parity_mode'] = {'dtype': 'split-bf16 (hi+lo, 3 MFMA passes): the precision the 1e-4 parity tests use',
                               'value': s['value'], 'ms_per_step': s['ms_per_step'],
-                              'kernels': {k: {'ms': round(v['ms'], 4), 'tflops': round(v['tflops'], 2)}
-                                          for k, v in s['kernels'].items()}}
+                              'roofline': roofline(s)}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out))
