@@ -1,0 +1,94 @@
+"""GPU: the N > 1 path of the trainer on ONE GPU -- two ranks share cuda:0 and all-reduce with gloo
+(the 8-GPU RCCL run is the driver's; this pins the semantics): every rank ends each step with
+bit-identical parameters, equal to a single process that averages the two ranks' gradients itself
+(DDP semantics of nerf-methods/nerfplusplus/ddp_train_nerf.py:323)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batches(rank, n=64):
+    from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
+    scene = SyntheticKitti(depth_sup_type='gt')
+    rng = np.random.RandomState((rank + 1) * 777)                       # per-rank seeds, :406-408
+    out = []
+    for _ in range(2):
+        b = scene.random_batch(n, rng)
+        b['depth_sup'][:8] = np.float32(0.05)
+        uni = dict(t_fg=rng.rand(n, 64).astype(np.float32), t_bg=rng.rand(n, 64).astype(np.float32),
+                   u_fg=rng.rand(n, 128).astype(np.float32), u_bg=rng.rand(n, 128).astype(np.float32))
+        out.append((b, uni))
+    return out
+
+
+def _to_dev(d, dev):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in d.items() if isinstance(v, np.ndarray)}
+
+
+def _worker(rank, world, port, out_dir, overlap):
+    import torch.distributed as dist
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    tr = NerfppTrainer(dev, precision=2, use_depth=True, depth_loss_type='mse', lambda_depth=0.1, world_size=world,
+                       overlap_allreduce=overlap)
+    for b, uni in _batches(rank):
+        tr.train_step(_to_dev(b, dev), uniforms=_to_dev(uni, dev))
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, 'params_rank%d.npy' % rank),
+            np.stack([e.params.cpu().numpy() for e in tr.engines]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_two_ranks_share_one_gpu(tmp_path, overlap):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), overlap), nprocs=2, join=True)
+    p0 = np.load(tmp_path / 'params_rank0.npy')
+    p1 = np.load(tmp_path / 'params_rank1.npy')
+    np.testing.assert_array_equal(p0, p1)                 # identical update on every rank
+
+    # single process: gradients of both ranks' batches averaged by hand, same Adam
+    from outdoor_nerf_depth_amd import ops
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    dev = torch.device('cuda:0')
+    tr = NerfppTrainer(dev, precision=2, use_depth=True, depth_loss_type='mse', lambda_depth=0.1, world_size=1)
+    b0, b1 = _batches(0), _batches(1)
+    for step in range(2):
+        tr.step_count += 1
+        grads = [torch.zeros_like(e.params) for e in tr.engines]
+        for b, uni in (b0[step], b1[step]):
+            bd, ud = _to_dev(b, dev), _to_dev(uni, dev)
+            far, fg_z, bg_z = ops.sample_coarse(bd['ray_o'], bd['ray_d'], bd['min_depth'], 64, ud['t_fg'], ud['t_bg'])
+            ret = None
+            for m, eng in enumerate(tr.engines):
+                if m == 1:
+                    fg_z = ops.sample_fine(fg_z, ret['fg_weights'], 128, u=ud['u_fg'])
+                    bg_z = ops.sample_fine(bg_z, ret['bg_weights'], 128, u=ud['u_bg'])
+                ret = eng.forward(bd['ray_o'], bd['ray_d'], far, fg_z, bg_z, training=True)
+                sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, bd['rgb'], bd['depth_sup'], 'mse', 0.1)
+                grads[m] += eng.backward(g_rgb, g_depth, g_w, grad_scale=0.5)
+        for m, eng in enumerate(tr.engines):
+            ops.adam_step(eng.params, grads[m], tr.exp_avg[m], tr.exp_avg_sq[m], tr.step_count, lr=tr.lrate)
+            eng.repack()
+    ref = np.stack([e.params.cpu().numpy() for e in tr.engines])
+    np.testing.assert_array_equal(p0, ref)
