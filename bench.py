@@ -31,7 +31,7 @@ PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s measured copy ceiling)
 # algorithmic bytes per sample row read by the weight-gradient GEMMs (every operand once per job):
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
-DW_BYTES_PER_ROW = (5728 + 5792) * 2
+DW_BYTES_PER_ROW = (5216 + 5280) * 2
 
 
 def parse():

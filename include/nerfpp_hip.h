@@ -167,6 +167,8 @@ typedef struct {
   void* ev_bwd_end;
   void* ev_dw_begin;
   void* ev_dw_end;
+  const float* params;             /* [NERFPP_LEVEL_PARAMS] the level's float32 parameters (the remap /
+                                      colour-head weight gradients are derived through them) */
 } nerfpp_backward_args;
 
 /* loss.backward() for one level (autograd in the reference)         ddp_train_nerf.py:497 */

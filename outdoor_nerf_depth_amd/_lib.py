@@ -36,7 +36,7 @@ class BackwardArgs(C.Structure):
                [(k, _fp) for k in ('ray_d', 'fg_far', 'fg_z', 'bg_z', 'packed', 'workspace', 'tables',
                                    'g_rgb', 'g_depth', 'g_fg_weights')] + \
                [('grad_scale', C.c_float), ('grads', _fp)] + \
-               [(k, _fp) for k in ('ev_bwd_begin', 'ev_bwd_end', 'ev_dw_begin', 'ev_dw_end')]
+               [(k, _fp) for k in ('ev_bwd_begin', 'ev_bwd_end', 'ev_dw_begin', 'ev_dw_end', 'params')]
 
 
 # every symbol include/nerfpp_hip.h declares: name -> (restype, argtypes)

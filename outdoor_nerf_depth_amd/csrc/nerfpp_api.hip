@@ -63,7 +63,7 @@ PackLayout pack_layout(int P) {
 
 // ---- workspace layout (bytes) -------------------------------------------------------------------
 struct WsLayout {
-  size_t tensor[2][T_COUNT], out_raw[2], depth_real, d_out[2], slabs[2], masks[2], total;
+  size_t tensor[2][T_COUNT], out_raw[2], depth_real, d_out[2], slabs[2], masks[2], fix_m[2], total;
   int64_t rows, rows_padded;
   int ksplit;
 };
@@ -89,6 +89,7 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
       }
       L.slabs[net] = off; off = align_up(off + (size_t)L.ksplit * gslab_floats(net) * 4, 256);
       L.masks[net] = off; off = align_up(off + (size_t)9 * (L.rows_padded / 32) * 64 * 16, 256);
+      L.fix_m[net] = off; off = align_up(off + (size_t)128 * 256 * 4, 256);
     }
   }
   L.depth_real = off; off = align_up(off + (size_t)L.rows_padded * 4, 256);
@@ -246,7 +247,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");
   REQUIRE(prec_ok(a->precision), "precision must be 1 or 2");
   REQUIRE(a->ray_d && a->fg_far && a->fg_z && a->bg_z && a->packed && a->workspace && a->tables, "inputs");
-  REQUIRE(a->g_rgb && a->g_depth && a->grads, "gradients");
+  REQUIRE(a->g_rgb && a->g_depth && a->grads && a->params, "gradients / params");
   hipStream_t st = (hipStream_t)stream;
   const int P = a->precision;
   const WsLayout L = ws_layout(a->n_rays, a->n_samples, P, true);
@@ -282,6 +283,9 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   for (int net = 0; net < N_NET; ++net)
     launch_unpack_grads(st, dw.slabs[net], L.ksplit, gslab_floats(net), a->tables + T.unpack[net],
                         net_params(net), a->grad_scale, a->grads + (net == 0 ? 0 : FG_PARAMS));
+  for (int net = 0; net < N_NET; ++net)
+    launch_remap_fixup(st, net, a->grads + (net == 0 ? 0 : FG_PARAMS), a->params + (net == 0 ? 0 : FG_PARAMS),
+                       (float*)(ws + L.fix_m[net]));
   return check_launch("level_backward");
 }
 

@@ -62,9 +62,10 @@ constexpr JobTable build_all_jobs() {
         add_job(jt, net, s, T_X, 0, true);
         add_job(jt, net, s, T_H0 + 4, kpew(net), false);
       } else if (s < 8) add_job(jt, net, s, T_H0 + s - 1, 0, true);
-      else if (s == FS_REMAP || s == FS_SIG) add_job(jt, net, s, T_H0 + 7, 0, true);
+      else if (s == FS_REMAP) continue;            // dW_remap = Wrgb0r^T * M, derived in remap_fixup_kernel
+      else if (s == FS_SIG) add_job(jt, net, s, T_H0 + 7, 0, true);
       else if (s == FS_RGB0) {
-        add_job(jt, net, s, T_R, 0, true);
+        add_job(jt, net, s, T_H0 + 7, 0, true);    // M = dG^T * H7 (NOT dG^T * R), fixed up after the slab sum
         add_job(jt, net, s, T_DIRX, 256, false);
       } else add_job(jt, net, s, T_G, 0, true);
     }

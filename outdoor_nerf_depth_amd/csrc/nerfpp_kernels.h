@@ -77,5 +77,6 @@ void launch_pack(hipStream_t st, const float* params, const int32_t* tbl, int64_
 void launch_gather_f32(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, float* out);
 void launch_unpack_grads(hipStream_t st, const float* slabs, int ksplit, int64_t slab_floats,
                          const int32_t* tbl, int64_t n_params, float scale, float* grads);
+void launch_remap_fixup(hipStream_t st, int net, float* grads, const float* params, float* tmp_m);
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                  double beta1, double beta2, double eps);

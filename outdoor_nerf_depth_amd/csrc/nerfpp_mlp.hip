@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   init_bias<8>(acc, a.bias + fs_bias_off(FS_REMAP), hi);
   stage_gemm<8, 16, P, NW>(pipe, acc, h);
   acc_to_frags<8, P, ACT_NONE>(acc, rm);
-  if (TRAIN) save_frags<16, P>(stage, a.ws.t[T_R], plane_rows * 256, 256, wrow0, lane, valid, rm);
+  // (R is not saved: the weight gradients that need it are derived from M = dG^T H7, nerfpp_optim.hip)
   f32x16 acc1[1];
   init_bias<1>(acc1, a.bias + fs_bias_off(FS_SIG), hi);
   stage_gemm<1, 16, P, NW>(pipe, acc1, h);
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   init_zero<8>(acc);
   stage_gemm<8, 8, P, NW>(pipe, acc, dg);
   acc_to_frags<8, P, ACT_NONE>(acc, dz);
-  save_frags<16, P>(stage, a.ws.t[T_DR], plane_rows * 256, 256, wrow0, lane, valid, dz);
+  // (dR is not saved either, same reason)
   // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
   {
     Frag<P> in[18];

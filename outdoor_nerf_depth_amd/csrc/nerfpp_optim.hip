@@ -56,9 +56,50 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   v[i] = vi;
 }
 
+// The remap layer has no activation, so with M = dG^T * H7 (what the weight-gradient GEMM leaves in
+// the first 256 columns of rgb_layers.0.weight.grad) and db_g = rgb_layers.0.bias.grad:
+//   d rgb_layers.0.weight[:, :256] = M * Wr^T + db_g (x) b_r        (R = H7 Wr^T + b_r)
+//   d base_remap_layers.0.weight   = Wg[:, :256]^T * M              (dR = dG Wg[:, :256])
+//   d base_remap_layers.0.bias     = Wg[:, :256]^T * db_g
+// which removes both 256-wide saves (R, dR) and one 256x256 GEMM over all samples.  float32, fixed
+// summation order.
+__global__ void remap_copy_m_kernel(const float* __restrict__ grads, int w_g, int ldg, float* __restrict__ m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 128 * 256) m[i] = grads[w_g + (i >> 8) * ldg + (i & 255)];
+}
+__global__ void remap_fixup_kernel(float* __restrict__ grads, const float* __restrict__ params,
+                                   const float* __restrict__ m, int w_g, int b_g, int ldg, int w_r, int b_r) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 128 * 256) {                                   // d Wg[o][j], j < 256
+    const int o = t >> 8, j = t & 255;
+    float acc = 0.f;
+    for (int i = 0; i < 256; ++i) acc += m[o * 256 + i] * params[w_r + j * 256 + i];
+    grads[w_g + o * ldg + j] = acc + grads[b_g + o] * params[b_r + j];
+  } else if (t < 128 * 256 + 256 * 256) {                // d Wr[j][i]
+    const int u = t - 128 * 256, j = u >> 8, i = u & 255;
+    float acc = 0.f;
+    for (int o = 0; o < 128; ++o) acc += params[w_g + o * ldg + j] * m[o * 256 + i];
+    grads[w_r + j * 256 + i] = acc;
+  } else if (t < 128 * 256 + 256 * 256 + 256) {          // d b_r[j]
+    const int j = t - (128 * 256 + 256 * 256);
+    float acc = 0.f;
+    for (int o = 0; o < 128; ++o) acc += params[w_g + o * ldg + j] * grads[b_g + o];
+    grads[b_r + j] = acc;
+  }
+}
+
 }  // namespace nerfpp
 
 using namespace nerfpp;
+
+void launch_remap_fixup(hipStream_t st, int net, float* grads, const float* params, float* tmp_m) {
+  const int w_g = ref_w_off(net, RT_RGB0), b_g = ref_b_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);
+  const int w_r = ref_w_off(net, RT_REMAP), b_r = ref_b_off(net, RT_REMAP);
+  hipLaunchKernelGGL(remap_copy_m_kernel, dim3(128), dim3(256), 0, st, grads, w_g, ldg, tmp_m);
+  const int total = 128 * 256 + 256 * 256 + 256;
+  hipLaunchKernelGGL(remap_fixup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, grads, params, tmp_m, w_g, b_g,
+                     ldg, w_r, b_r);
+}
 
 void launch_pack(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, int P, void* out) {
   dim3 grid((unsigned)((n + 255) / 256)), block(256);

@@ -217,6 +217,7 @@ class LevelEngine(object):
         a.g_fg_weights = g_fg_weights.data_ptr() if g_fg_weights is not None else None
         a.grad_scale = float(grad_scale)
         a.grads = grads.data_ptr()
+        a.params = self.params.data_ptr()
         if events is not None:          # (bwd begin, bwd end, dw begin, dw end)
             a.ev_bwd_begin, a.ev_bwd_end, a.ev_dw_begin, a.ev_dw_end = [e.cuda_event for e in events]
         L.check(L.lib().nerfpp_level_backward(_stream(), C.byref(a)), 'nerfpp_level_backward')
