@@ -98,15 +98,20 @@ constexpr int OPER_BYTES = 16 * SEG;          // 32 rows x 512 B + padding
 // every LDS read of the ring (it cannot prove the transposed reads do not alias the in-flight
 // destination).  Completion is tracked by the counted s_waitcnt in the main loop instead.
 // M0 carries the wave-uniform LDS destination; it is saved/restored inside the statement.
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)l);
+__device__ __forceinline__ void glds16(const void* g, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
-__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 512));
+// LDS reads address the dynamic LDS array through an address_space(3) pointer + 32-bit byte offset
+// (a flat pointer would drag a flat->LDS null check into divergent code and trips a backend bug).
+extern __shared__ __attribute__((aligned(16))) char dw_smem[];
+typedef uint32_t lds_addr;
+__device__ __forceinline__ bf16x8 tr_frag(lds_addr off) {
+  __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)dw_smem;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + 512));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
@@ -120,7 +125,7 @@ __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
 
 // one 32-row chunk: 2 k16-steps x (<=4 out-blocks x <=2 in-blocks) MFMAs for this wave
 template <int P, bool FULL>
-__device__ __forceinline__ void compute_chunk(const char* buf, int wo, int wi, int nbo, int nbi, bool do_bias,
+__device__ __forceinline__ void compute_chunk(lds_addr buf, int wo, int wi, int nbo, int nbi, bool do_bias,
                                               f32x16 (&acc)[4][2], float (&bsum)[4]) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
@@ -154,7 +159,36 @@ __device__ __forceinline__ void compute_chunk(const char* buf, int wo, int wi, i
   }
 }
 
-extern __shared__ __attribute__((aligned(16))) char dw_smem[];
+// Narrow jobs (fewer than 8x8 blocks): blocks are dealt round-robin to the 8 waves (wave w owns blocks
+// w, w+8, ...; block b = (bo = b / n_ib, bi = b % n_ib)), so every wave has work between barriers.
+template <int P>
+__device__ __forceinline__ void compute_chunk_rr(lds_addr buf, int wave, int n_ib, int nblk, bool has_bias,
+                                                 f32x16 (&acc)[8], float (&bsum)[8]) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = wave + 8 * k;
+      if (b >= nblk) break;
+      const int bo = b / n_ib, bi = b - bo * n_ib;
+      bf16x8 fa[P], fb[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        fa[p] = tr_frag(buf + p * OPER_BYTES + kk * 8 * SEG + bo * 64);
+        fb[p] = tr_frag(buf + (P + p) * OPER_BYTES + kk * 8 * SEG + bi * 64);
+      }
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[k], 0, 0, 0);
+      if constexpr (P == 2) {
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[k], 0, 0, 0);
+      }
+      if (has_bias && bi == 0) {
+        bsum[k] += bf16_sum8(fa[0]);
+        if constexpr (P == 2) bsum[k] += bf16_sum8(fa[1]);
+      }
+    }
+  }
+}
 
 template <int P, bool FULL>
 __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, int njobs0, int dbg) {
@@ -187,15 +221,24 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, int njobs0, int dbg) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[x][0][r] = 0.f; acc[x][1][r] = 0.f; }
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  // the narrow instantiation deals blocks round-robin instead (its own accumulator set)
+  f32x16 acc_rr[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_rr[x][r] = 0.f;
+  float bsum_rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int n_ib = job.n_i / 32, nblk = (job.n_o / 32) * n_ib;
 
   // DMA: 2 operands x P planes x 16 segments per chunk, 4P wave-instructions per wave
   const int dma_col = (lane & 31) * 16, dma_row = lane >> 5;
   constexpr int NBUF = P == 1 ? 4 : 2;           // LDS ring depth (P=1: 4 x 34 KiB, P=2: 2 x 68 KiB)
   constexpr int DMA_PER_CHUNK = 4 * P;           // wave-instructions per wave per chunk
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
   auto issue = [&](int c) {
     if (c >= nchunk || dbg == 2) return;
     const int64_t r0 = r_begin + (int64_t)c * 32;
-    char* buf = dw_smem + (c % NBUF) * (2 * P * OPER_BYTES);
+    const uint32_t buf = lds_base + (c % NBUF) * (2 * P * OPER_BYTES);
 #pragma unroll
     for (int x = 0; x < 4 * P; ++x) {
       const int id = x * 8 + wave;                 // 0 .. 32P-1
@@ -226,12 +269,31 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, int njobs0, int dbg) 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(c + NBUF - 1);
-    if ((!active && !do_bias) || dbg == 1) continue;
-    const char* buf = dw_smem + (c % NBUF) * (2 * P * OPER_BYTES) + lane_off;
-    compute_chunk<P, FULL>(buf, wo, wi, nbo, nbi, do_bias, acc, bsum);
+    if (dbg == 1) continue;
+    const lds_addr buf = (c % NBUF) * (2 * P * OPER_BYTES) + lane_off;
+    if constexpr (FULL) compute_chunk<P, true>(buf, wo, wi, nbo, nbi, do_bias, acc, bsum);
+    else compute_chunk_rr<P>(buf, wave, n_ib, nblk, job.gb_off >= 0, acc_rr, bsum_rr);
   }
 
   float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
+  if constexpr (!FULL) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = wave + 8 * k;
+      if (b >= nblk) break;
+      const int bo = b / n_ib, bi = b - bo * n_ib;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * bo + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        slab[job.gw_off + o * job.gw_ld + 32 * bi + li] = acc_rr[k][r];
+      }
+      if (job.gb_off >= 0 && bi == 0) {
+        const float tot = bsum_rr[k] + __shfl_xor(bsum_rr[k], 32, 64);
+        if (hi == 0) slab[gw_floats(net) + job.gb_off + 32 * bo + li] = tot;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int bo = 0; bo < 4; ++bo) {
     if (bo >= nbo) continue;
