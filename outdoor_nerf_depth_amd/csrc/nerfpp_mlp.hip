@@ -32,35 +32,68 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// ---- weight stream pipe: blocks of BLK_FRAGS*P KiB, double-buffered in LDS ----------------------
-template <int P, int NW>
+// LDS-DMA through inline asm (invisible to hipcc's waitcnt pass; completion is tracked by the counted
+// s_waitcnt of the ring pipe).  M0 carries the wave-uniform absolute LDS destination.
+__device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+
+// ---- weight stream pipe: blocks of BLK_FRAGS*P KiB streamed L2 -> LDS ----------------------------
+// RING = false (training kernels): double buffer, builtin DMA, vmcnt(0) + __syncthreads per block
+//        (activation stores share vmcnt with the DMA and may retire out of order, so only a full
+//        drain is safe there).
+// RING = true  (inference forward: no stores in flight): 4-deep ring, inline-asm DMA, COUNTED vmcnt
+//        (all outstanding VMEM ops are same-type loads, in order) and a raw s_barrier, so two blocks
+//        stay in flight while one is consumed.
+template <int P, int NW, bool RING>
 struct WeightPipe {
   static constexpr int BLK_BYTES = BLK_FRAGS * P * FRAG_BYTES;
+  static constexpr int NBUF = RING ? 4 : 2;
+  static constexpr int PER_BLK = BLK_FRAGS * P / NW;          // DMA wave-instructions per wave per block
   const char* g;
   int nblk, cur, wave, lane;
+  uint32_t lds_base;
   __device__ __forceinline__ void init(const void* stream, int nblk_, int wave_, int lane_) {
     g = (const char*)stream; nblk = nblk_; cur = 0; wave = wave_; lane = lane_;
-    issue(0);
+    lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) issue(b);
   }
   __device__ __forceinline__ void issue(int blk) {
     if (blk < nblk) {
       const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
-      char* dst = smem + (blk & 1) * BLK_BYTES;
+      const int slot = RING ? (blk & 3) : (blk & 1);
 #pragma unroll
-      for (int f = 0; f < BLK_FRAGS * P / NW; ++f) {
+      for (int f = 0; f < PER_BLK; ++f) {
         const int fi = f * NW + wave;
-        glds16(src + fi * FRAG_BYTES, dst + fi * FRAG_BYTES);
+        if constexpr (RING) glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
+        else glds16(src + fi * FRAG_BYTES, smem + slot * BLK_BYTES + fi * FRAG_BYTES);
       }
     }
   }
-  // make block `cur` readable, start fetching block cur+1, return LDS address of block cur
+  // make block `cur` readable, start fetching the next free slot, return LDS address of block cur
   __device__ __forceinline__ const char* acquire() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    issue(cur + 1);
-    const char* l = smem + (cur & 1) * BLK_BYTES + lane * 16;
-    ++cur;
-    return l;
+    if constexpr (RING) {
+      const int younger = nblk - 1 - cur < NBUF - 2 ? nblk - 1 - cur : NBUF - 2;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_BLK) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_BLK) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(cur + NBUF - 1);
+      const char* l = smem + (cur & 3) * BLK_BYTES + lane * 16;
+      ++cur;
+      return l;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      issue(cur + 1);
+      const char* l = smem + (cur & 1) * BLK_BYTES + lane * 16;
+      ++cur;
+      return l;
+    }
   }
 };
 
@@ -76,8 +109,8 @@ __device__ __forceinline__ void mfma_p(f32x16& acc, const char* lfrag, const Fra
 }
 
 // acc[ob] += W_stage[ob-block, :] * B   for one stage of NKC k-chunks x NOB out-blocks
-template <int NOB, int NKC, int P, int NW>
-__device__ __forceinline__ void stage_gemm(WeightPipe<P, NW>& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC]) {
+template <int NOB, int NKC, int P, typename Pipe>
+__device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC]) {
   constexpr int KPB = BLK_FRAGS / NOB;            // k-chunks per block
   static_assert(NKC % KPB == 0, "stage must be block aligned");
 #pragma unroll
@@ -168,6 +201,21 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NOB], const float* __res
     for (int q = 0; q < 4; ++q) {
       const float4 v = p[q];
       acc[ob][4 * q] = v.x; acc[ob][4 * q + 1] = v.y; acc[ob][4 * q + 2] = v.z; acc[ob][4 * q + 3] = v.w;
+    }
+  }
+}
+// same, but the bias stream has been copied to LDS (inference forward: keeps compiler-tracked global
+// loads out of the counted-vmcnt weight ring)
+template <int NOB>
+__device__ __forceinline__ void init_bias_lds(f32x16 (&acc)[NOB], uint32_t lds_off_bytes, int hi) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *(__attribute__((address_space(3))) f32x4*)(base + lds_off_bytes + (ob * 32 + hi * 16 + 4 * q) * 4);
+      acc[ob][4 * q] = v[0]; acc[ob][4 * q + 1] = v[1]; acc[ob][4 * q + 2] = v[2]; acc[ob][4 * q + 3] = v[3];
     }
   }
 }
@@ -357,11 +405,30 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   const size_t row = valid ? row_raw : (size_t)a.rows - 1;
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;          // this wave's first tile row
-  char* stage = smem + 2 * BLK_FRAGS * P * FRAG_BYTES + wave * STAGE_BYTES;
+  constexpr bool RINGMODE = !TRAIN && P == 1;                               // inference, bf16: counted-vmcnt ring
+  constexpr int WBYTES = (RINGMODE ? 4 : 2) * BLK_FRAGS * P * FRAG_BYTES;   // weight buffers
+  char* stage = smem + WBYTES + wave * STAGE_BYTES;
   const size_t nblk32 = a.rows_padded / 32;
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
-  WeightPipe<P, NW> pipe;
+  const uint32_t bias_lds = WBYTES + (TRAIN ? NW * STAGE_BYTES : 0) + NW * KPE * P * 1024;   // RINGMODE only
+  if constexpr (RINGMODE) {
+    for (int i = threadIdx.x; i < FWD_BIAS_FLOATS / 4; i += NW * 64)
+      *(float4*)(smem + bias_lds + i * 16) = ((const float4*)a.bias)[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  auto bias_init8 = [&](f32x16 (&acc_)[8], int off) {
+    if constexpr (!RINGMODE) init_bias<8>(acc_, a.bias + off, hi); else init_bias_lds<8>(acc_, bias_lds + off * 4, hi);
+  };
+  auto bias_init4 = [&](f32x16 (&acc_)[4], int off) {
+    if constexpr (!RINGMODE) init_bias<4>(acc_, a.bias + off, hi); else init_bias_lds<4>(acc_, bias_lds + off * 4, hi);
+  };
+  auto bias_init1 = [&](f32x16 (&acc_)[1], int off) {
+    if constexpr (!RINGMODE) init_bias<1>(acc_, a.bias + off, hi); else init_bias_lds<1>(acc_, bias_lds + off * 4, hi);
+  };
+
+  WeightPipe<P, NW, RINGMODE> pipe;
   pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
 
   float x[4], vd[3], depth_real;
@@ -369,14 +436,14 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   Frag<P> pe[KPE];
   encode_point<NET, P>(x, hi, pe);
   if (TRAIN) save_frags<KPE, P>(stage, a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), wrow0, lane, valid, pe);
-  char* pe_stash = smem + 2 * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0) + wave * (KPE * P * 1024);
+  char* pe_stash = smem + WBYTES + (TRAIN ? NW * STAGE_BYTES : 0) + wave * (KPE * P * 1024);
   stash_frags<KPE, P>(pe_stash, lane, pe);
 
   f32x16 acc[8];
   Frag<P> h[16];
   // L0
-  init_bias<8>(acc, a.bias + fs_bias_off(FS_L0), hi);
-  stage_gemm<8, KPE, P, NW>(pipe, acc, pe);
+  bias_init8(acc, fs_bias_off(FS_L0));
+  stage_gemm<8, KPE, P>(pipe, acc, pe);
   const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
   if (TRAIN) {
     mask_out[0] = bits;
@@ -384,8 +451,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   }
   // L1..L4
   for (int l = 1; l <= 4; ++l) {
-    init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
-    stage_gemm<8, 16, P, NW>(pipe, acc, h);
+    bias_init8(acc, fs_bias_off(FS_L0) + l * 256);
+    stage_gemm<8, 16, P>(pipe, acc, h);
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     if (TRAIN) {
       mask_out[(size_t)l * nblk32 * 64] = bits;
@@ -403,8 +470,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) in5[KPE + c] = h[c];
-    init_bias<8>(acc, a.bias + fs_bias_off(FS_L5), hi);
-    stage_gemm<8, KPE + 16, P, NW>(pipe, acc, in5);
+    bias_init8(acc, fs_bias_off(FS_L5));
+    stage_gemm<8, KPE + 16, P>(pipe, acc, in5);
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     if (TRAIN) {
       mask_out[(size_t)5 * nblk32 * 64] = bits;
@@ -413,8 +480,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   }
   // L6, L7
   for (int l = 6; l <= 7; ++l) {
-    init_bias<8>(acc, a.bias + fs_bias_off(FS_L0) + l * 256, hi);
-    stage_gemm<8, 16, P, NW>(pipe, acc, h);
+    bias_init8(acc, fs_bias_off(FS_L0) + l * 256);
+    stage_gemm<8, 16, P>(pipe, acc, h);
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     if (TRAIN) {
       mask_out[(size_t)l * nblk32 * 64] = bits;
@@ -423,13 +490,13 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   }
   // remap (no activation) and sigma, both from h7                       nerf_network.py:131-136
   Frag<P> rm[16];
-  init_bias<8>(acc, a.bias + fs_bias_off(FS_REMAP), hi);
-  stage_gemm<8, 16, P, NW>(pipe, acc, h);
+  bias_init8(acc, fs_bias_off(FS_REMAP));
+  stage_gemm<8, 16, P>(pipe, acc, h);
   acc_to_frags<8, P, ACT_NONE>(acc, rm);
   // (R is not saved: the weight gradients that need it are derived from M = dG^T H7, nerfpp_optim.hip)
   f32x16 acc1[1];
-  init_bias<1>(acc1, a.bias + fs_bias_off(FS_SIG), hi);
-  stage_gemm<1, 16, P, NW>(pipe, acc1, h);
+  bias_init1(acc1, fs_bias_off(FS_SIG));
+  stage_gemm<1, 16, P>(pipe, acc1, h);
   const float sigma_raw = acc1[0][0];
   // colour head                                                         nerf_network.py:137-138
   Frag<P> g[8];
@@ -442,8 +509,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     if (TRAIN) save_frags<2, P>(stage, a.ws.t[T_DIRX], plane_rows * 32, 32, wrow0, lane, valid, df);
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
-    init_bias<4>(acc4, a.bias + fs_bias_off(FS_RGB0), hi);
-    stage_gemm<4, 20, P, NW>(pipe, acc4, in);
+    bias_init4(acc4, fs_bias_off(FS_RGB0));
+    stage_gemm<4, 20, P>(pipe, acc4, in);
     const uint4 bits = acc_to_frags_relu_bits<4, P>(acc4, g);
     if (TRAIN) {
       mask_out[(size_t)8 * nblk32 * 64] = bits;
@@ -456,8 +523,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     for (int c = 0; c < 8; ++c) in[c] = g[c];
 #pragma unroll
     for (int c = 8; c < 16; ++c) in[c] = zero_frag<P>();
-    init_bias<1>(acc1, a.bias + fs_bias_off(FS_RGB1), hi);
-    stage_gemm<1, 16, P, NW>(pipe, acc1, in);
+    bias_init1(acc1, fs_bias_off(FS_RGB1));
+    stage_gemm<1, 16, P>(pipe, acc1, in);
   }
   if (valid && hi == 0) {
     float4 o;
@@ -486,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   const size_t nblk32 = a.rows_padded / 32;
   const uint4* mask_in = a.masks + (wrow0 / 32) * 64 + lane;
 
-  WeightPipe<P, NW> pipe;
+  WeightPipe<P, NW, false> pipe;
   pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
 
   float4 d = ((const float4*)a.d_out)[row];
@@ -505,7 +572,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     }
     f32x16 acc4[4];
     init_zero<4>(acc4);
-    stage_gemm<4, 4, P, NW>(pipe, acc4, in);
+    stage_gemm<4, 4, P>(pipe, acc4, in);
     mask_to_frags<4, P>(acc4, mask_in[(size_t)8 * nblk32 * 64], dg);
     save_frags<8, P>(stage, a.ws.t[T_DG], plane_rows * 128, 128, wrow0, lane, valid, dg);
   }
@@ -513,7 +580,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   Frag<P> dz[16];
   // B1: dR = Wrgb0[:, :256]^T dG  (no activation on the remap layer)
   init_zero<8>(acc);
-  stage_gemm<8, 8, P, NW>(pipe, acc, dg);
+  stage_gemm<8, 8, P>(pipe, acc, dg);
   acc_to_frags<8, P, ACT_NONE>(acc, dz);
   // (dR is not saved either, same reason)
   // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
@@ -528,14 +595,14 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
       save_frags<2, P>(stage, a.ws.t[T_DS], plane_rows * 32, 32, wrow0, lane, valid, ds);
     }
     init_zero<8>(acc);
-    stage_gemm<8, 18, P, NW>(pipe, acc, in);
+    stage_gemm<8, 18, P>(pipe, acc, in);
     mask_to_frags<8, P>(acc, mask_in[(size_t)7 * nblk32 * 64], dz);
     save_frags<16, P>(stage, a.ws.t[T_DZ0 + 7], plane_rows * 256, 256, wrow0, lane, valid, dz);
   }
   // B3..B9: dH_{l-1} = W_l^T dZ_l, l = 7..1
   for (int l = 7; l >= 1; --l) {
     init_zero<8>(acc);
-    stage_gemm<8, 16, P, NW>(pipe, acc, dz);
+    stage_gemm<8, 16, P>(pipe, acc, dz);
     mask_to_frags<8, P>(acc, mask_in[(size_t)(l - 1) * nblk32 * 64], dz);
     save_frags<16, P>(stage, a.ws.t[T_DZ0 + l - 1], plane_rows * 256, 256, wrow0, lane, valid, dz);
   }
@@ -555,7 +622,9 @@ static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0) + NW * kpe(NET) * P * 1024;
+  constexpr bool RINGMODE = !TRAIN && P == 1;
+  const size_t lds = (RINGMODE ? 4 : 2) * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0) + NW * kpe(NET) * P * 1024 +
+                     (RINGMODE ? FWD_BIAS_FLOATS * 4 : 0);
   hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 template <int NET, int P>
