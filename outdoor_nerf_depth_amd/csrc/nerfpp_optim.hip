@@ -67,21 +67,40 @@ __global__ void remap_copy_m_kernel(const float* __restrict__ grads, int w_g, in
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 128 * 256) m[i] = grads[w_g + (i >> 8) * ldg + (i & 255)];
 }
+// One wave per output row-segment so that every global read is coalesced:
+//   part A (128 x 256 outputs): out[o][j] = sum_i M[o][i] * Wr[j][i] + db_g[o] * b_r[j]
+//           wave = (o, 4 consecutive j): lanes stride over i, 4 dot products, wave reduction
+//   part B (256 x 256): dWr[j][i] = sum_o Wg[o][j] * M[o][i]      thread = (j, i), lanes over i
+//   part C (256):       db_r[j]   = sum_o Wg[o][j] * db_g[o]
 __global__ void remap_fixup_kernel(float* __restrict__ grads, const float* __restrict__ params,
                                    const float* __restrict__ m, int w_g, int b_g, int ldg, int w_r, int b_r) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < 128 * 256) {                                   // d Wg[o][j], j < 256
-    const int o = t >> 8, j = t & 255;
-    float acc = 0.f;
-    for (int i = 0; i < 256; ++i) acc += m[o * 256 + i] * params[w_r + j * 256 + i];
-    grads[w_g + o * ldg + j] = acc + grads[b_g + o] * params[b_r + j];
-  } else if (t < 128 * 256 + 256 * 256) {                // d Wr[j][i]
-    const int u = t - 128 * 256, j = u >> 8, i = u & 255;
+  constexpr int A_WAVES = 128 * 64;                       // (o, j-quad)
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (gw < A_WAVES) {
+    const int o = gw >> 6, j0 = (gw & 63) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < 256; i += 64) {
+      const float mv = m[o * 256 + i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += mv * params[w_r + (j0 + q) * 256 + i];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) acc[q] += __shfl_xor(acc[q], d, 64);
+    }
+    const float sel = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+    if (lane < 4) grads[w_g + o * ldg + j0 + lane] = sel + grads[b_g + o] * params[b_r + j0 + lane];
+    return;
+  }
+  const int t = (gw - A_WAVES) * 64 + lane;
+  if (t < 256 * 256) {                                    // d Wr[j][i]
+    const int j = t >> 8, i = t & 255;
     float acc = 0.f;
     for (int o = 0; o < 128; ++o) acc += params[w_g + o * ldg + j] * m[o * 256 + i];
     grads[w_r + j * 256 + i] = acc;
-  } else if (t < 128 * 256 + 256 * 256 + 256) {          // d b_r[j]
-    const int j = t - (128 * 256 + 256 * 256);
+  } else if (t < 256 * 256 + 256) {                       // d b_r[j]
+    const int j = t - 256 * 256;
     float acc = 0.f;
     for (int o = 0; o < 128; ++o) acc += params[w_g + o * ldg + j] * grads[b_g + o];
     grads[b_r + j] = acc;
@@ -96,7 +115,7 @@ void launch_remap_fixup(hipStream_t st, int net, float* grads, const float* para
   const int w_g = ref_w_off(net, RT_RGB0), b_g = ref_b_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);
   const int w_r = ref_w_off(net, RT_REMAP), b_r = ref_b_off(net, RT_REMAP);
   hipLaunchKernelGGL(remap_copy_m_kernel, dim3(128), dim3(256), 0, st, grads, w_g, ldg, tmp_m);
-  const int total = 128 * 256 + 256 * 256 + 256;
+  const int total = 128 * 64 * 64 + 256 * 256 + 256;          // part A waves * 64 + part B + part C threads
   hipLaunchKernelGGL(remap_fixup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, grads, params, tmp_m, w_g, b_g,
                      ldg, w_r, b_r);
 }
