@@ -162,11 +162,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hooks: NERFPP_SHARE_GPU=1 puts every rank on cuda:0 and NERFPP_DIST_BACKEND=gloo replaces RCCL,
+    # so the N > 1 code path can be smoke-tested on a 1-GPU box (numbers from such a run mean nothing)
+    if os.environ.get('NERFPP_SHARE_GPU'):
+        local = 0
+    backend = os.environ.get('NERFPP_DIST_BACKEND', 'nccl')
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the NeRF++ hot path has no CPU fallback'
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
