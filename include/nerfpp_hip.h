@@ -85,6 +85,16 @@ int nerfpp_sample_fine(void* stream, int n_rays, int s_old, int n_new, const flo
                        const float* weights, const float* u, float* z_merged, float* samples,
                        int64_t* above_inds);
 
+/* ray batch from a GPU-resident frame (nerf_sample_ray_split.py:10-34 get_rays_single_image and
+ * :178-221 random_sample): for every flat pixel index pix[i] (int64, row-major H x W)
+ *   ray_d = c2w[:3,:3] * K^-1 * [u+.5, v+.5, 1]^T (un-normalised), ray_o = c2w[:3,3],
+ *   rgb / depth_sup gathered from the frame's images, min_depth = 1e-4.
+ * cam: 21 floats on the device = K^-1 (3x3 row-major) then c2w[:3,:4] (row-major).
+ * rgb_img [H*W,3] / depth_img [H*W] and their outputs may be NULL. */
+int nerfpp_gather_rays(void* stream, int n_rays, int width, const float* cam, const int64_t* pix,
+                       const float* rgb_img, const float* depth_img, float* ray_o, float* ray_d,
+                       float* rgb, float* depth_sup, float* min_depth);
+
 /* ---------------------------------------------------------------- parameters */
 
 /* Index tables tying the reference's flat parameter order to the packed MFMA weight streams.

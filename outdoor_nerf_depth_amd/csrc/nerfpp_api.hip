@@ -154,6 +154,17 @@ int nerfpp_sample_fine(void* stream, int n_rays, int s_old, int n_new, const flo
   return check_launch("sample_fine");
 }
 
+int nerfpp_gather_rays(void* stream, int n_rays, int width, const float* cam, const int64_t* pix,
+                       const float* rgb_img, const float* depth_img, float* ray_o, float* ray_d, float* rgb,
+                       float* depth_sup, float* min_depth) {
+  REQUIRE(n_rays > 0 && width > 0 && cam && pix && ray_o && ray_d && min_depth, "non-null pointers");
+  REQUIRE((rgb == nullptr) || rgb_img, "rgb output needs rgb_img");
+  REQUIRE((depth_sup == nullptr) || depth_img, "depth_sup output needs depth_img");
+  launch_gather_rays((hipStream_t)stream, n_rays, width, cam, pix, rgb_img, depth_img, ray_o, ray_d, rgb, depth_sup,
+                     min_depth);
+  return check_launch("gather_rays");
+}
+
 int64_t nerfpp_level_tables_elems(void) { return tbl_layout().total; }
 
 int nerfpp_build_level_tables(int32_t* host_tables) {

@@ -530,3 +530,39 @@ void launch_loss(hipStream_t st, int n, int S, int type, float lambda_depth, flo
                      depth, depth_sup, fg_weights, fg_z, fg_dists, fg_far, scalars, g_rgb, g_depth,
                      g_fg_weights);
 }
+
+// ------------------------------------------------------------------------------------------------
+// f-1: ray batch from a GPU-resident frame.  nerf_sample_ray_split.py:10-34 (get_rays_single_image:
+// half-pixel centres, d = R * K^-1 * [u+.5, v+.5, 1]^T un-normalised, o = t) and :178-221
+// (random_sample: gather rgb / depth at the selected pixels, min_depth = 1e-4).
+// cam[21] = K^-1 (3x3 row-major) then c2w[:3, :4] (row-major), float32, as the host computed them.
+// ------------------------------------------------------------------------------------------------
+namespace nerfpp {
+__global__ void gather_rays_kernel(int n, int W, const float* __restrict__ cam, const int64_t* __restrict__ pix,
+                                   const float* __restrict__ rgb_img, const float* __restrict__ depth_img,
+                                   float* __restrict__ ray_o, float* __restrict__ ray_d, float* __restrict__ rgb,
+                                   float* __restrict__ depth_sup, float* __restrict__ min_depth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = pix[i];
+  const float u = (float)(p % W) + 0.5f, v = (float)(p / W) + 0.5f;
+  const float cx = (cam[0] * u + cam[1] * v) + cam[2];
+  const float cy = (cam[3] * u + cam[4] * v) + cam[5];
+  const float cz = (cam[6] * u + cam[7] * v) + cam[8];
+  const float* c2w = cam + 9;
+  ray_d[i * 3 + 0] = (c2w[0] * cx + c2w[1] * cy) + c2w[2] * cz;
+  ray_d[i * 3 + 1] = (c2w[4] * cx + c2w[5] * cy) + c2w[6] * cz;
+  ray_d[i * 3 + 2] = (c2w[8] * cx + c2w[9] * cy) + c2w[10] * cz;
+  ray_o[i * 3 + 0] = c2w[3]; ray_o[i * 3 + 1] = c2w[7]; ray_o[i * 3 + 2] = c2w[11];
+  if (rgb) { rgb[i * 3] = rgb_img[p * 3]; rgb[i * 3 + 1] = rgb_img[p * 3 + 1]; rgb[i * 3 + 2] = rgb_img[p * 3 + 2]; }
+  if (depth_sup) depth_sup[i] = depth_img[p];
+  min_depth[i] = 1e-4f;
+}
+}  // namespace nerfpp
+
+void launch_gather_rays(hipStream_t st, int n, int W, const float* cam, const int64_t* pix, const float* rgb_img,
+                        const float* depth_img, float* ray_o, float* ray_d, float* rgb, float* depth_sup,
+                        float* min_depth) {
+  hipLaunchKernelGGL(nerfpp::gather_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, cam, pix, rgb_img,
+                     depth_img, ray_o, ray_d, rgb, depth_sup, min_depth);
+}

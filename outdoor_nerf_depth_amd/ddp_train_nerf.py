@@ -118,6 +118,9 @@ def config_parser():
     p.add_argument('--N_rand_override', type=int, default=None,
                    help='the reference overrides N_rand to 1024 on >14 GB GPUs; this overrides that')
     p.add_argument('--i_test', type=int, default=50000, help='test-set render period (hard-coded 50000 upstream)')
+    p.add_argument('--device_sampling', action='store_true',
+                   help='keep the training frames in HBM and draw ray batches on the device (no host '
+                        'np.random.choice over H*W, no per-step H2D copies)')
     return p
 
 
@@ -272,6 +275,10 @@ def ddp_train_nerf(rank, args):
         val_ray_samplers = load_data_split(args.datadir, args.scene, split='test', skip=args.testskip,
                                            depth_sup_type=args.depth_sup_type)
     depth_scale = ray_samplers[0].get_depth_scale() or 1.0
+    device_samplers = None
+    if args.device_sampling:
+        from .device_sampler import DeviceRaySamplers
+        device_samplers = DeviceRaySamplers(ray_samplers, device)
 
     cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
     trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,
@@ -295,8 +302,11 @@ def ddp_train_nerf(rank, args):
 
     for global_step in range(start + 1, start + 1 + args.N_iters):
         time0 = time.time()
-        i = np.random.randint(low=0, high=len(ray_samplers))
-        ray_batch = batch_to_device(ray_samplers[i].random_sample(args.N_rand, center_crop=False), device)
+        if device_samplers is not None:
+            ray_batch = device_samplers.random_sample(args.N_rand)
+        else:
+            i = np.random.randint(low=0, high=len(ray_samplers))
+            ray_batch = batch_to_device(ray_samplers[i].random_sample(args.N_rand, center_crop=False), device)
         scalars = trainer.train_step(ray_batch)
         log_now = rank == 0 and (global_step % args.i_print == 0 or global_step < 10)
         if log_now:

@@ -1,0 +1,70 @@
+"""GPU-resident frames and on-device ray-batch sampling.
+
+The reference draws every batch on the host: `np.random.choice(H*W, N_rand, replace=False)` (a full
+permutation of 465 750 pixels), numpy fancy indexing of five arrays and five H2D copies per step
+(nerf_sample_ray_split.py:155-221, ddp_train_nerf.py:423-427).  At MI355X step times that is the
+bottleneck, so here the frames (rgb, depth prior, cameras) live in HBM and a batch is
+`torch.randperm` on the device + one `nerfpp_gather_rays` kernel that regenerates the rays from
+K^-1 / c2w (same formula as get_rays_single_image) and gathers rgb / depth_sup.
+Same dict keys as the reference's sampler output.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class DeviceRaySamplers(object):
+    """All training frames of one split on the device."""
+
+    def __init__(self, ray_samplers, device):
+        self.device = torch.device(device)
+        s0 = ray_samplers[0]
+        self.H, self.W = s0.H, s0.W
+        self.n_frames = len(ray_samplers)
+        cams = np.zeros((self.n_frames, 21), np.float32)
+        for f, s in enumerate(ray_samplers):
+            cams[f, :9] = np.linalg.inv(s.intrinsics[:3, :3]).astype(np.float32).reshape(-1)
+            cams[f, 9:] = np.asarray(s.c2w_mat, np.float32)[:3, :4].reshape(-1)
+        self.cams = torch.from_numpy(cams).to(self.device)
+        self.rgb = None
+        if s0.img is not None:
+            self.rgb = torch.stack([torch.from_numpy(np.ascontiguousarray(s.img, np.float32)) for s in ray_samplers]
+                                   ).to(self.device)                                    # [F, H*W, 3]
+        self.depth_sup = None
+        if s0.depth_sup is not None:
+            self.depth_sup = torch.stack([torch.from_numpy(np.ascontiguousarray(s.depth_sup, np.float32))
+                                          for s in ray_samplers]).to(self.device)      # [F, H*W]
+        self.depth_scale = s0.get_depth_scale()
+
+    def gather(self, frame, pix):
+        """Ray batch of `frame` at the flat pixel indices `pix` (int64 device tensor)."""
+        n = pix.numel()
+        dev = self.device
+        out = dict(ray_o=torch.empty(n, 3, device=dev), ray_d=torch.empty(n, 3, device=dev),
+                   min_depth=torch.empty(n, device=dev))
+        rgb_img = self.rgb[frame] if self.rgb is not None else None
+        dep_img = self.depth_sup[frame] if self.depth_sup is not None else None
+        if rgb_img is not None:
+            out['rgb'] = torch.empty(n, 3, device=dev)
+        if dep_img is not None:
+            out['depth_sup'] = torch.empty(n, device=dev)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        L.check(L.lib().nerfpp_gather_rays(C.c_void_p(torch.cuda.current_stream().cuda_stream), n, self.W,
+                                           p(self.cams[frame]), p(pix), p(rgb_img), p(dep_img), p(out['ray_o']),
+                                           p(out['ray_d']), p(out.get('rgb')), p(out.get('depth_sup')),
+                                           p(out['min_depth'])), 'nerfpp_gather_rays')
+        if 'depth_sup' in out:
+            out['depth_gt'] = out['depth_sup']
+        return out
+
+    def random_sample(self, N_rand, frame=None):
+        """One random frame (host RNG, like ddp_train_nerf.py:423), N_rand distinct pixels (device RNG)."""
+        if frame is None:
+            frame = int(np.random.randint(low=0, high=self.n_frames))
+        pix = torch.randperm(self.H * self.W, device=self.device)[:N_rand]
+        out = self.gather(frame, pix)
+        out['frame'] = frame
+        return out

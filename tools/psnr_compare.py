@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Train the same synthetic KITTI-shaped scene in split-bf16 (parity) and single-pass bf16 (speed)
+precision with identical data / uniforms order and compare held-out PSNR (mse2psnr on float images,
+the in-loop definition of ddp_train_nerf.py:558,623) and depth RMSE.
+
+    python tools/psnr_compare.py [--iters 3000] [--hw 47,155] [--frames 40] [--n_rand 1024]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from outdoor_nerf_depth_amd import _lib as L                                    # noqa: E402
+from outdoor_nerf_depth_amd.data_loader_split import synthetic_ray_samplers    # noqa: E402
+from outdoor_nerf_depth_amd.device_sampler import DeviceRaySamplers            # noqa: E402
+from outdoor_nerf_depth_amd.ddp_train_nerf import render_single_image, mse2psnr  # noqa: E402
+from outdoor_nerf_depth_amd.trainer import NerfppTrainer                       # noqa: E402
+
+
+def run(prec, args, train, test, dev):
+    torch.manual_seed(777)
+    np.random.seed(777)
+    ds = DeviceRaySamplers(train, dev)
+    tr = NerfppTrainer(dev, precision=prec, use_depth=True, depth_loss_type='mse', lambda_depth=0.1,
+                       depth_scale=ds.depth_scale or 1.0)
+    t0 = time.time()
+    for it in range(args.iters):
+        tr.train_step(ds.random_sample(args.n_rand))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    psnrs, rmses = [], []
+    for s in test:
+        ret = render_single_image(0, 1, tr, s, 8192)
+        im = ret[-1]['rgb'].numpy()
+        psnrs.append(float(mse2psnr(np.mean((s.get_img() - im) ** 2))))
+        gt = s.get_gt_depth_img()
+        valid = gt > 0
+        if valid.any():
+            rmses.append(float(np.sqrt(np.mean((ret[-1]['depth'].numpy()[valid] - gt[valid]) ** 2)) / s.get_depth_scale()))
+    return dict(psnr=float(np.mean(psnrs)), depth_rmse_m=float(np.mean(rmses)) if rmses else None,
+                train_s=dt, it_per_s=args.iters / dt)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--iters', type=int, default=3000)
+    p.add_argument('--hw', type=str, default='47,155')
+    p.add_argument('--frames', type=int, default=40)
+    p.add_argument('--n_rand', type=int, default=1024)
+    a = p.parse_args()
+    H, W = [int(x) for x in a.hw.split(',')]
+    dev = torch.device('cuda:0')
+    train = synthetic_ray_samplers('train', 1, 'mono_crop', a.frames, H, W)
+    test = synthetic_ray_samplers('test', 1, 'mono_crop', a.frames, H, W)
+    out = {'config': vars(a), 'n_train_frames': len(train), 'n_test_frames': len(test)}
+    out['split_bf16'] = run(L.PREC_SPLIT_BF16, a, train, test, dev)
+    out['bf16'] = run(L.PREC_BF16, a, train, test, dev)
+    out['psnr_gap_db'] = out['bf16']['psnr'] - out['split_bf16']['psnr']
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
