@@ -29,8 +29,11 @@ def run(prec, args, train, test, dev):
     tr = NerfppTrainer(dev, precision=prec, use_depth=True, depth_loss_type='mse', lambda_depth=0.1,
                        depth_scale=ds.depth_scale or 1.0)
     t0 = time.time()
+    curve = {}
     for it in range(args.iters):
         tr.train_step(ds.random_sample(args.n_rand))
+        if (it + 1) in args.eval_at:
+            curve[it + 1] = float(np.mean([float(mse2psnr(np.mean((s.get_img() - render_single_image(0, 1, tr, s, 8192)[-1]['rgb'].numpy()) ** 2))) for s in test]))
     torch.cuda.synchronize()
     dt = time.time() - t0
     psnrs, rmses = [], []
@@ -42,7 +45,7 @@ def run(prec, args, train, test, dev):
         valid = gt > 0
         if valid.any():
             rmses.append(float(np.sqrt(np.mean((ret[-1]['depth'].numpy()[valid] - gt[valid]) ** 2)) / s.get_depth_scale()))
-    return dict(psnr=float(np.mean(psnrs)), depth_rmse_m=float(np.mean(rmses)) if rmses else None,
+    return dict(psnr=float(np.mean(psnrs)), curve=curve, depth_rmse_m=float(np.mean(rmses)) if rmses else None,
                 train_s=dt, it_per_s=args.iters / dt)
 
 
@@ -52,12 +55,14 @@ def main():
     p.add_argument('--hw', type=str, default='47,155')
     p.add_argument('--frames', type=int, default=40)
     p.add_argument('--n_rand', type=int, default=1024)
+    p.add_argument('--evals', type=str, default='')
     a = p.parse_args()
+    a.eval_at = set(int(x) for x in a.evals.split(',') if x)
     H, W = [int(x) for x in a.hw.split(',')]
     dev = torch.device('cuda:0')
     train = synthetic_ray_samplers('train', 1, 'mono_crop', a.frames, H, W)
     test = synthetic_ray_samplers('test', 1, 'mono_crop', a.frames, H, W)
-    out = {'config': vars(a), 'n_train_frames': len(train), 'n_test_frames': len(test)}
+    out = {'config': {k: v for k, v in vars(a).items() if k != 'eval_at'}, 'n_train_frames': len(train), 'n_test_frames': len(test)}
     out['split_bf16'] = run(L.PREC_SPLIT_BF16, a, train, test, dev)
     out['bf16'] = run(L.PREC_BF16, a, train, test, dev)
     out['psnr_gap_db'] = out['bf16']['psnr'] - out['split_bf16']['psnr']
