@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Offline test-set render + metrics: the counterpart of nerf-methods/nerfplusplus/ddp_test_nerf.py
+(:23-160) on the HIP path.  Same parser as training (`--config`, `--render_splits`, `--ckpt_path`);
+for every split renders each image with the newest (or given) checkpoint -- deterministic
+sampling, no perturbation -- and writes under {basedir}/{expname}/render_{split}_{step:06d}/:
+  {idx:06d}.png, fg_*.png, bg_*.png, depth_*.png (uint16 = metres*256), and
+  psnr_/rmse_/absrel_{step:06d}.txt (per image, then the mean).
+PSNR = mse2psnr(mean((gt-im)^2)) on float images; depth metrics use the 80 m cap and
+1e-3 < gt < 80 validity of the reference (:87-116).
+"""
+import os
+import sys
+
+import numpy as np
+
+from .ddp_train_nerf import (config_parser, validate_args, setup_logger, render_single_image, load_checkpoint,
+                             find_latest_checkpoint, depth_metrics, mse2psnr, to8b, logger)
+
+
+def ddp_test_nerf(rank, args):
+    import torch
+    from PIL import Image
+    from .trainer import NerfppTrainer
+    from .data_loader_split import load_data_split, synthetic_ray_samplers
+    from . import _lib as L
+    setup_logger()
+    world = args.world_size
+    torch.cuda.set_device(rank)
+    device = torch.device('cuda', rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ['MASTER_PORT'] = str(args.port)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
+    trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,
+                            cascade_samples=cascade, use_depth=False, world_size=1)
+    ckpt, start = find_latest_checkpoint(args)
+    if ckpt is None:
+        raise SystemExit('no checkpoint found under %s' % os.path.join(args.basedir, args.expname))
+    logger.info('Reloading from: {}'.format(ckpt))
+    load_checkpoint(ckpt, trainer)
+    for split in [x.strip() for x in args.render_splits.strip().split(',')]:
+        out_dir = os.path.join(args.basedir, args.expname, 'render_{}_{:06d}'.format(split, start))
+        if rank == 0:
+            os.makedirs(out_dir, exist_ok=True)
+        if args.synthetic:
+            hw = [int(x) for x in args.synthetic_hw.split(',')] if args.synthetic_hw else [None, None]
+            samplers = synthetic_ray_samplers(split, args.testskip, args.depth_sup_type, args.synthetic_frames,
+                                              hw[0], hw[1])
+        else:
+            samplers = load_data_split(args.datadir, args.scene, split, skip=args.testskip,
+                                       depth_sup_type=args.depth_sup_type)
+        psnrs, rmses, abs_rels = [], [], []
+        for idx, sampler in enumerate(samplers):
+            ret = render_single_image(rank, world, trainer, sampler, args.chunk_size)
+            if rank != 0:
+                continue
+            fname = '{:06d}.png'.format(idx)
+            im = ret[-1]['rgb'].numpy()
+            if sampler.get_img() is not None:
+                gt_im = sampler.get_img()
+                psnrs.append(float(mse2psnr(np.mean((gt_im - im) * (gt_im - im)))))
+            if sampler.get_gt_depth_img() is not None:
+                rmse, absrel = depth_metrics(ret[-1]['depth'].numpy(), sampler)
+                rmses.append(rmse)
+                abs_rels.append(absrel)
+                d16 = ((ret[-1]['depth'].numpy() / sampler.get_depth_scale()).clip(1e-3, 80) * 256.0)
+                Image.fromarray(d16.astype(np.uint16)).save(os.path.join(out_dir, 'depth_' + fname))
+            Image.fromarray(to8b(im)).save(os.path.join(out_dir, fname))
+            Image.fromarray(to8b(ret[-1]['fg_rgb'].numpy())).save(os.path.join(out_dir, 'fg_' + fname))
+            Image.fromarray(to8b(ret[-1]['bg_rgb'].numpy())).save(os.path.join(out_dir, 'bg_' + fname))
+        if rank == 0:
+            for name, vals in (('psnr', psnrs), ('rmse', rmses), ('absrel', abs_rels)):
+                if vals:
+                    vals = vals + [float(np.mean(vals))]
+                    with open(os.path.join(out_dir, '%s_%06d.txt' % (name, start)), 'w') as f:
+                        f.write('\n'.join(str(p) for p in vals))
+                    logger.info('%s %s: %s' % (split, name, vals[-1]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test(argv=None):
+    import torch
+    args = config_parser().parse_args(argv)
+    validate_args(args)
+    if args.world_size == -1:
+        args.world_size = torch.cuda.device_count()
+    if args.world_size <= 1:
+        args.world_size = 1
+        ddp_test_nerf(0, args)
+    else:
+        torch.multiprocessing.spawn(ddp_test_nerf, args=(args,), nprocs=args.world_size, join=True)
+
+
+if __name__ == '__main__':
+    setup_logger()
+    test()

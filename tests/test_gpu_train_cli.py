@@ -32,6 +32,14 @@ def test_train_cli_checkpoint_resume_and_eval(tmp_path):
     assert (rdir / '000000.png').exists() and (rdir / 'psnr_000005.txt').exists() and (rdir / 'rmse_000005.txt').exists()
     psnr = [float(x) for x in (rdir / 'psnr_000005.txt').read_text().split()]
     assert np.isfinite(psnr).all() and len(psnr) == 3          # 2 test frames + mean
+    # offline evaluation entry point (ddp_test_nerf.py): same parser, newest checkpoint, metric files
+    from outdoor_nerf_depth_amd import ddp_test_nerf as TT
+    targs = T.config_parser().parse_args(base + ['--render_splits', 'test'])
+    targs.world_size = 1
+    TT.ddp_test_nerf(0, targs)
+    tdir = exp / 'render_test_000005'
+    assert (tdir / 'fg_000001.png').exists() and (tdir / 'depth_000001.png').exists()
+    assert len((tdir / 'absrel_000005.txt').read_text().split()) == 3
     # "already trained" guard of the reference (:733-735)
     with pytest.raises(SystemExit) as e:
         T.train(base + ['--N_iters', '2'])
