@@ -2,8 +2,8 @@
 //
 //   mlp_fwd_kernel : positional encoding (+ inverted-sphere parametrisation for the background)
 //                    -> 8x256 trunk with skip -> sigma / remap / colour heads, activations chained
-//                    in registers, weights streamed L2 -> LDS (global_load_lds, double-buffered
-//                    16-fragment blocks) -> v_mfma_f32_32x32x16_bf16.
+//                    in registers, weights streamed L2 -> LDS (global_load_lds, 16-fragment blocks)
+//                    -> v_mfma_f32_32x32x16_bf16.
 //                    Reference: nerf_network.py:42-60,120-142; ddp_model.py:16-45,86-94,107-120.
 //   mlp_bwd_kernel : the dX chain of the same network (closed-form backward of the above; the
 //                    reference relies on autograd), again chained in registers; writes every dZ
@@ -12,9 +12,25 @@
 // Precision P: 1 = single-pass bf16 operands / f32 accumulate ("speed" mode);
 //              2 = split-bf16 (x = hi + lo, 3 MFMA passes hi*hi + hi*lo + lo*hi), which holds
 //                  ~1e-5 relative error against the float32 reference ("parity" mode).
+//
+// Weight-pipe modes (WeightPipe<P, NW, MODE>):
+//   PIPE_CLASSIC : double buffer, builtin DMA, every wave drains vmcnt(0) + __syncthreads per block.
+//                  Used by the split-bf16 training kernels.
+//   PIPE_RING    : inference forward (no stores in flight): 4-deep ring, inline-asm DMA, COUNTED
+//                  vmcnt (all outstanding VMEM ops are same-type loads, in order), raw s_barrier.
+//   PIPE_ROLES   : bf16 training kernels.  Activation stores and the weight DMA share vmcnt and may
+//                  retire out of order, so a wave that stores can only wait for its DMA with a full
+//                  drain -- which serialises "compute" and "write 16 KB per wave" at every layer.
+//                  Here wave 0 (the LOADER) is the only wave that issues and waits for the DMA, and it
+//                  never stores: it hands its tile to wave 1 through an LDS region, and wave 1 writes
+//                  it out after the next barrier.  The other waves never touch vmcnt, so their stores
+//                  drain under the following MFMA work.  Biases come from LDS and (backward) the ReLU
+//                  sign words are DMA'd into LDS by the loader, so no wave issues a global LOAD in
+//                  steady state either.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 #include "nerfpp_common.h"
 #include "nerfpp_kernels.h"
 
@@ -22,78 +38,86 @@ namespace nerfpp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define LDS_AS __attribute__((address_space(3)))
 
 template <int P> struct Frag { bf16x8 v[P]; };
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
+enum { PIPE_CLASSIC = 0, PIPE_RING = 1, PIPE_ROLES = 2 };
 
-// LDS-DMA through inline asm (invisible to hipcc's waitcnt pass; completion is tracked by the counted
-// s_waitcnt of the ring pipe).  M0 carries the wave-uniform absolute LDS destination.
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (LDS_AS void*)l, 16, 0, 0);
+}
+// LDS-DMA through inline asm (invisible to hipcc's waitcnt pass; completion is tracked by our own
+// s_waitcnt).  M0 carries the wave-uniform absolute LDS destination.
 __device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
   const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
+__device__ __forceinline__ uint32_t lds_base_addr() { return (uint32_t)(uintptr_t)(LDS_AS char*)smem; }
 
-// ---- weight stream pipe: blocks of BLK_FRAGS*P KiB streamed L2 -> LDS ----------------------------
-// RING = false (training kernels): double buffer, builtin DMA, vmcnt(0) + __syncthreads per block
-//        (activation stores share vmcnt with the DMA and may retire out of order, so only a full
-//        drain is safe there).
-// RING = true  (inference forward: no stores in flight): 4-deep ring, inline-asm DMA, COUNTED vmcnt
-//        (all outstanding VMEM ops are same-type loads, in order) and a raw s_barrier, so two blocks
-//        stay in flight while one is consumed.
-template <int P, int NW, bool RING>
+template <int P, int NW, int MODE>
 struct WeightPipe {
   static constexpr int BLK_BYTES = BLK_FRAGS * P * FRAG_BYTES;
-  static constexpr int NBUF = RING ? 4 : 2;
+  static constexpr int NBUF = MODE == PIPE_RING ? 4 : 2;
   static constexpr int PER_BLK = BLK_FRAGS * P / NW;          // DMA wave-instructions per wave per block
   const char* g;
   int nblk, cur, wave, lane;
   uint32_t lds_base;
   __device__ __forceinline__ void init(const void* stream, int nblk_, int wave_, int lane_) {
     g = (const char*)stream; nblk = nblk_; cur = 0; wave = wave_; lane = lane_;
-    lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    lds_base = lds_base_addr();
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b) issue(b);
   }
   __device__ __forceinline__ void issue(int blk) {
-    if (blk < nblk) {
-      const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
-      const int slot = RING ? (blk & 3) : (blk & 1);
+    if (blk >= nblk) return;
+    const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
+    const int slot = blk & (NBUF - 1);
+    if constexpr (MODE == PIPE_ROLES) {
+      if (wave != 0) return;                                   // the loader wave issues the whole block
+#pragma unroll
+      for (int fi = 0; fi < BLK_FRAGS * P; ++fi)
+        glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
+    } else {
 #pragma unroll
       for (int f = 0; f < PER_BLK; ++f) {
         const int fi = f * NW + wave;
-        if constexpr (RING) glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
+        if constexpr (MODE == PIPE_RING) glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
         else glds16(src + fi * FRAG_BYTES, smem + slot * BLK_BYTES + fi * FRAG_BYTES);
       }
     }
   }
   // make block `cur` readable, start fetching the next free slot, return LDS address of block cur
   __device__ __forceinline__ const char* acquire() {
-    if constexpr (RING) {
+    if constexpr (MODE == PIPE_RING) {
       const int younger = nblk - 1 - cur < NBUF - 2 ? nblk - 1 - cur : NBUF - 2;
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_BLK) : "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_BLK) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       issue(cur + NBUF - 1);
-      const char* l = smem + (cur & 3) * BLK_BYTES + lane * 16;
-      ++cur;
-      return l;
+    } else if constexpr (MODE == PIPE_ROLES) {
+      // loader: every VMEM op it has in flight is a load (weights, bias, masks) -> a full drain is
+      // cheap and exact.  Everybody: LDS writes of the hand-off region must have landed.
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(cur + 1);
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       issue(cur + 1);
-      const char* l = smem + (cur & 1) * BLK_BYTES + lane * 16;
-      ++cur;
-      return l;
     }
+    const char* l = smem + (cur & (NBUF - 1)) * BLK_BYTES + lane * 16;
+    ++cur;
+    return l;
   }
 };
 
@@ -108,14 +132,21 @@ __device__ __forceinline__ void mfma_p(f32x16& acc, const char* lfrag, const Fra
   }
 }
 
-// acc[ob] += W_stage[ob-block, :] * B   for one stage of NKC k-chunks x NOB out-blocks
-template <int NOB, int NKC, int P, typename Pipe>
-__device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC]) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+#define HOOK(...) [&]() __attribute__((always_inline)) { __VA_ARGS__; }
+#define IC(n) std::integral_constant<int, (n)>{}
+
+// acc[ob] += W_stage[ob-block, :] * B   for one stage of NKC k-chunks x NOB out-blocks.
+// `hook()` runs once, right after the first block's barrier (PIPE_ROLES: wave 1 flushes the loader's
+// tile of the previous stage there; the loader queues the next ReLU-sign DMA).
+template <int NOB, int NKC, int P, typename Pipe, typename Hook>
+__device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC], const Hook& hook) {
   constexpr int KPB = BLK_FRAGS / NOB;            // k-chunks per block
   static_assert(NKC % KPB == 0, "stage must be block aligned");
 #pragma unroll
   for (int blk = 0; blk < NKC / KPB; ++blk) {
     const char* l = pipe.acquire();
+    if (blk == 0) hook();
 #pragma unroll
     for (int kl = 0; kl < KPB; ++kl) {
 #pragma unroll
@@ -175,21 +206,56 @@ __device__ __forceinline__ void unstash_frags(const char* base, int lane, Frag<P
     for (int p = 0; p < P; ++p) *(uint4*)&f[c].v[p] = *(const uint4*)(base + ((c * P + p) * 64 + lane) * 16);
 }
 
-// ReLU + conversion + sign bits in one pass over the accumulators (bit ob*16 + r <-> acc[ob][r] > 0)
+// ReLU + conversion + sign words in one pass over the accumulators.
+// Sign-word layout (uint4 per lane per stage, consumed by mask_to_frags in the backward kernel): element
+// (ob, r = 8*hh + 2*w + e) lives in word ob>>1 at bit (e ? 31 : 15) - j, j = (ob&1)*8 + hh*4 + w, and holds
+// the SIGN BIT of the pre-activation (set = unit inactive, gradient 0).  In that layout the 16 packed
+// bf16 dwords of a word are gathered with 2 VALU ops each, and ReLU is one packed signed-int16 max per
+// dword (a bf16 with the sign bit set is a negative int16), instead of compare/select/or per element.
 template <int NOB, int P>
 __device__ __forceinline__ uint4 acc_to_frags_relu_bits(const f32x16 (&acc)[NOB], Frag<P> (&h)[2 * NOB]) {
   uint32_t m[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+    for (int hh = 0; hh < 2; ++hh) {
+      if constexpr (P == 1) {
+        bf16x8 q;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float v = acc[ob][8 * hh + t];
-        m[ob >> 1] |= (v > 0.f ? 1u : 0u) << ((ob & 1) * 16 + 8 * hh + t);
-        set_slot<P>(h[2 * ob + hh], t, fmaxf(v, 0.f));
+        for (int t = 0; t < 8; ++t) q[t] = (__bf16)acc[ob][8 * hh + t];
+        const u32x4 d = __builtin_bit_cast(u32x4, q);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int j = (ob & 1) * 8 + hh * 4 + w;
+          m[ob >> 1] |= (d[w] >> j) & (0x80008000u >> j);
+        }
+        const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        h[2 * ob + hh].v[0] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, q), zero));
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float v = acc[ob][8 * hh + t];
+          const int j = (ob & 1) * 8 + hh * 4 + (t >> 1);
+          m[ob >> 1] |= (__float_as_uint(v) >> 31) << (((t & 1) ? 31 : 15) - j);
+          set_slot<P>(h[2 * ob + hh], t, fmaxf(v, 0.f));
+        }
       }
+    }
   return make_uint4(m[0], m[1], m[2], m[3]);
+}
+
+// rows past the end of the batch (last tile only): their fragments are written out as zeros
+template <int N, int P>
+__device__ __forceinline__ void zero_invalid(Frag<P> (&f)[N], bool valid) {
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      u32x4 d = __builtin_bit_cast(u32x4, f[c].v[p]);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) d[w] = valid ? d[w] : 0u;
+      f[c].v[p] = __builtin_bit_cast(bf16x8, d);
+    }
 }
 
 template <int NOB>
@@ -204,17 +270,17 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NOB], const float* __res
     }
   }
 }
-// same, but the bias stream has been copied to LDS (inference forward: keeps compiler-tracked global
-// loads out of the counted-vmcnt weight ring)
+// same, but the bias stream has been copied to LDS (keeps compiler-tracked global loads out of the
+// steady state of the ring / roles pipes)
 template <int NOB>
 __device__ __forceinline__ void init_bias_lds(f32x16 (&acc)[NOB], uint32_t lds_off_bytes, int hi) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)smem;
+  LDS_AS char* base = (LDS_AS char*)smem;
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *(__attribute__((address_space(3))) f32x4*)(base + lds_off_bytes + (ob * 32 + hi * 16 + 4 * q) * 4);
+      const f32x4 v = *(LDS_AS f32x4*)(base + lds_off_bytes + (ob * 32 + hi * 16 + 4 * q) * 4);
       acc[ob][4 * q] = v[0]; acc[ob][4 * q + 1] = v[1]; acc[ob][4 * q + 2] = v[2]; acc[ob][4 * q + 3] = v[3];
     }
   }
@@ -227,36 +293,40 @@ __device__ __forceinline__ void init_zero(f32x16 (&acc)[NOB]) {
     for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
 }
 
-// fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements).
-// The accumulator layout gives every lane 8-byte pieces of 32 DIFFERENT rows, so the tile is first
-// transposed through a per-wave LDS staging area ([32 rows][<=128 cols], row stride 272 B) and then
-// written with 16 B per lane, whole 128..256-byte row segments per instruction.
-// Rows past the end of the batch (tile tail, < rows_padded) are written as zeros so the
-// weight-gradient GEMMs can run over whole 32-row chunks without masking.
-constexpr int STAGE_ROW = 272;                      // 256 B of data + 16 B pad (keeps 16-B alignment)
-constexpr int STAGE_BYTES = 32 * STAGE_ROW;         // per wave
-
 __device__ __forceinline__ void lds_wave_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
+  const u32x4 vv = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(vv, (u32x4*)gptr);
+}
 
-template <int NCH, int P>
+// fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements).
+// The accumulator layout gives every lane 8-byte pieces of 32 DIFFERENT rows, so the tile is first
+// transposed through a per-wave LDS staging area ([32 rows][PC*16 cols], row stride PC*32+16 B) and
+// then written with 16 B per lane (whole 128..256-byte row segments per instruction), non-temporal.
+// (Rows past the end of the batch (tile tail, < rows_padded) must be written as zeros so the
+// weight-gradient GEMMs can run over whole 32-row chunks without masking: the kernels zero those
+// lanes' fragments -- zero_invalid, last tile only -- before they get here.)
+template <int PC> constexpr int stage_row() { return PC * 32 + 16; }
+template <int PC> constexpr int stage_bytes() { return 32 * stage_row<PC>(); }
+
+template <int NCH, int P, int PC>
 __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t plane, int ld, size_t wave_row0,
-                                           int lane, bool valid, const Frag<P> (&h)[NCH]) {
+                                           int lane, const Frag<P> (&h)[NCH]) {
+  constexpr int SR = stage_row<PC>();
   const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
 #pragma unroll
-    for (int c0 = 0; c0 < NCH; c0 += 8) {
-      constexpr int dummy = 0; (void)dummy;
-      const int nc = NCH - c0 < 8 ? NCH - c0 : 8;           // chunks in this pass (compile-time after unroll)
-      char* w = stage + j * STAGE_ROW + 8 * hi;
+    for (int c0 = 0; c0 < NCH; c0 += PC) {
+      const int nc = NCH - c0 < PC ? NCH - c0 : PC;           // chunks in this pass (compile-time after unroll)
+      char* w = stage + j * SR + 8 * hi;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < PC; ++c) {
         if (c < nc) {
-          uint4 bits = *(const uint4*)&h[c0 + c].v[p];
-          if (!valid) bits = make_uint4(0, 0, 0, 0);
+          const uint4 bits = *(const uint4*)&h[c0 + c].v[p];
           *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
           *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
         }
@@ -264,15 +334,22 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
       lds_wave_sync();
       const int lpr = 2 * nc;                               // 16-byte pieces per row
       char* g = (char*)(base + p * plane + wave_row0 * ld + c0 * 16);
+      if ((lpr & (lpr - 1)) == 0) {
+        // power-of-two row length: one per-lane base address + compile-time offsets
+        const int rpi = 64 / lpr, row = lane / lpr, piece = lane - row * lpr;
+        char* gl = g + (size_t)row * ld * 2 + piece * 16;
+        const char* sl = stage + row * SR + piece * 16;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int idx = it * 64 + lane;
-        if (it * 64 < 32 * lpr && idx < 32 * lpr) {
-          const int row = idx / lpr, piece = idx - row * lpr;
-          const uint4 v = *(const uint4*)(stage + row * STAGE_ROW + piece * 16);
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 vv = {v.x, v.y, v.z, v.w};
-          __builtin_nontemporal_store(vv, (u32x4*)(g + (size_t)row * ld * 2 + piece * 16));
+        for (int it = 0; it < PC; ++it)
+          if (it < nc) store_nt16(gl + (size_t)it * rpi * ld * 2, *(const uint4*)(sl + it * rpi * SR));
+      } else {
+#pragma unroll
+        for (int it = 0; it < PC; ++it) {
+          const int idx = it * 64 + lane;
+          if (it < nc) {
+            const int row = idx / lpr, piece = idx - row * lpr;
+            store_nt16(g + (size_t)row * ld * 2 + piece * 16, *(const uint4*)(stage + row * SR + piece * 16));
+          }
         }
       }
       lds_wave_sync();
@@ -280,30 +357,77 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
   }
 }
 
-// ReLU sign bits of one stage: bit ob*16 + r  <->  acc[ob][r] > 0
-template <int NOB>
-__device__ __forceinline__ uint4 relu_bits(const f32x16 (&acc)[NOB]) {
-  uint32_t m[4] = {0, 0, 0, 0};
+// ---- PIPE_ROLES hand-off: the loader's tile goes to an LDS region, wave 1 writes it out later --------
+constexpr int REGION_ROW = 528;                              // 512 B of data + 16 B pad
+constexpr int REGION_MASK = 32 * REGION_ROW;                 // 64 x 16 B of ReLU sign words after the tile
+constexpr int REGION_BYTES = REGION_MASK + 1024 + 512;       // 18432
+
+template <int NCH>
+__device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<1> (&h)[NCH]) {
+  const int j = lane & 31, hi = lane >> 5;
+  char* w = region + j * REGION_ROW + 8 * hi;
 #pragma unroll
-  for (int ob = 0; ob < NOB; ++ob)
+  for (int c = 0; c < NCH; ++c) {
+    const uint4 bits = *(const uint4*)&h[c].v[0];
+    *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
+    *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
+  }
+}
+// wave 1, after the barrier that follows the loader's handoff_write: region -> HBM (mask_dst: this lane's
+// slot of the loader's sign-word block, or nullptr)
+template <int NCH>
+__device__ __forceinline__ void handoff_flush(const char* region, int lane, __bf16* base, int ld, size_t row0,
+                                              uint4* mask_dst) {
+  constexpr int LPR = 2 * NCH;
+  char* g = (char*)(base + row0 * ld);
+  if constexpr ((LPR & (LPR - 1)) == 0) {
+    constexpr int RPI = 64 / LPR;
+    const int row = lane / LPR, piece = lane - row * LPR;
+    char* gl = g + (size_t)row * ld * 2 + piece * 16;
+    const char* sl = region + row * REGION_ROW + piece * 16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m[ob >> 1] |= (acc[ob][r] > 0.f ? 1u : 0u) << ((ob & 1) * 16 + r);
-  return make_uint4(m[0], m[1], m[2], m[3]);
+    for (int it = 0; it < NCH; ++it) store_nt16(gl + (size_t)it * RPI * ld * 2, *(const uint4*)(sl + it * RPI * REGION_ROW));
+  } else {
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / LPR, piece = idx - row * LPR;
+      store_nt16(g + (size_t)row * ld * 2 + piece * 16, *(const uint4*)(region + row * REGION_ROW + piece * 16));
+    }
+  }
+  if (mask_dst) *mask_dst = *(const uint4*)(region + REGION_MASK + lane * 16);
 }
 
-// dH (accumulators) * [forward activation > 0] -> dZ fragments
+// dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
 template <int NOB, int P>
 __device__ __forceinline__ void mask_to_frags(const f32x16 (&acc)[NOB], const uint4 bits, Frag<P> (&dz)[2 * NOB]) {
-  const uint32_t m[4] = {bits.x, bits.y, bits.z, bits.w};
+  const uint32_t act[4] = {~bits.x, ~bits.y, ~bits.z, ~bits.w};       // bit set = unit active
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+    for (int hh = 0; hh < 2; ++hh) {
+      if constexpr (P == 1) {
+        bf16x8 q;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const bool on = (m[ob >> 1] >> ((ob & 1) * 16 + 8 * hh + t)) & 1u;
-        set_slot<P>(dz[2 * ob + hh], t, on ? acc[ob][8 * hh + t] : 0.f);
+        for (int t = 0; t < 8; ++t) q[t] = (__bf16)acc[ob][8 * hh + t];
+        u32x4 d = __builtin_bit_cast(u32x4, q);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int j = (ob & 1) * 8 + hh * 4 + w;
+          // bits 31 / 15 of (act << j) are this dword's two flags: smear each over its half
+          const s16x2 keep = __builtin_bit_cast(s16x2, act[ob >> 1] << j) >> (s16x2){15, 15};
+          d[w] &= __builtin_bit_cast(uint32_t, keep);
+        }
+        dz[2 * ob + hh].v[0] = __builtin_bit_cast(bf16x8, d);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int j = (ob & 1) * 8 + hh * 4 + (t >> 1);
+          const bool on = (act[ob >> 1] >> (((t & 1) ? 31 : 15) - j)) & 1u;
+          set_slot<P>(dz[2 * ob + hh], t, on ? acc[ob][8 * hh + t] : 0.f);
+        }
       }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -392,12 +516,40 @@ __device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P>
     for (int t = 0; t < 8; ++t) set_slot<P>(df[c], t, v[8 * c + t]);
 }
 
+// LDS carve-up shared by kernel and launcher
+template <int NET, int P, int NW, bool TRAIN>
+struct FwdLds {
+  static constexpr int MODE = !TRAIN ? (P == 1 ? PIPE_RING : PIPE_CLASSIC) : (P == 1 ? PIPE_ROLES : PIPE_CLASSIC);
+  static constexpr bool ROLES = MODE == PIPE_ROLES;
+  static constexpr bool BIAS_LDS = MODE != PIPE_CLASSIC;
+  static constexpr int PC = ROLES ? 4 : 8;                                   // staging pass width (chunks)
+  static constexpr int W = (MODE == PIPE_RING ? 4 : 2) * BLK_FRAGS * P * FRAG_BYTES;
+  static constexpr int REGION = W;
+  static constexpr int STAGE = REGION + (ROLES ? REGION_BYTES : 0);
+  static constexpr int STASH = STAGE + (TRAIN ? NW * stage_bytes<PC>() : 0);
+  static constexpr int BIAS = STASH + NW * kpe(NET) * P * 1024;
+  static constexpr int TOTAL = BIAS + (BIAS_LDS ? FWD_BIAS_FLOATS * 4 : 0);
+};
+template <int P, int NW>
+struct BwdLds {
+  static constexpr int MODE = P == 1 ? PIPE_ROLES : PIPE_CLASSIC;
+  static constexpr bool ROLES = MODE == PIPE_ROLES;
+  static constexpr int PC = ROLES ? 4 : 8;
+  static constexpr int W = 2 * BLK_FRAGS * P * FRAG_BYTES;
+  static constexpr int REGION = W;
+  static constexpr int STAGE = REGION + (ROLES ? REGION_BYTES : 0);
+  static constexpr int MASKS = STAGE + NW * stage_bytes<PC>();              // 2 x NW KiB of sign words (ROLES)
+  static constexpr int TOTAL = MASKS + (ROLES ? 2 * NW * 1024 : 0);
+};
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int NET, int P, int NW, bool TRAIN>
 __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpFwdArgs a) {
-  constexpr int KPE = kpe(NET);
+  using LD = FwdLds<NET, P, NW, TRAIN>;
+  constexpr int KPE = kpe(NET), PC = LD::PC;
+  constexpr bool ROLES = LD::ROLES;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
   const size_t row_raw = (size_t)blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
@@ -405,59 +557,82 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   const size_t row = valid ? row_raw : (size_t)a.rows - 1;
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;          // this wave's first tile row
-  constexpr bool RINGMODE = !TRAIN && P == 1;                               // inference, bf16: counted-vmcnt ring
-  constexpr int WBYTES = (RINGMODE ? 4 : 2) * BLK_FRAGS * P * FRAG_BYTES;   // weight buffers
-  char* stage = smem + WBYTES + wave * STAGE_BYTES;
+  const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
+  const bool tail = wrow0 + 32 > (size_t)a.rows;                            // wave-uniform
+  char* region = smem + LD::REGION;
+  char* stage = loader ? region : smem + LD::STAGE + wave * stage_bytes<PC>();   // the loader never stages
+  char* pe_stash = smem + LD::STASH + wave * (KPE * P * 1024);
   const size_t nblk32 = a.rows_padded / 32;
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
-  const uint32_t bias_lds = WBYTES + (TRAIN ? NW * STAGE_BYTES : 0) + NW * KPE * P * 1024;   // RINGMODE only
-  if constexpr (RINGMODE) {
+  WeightPipe<P, NW, LD::MODE> pipe;
+  pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
+  if constexpr (LD::BIAS_LDS) {
     for (int i = threadIdx.x; i < FWD_BIAS_FLOATS / 4; i += NW * 64)
-      *(float4*)(smem + bias_lds + i * 16) = ((const float4*)a.bias)[i];
+      *(float4*)(smem + LD::BIAS + i * 16) = ((const float4*)a.bias)[i];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   auto bias_init8 = [&](f32x16 (&acc_)[8], int off) {
-    if constexpr (!RINGMODE) init_bias<8>(acc_, a.bias + off, hi); else init_bias_lds<8>(acc_, bias_lds + off * 4, hi);
+    if constexpr (!LD::BIAS_LDS) init_bias<8>(acc_, a.bias + off, hi); else init_bias_lds<8>(acc_, LD::BIAS + off * 4, hi);
   };
   auto bias_init4 = [&](f32x16 (&acc_)[4], int off) {
-    if constexpr (!RINGMODE) init_bias<4>(acc_, a.bias + off, hi); else init_bias_lds<4>(acc_, bias_lds + off * 4, hi);
+    if constexpr (!LD::BIAS_LDS) init_bias<4>(acc_, a.bias + off, hi); else init_bias_lds<4>(acc_, LD::BIAS + off * 4, hi);
   };
   auto bias_init1 = [&](f32x16 (&acc_)[1], int off) {
-    if constexpr (!RINGMODE) init_bias<1>(acc_, a.bias + off, hi); else init_bias_lds<1>(acc_, bias_lds + off * 4, hi);
+    if constexpr (!LD::BIAS_LDS) init_bias<1>(acc_, a.bias + off, hi); else init_bias_lds<1>(acc_, LD::BIAS + off * 4, hi);
   };
-
-  WeightPipe<P, NW, RINGMODE> pipe;
-  pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
+  // after the first barrier of a stage: wave 1 writes out what the loader handed over at the end of
+  // the previous stage (statically known per stage; mask_stage < 0: no sign words)
+  auto flush = [&](auto nch_c, __bf16* base, int ld, int mask_stage) __attribute__((always_inline)) {
+    if constexpr (ROLES) {
+      if (partner)
+        handoff_flush<decltype(nch_c)::value>(region, lane, base, ld, wrow0 - 32,
+                                              mask_stage >= 0 ? mask_out - 64 + (size_t)mask_stage * nblk32 * 64 : nullptr);
+    }
+  };
+  // save one tensor of this stage: storer waves write their own tile, the loader hands its tile over
+  auto save = [&](auto nch_c, __bf16* base, int ld, auto& frags, bool has_mask, uint4 bits, int mask_stage) __attribute__((always_inline)) {
+    constexpr int NCH = decltype(nch_c)::value;
+    if constexpr (!TRAIN) return;
+    if (tail) zero_invalid(frags, valid);       // wave-uniform, last tile only; those rows' values are never used
+    if constexpr (ROLES) {
+      if (loader) {
+        handoff_write<NCH>(region, lane, frags);
+        if (has_mask) *(uint4*)(region + REGION_MASK + lane * 16) = bits;
+      } else {
+        if (has_mask) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
+        save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
+      }
+    } else {
+      if (has_mask) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
+      save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
+    }
+  };
+  const uint4 nobits = make_uint4(0, 0, 0, 0);
 
   float x[4], vd[3], depth_real;
   sample_point<NET>(a.geom, row, a.S, x, vd, &depth_real);
   Frag<P> pe[KPE];
   encode_point<NET, P>(x, hi, pe);
-  if (TRAIN) save_frags<KPE, P>(stage, a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), wrow0, lane, valid, pe);
-  char* pe_stash = smem + WBYTES + (TRAIN ? NW * STAGE_BYTES : 0) + wave * (KPE * P * 1024);
+  save(std::integral_constant<int, KPE>{}, a.ws.t[T_X], kpew(NET), pe, false, nobits, 0);
   stash_frags<KPE, P>(pe_stash, lane, pe);
 
   f32x16 acc[8];
   Frag<P> h[16];
   // L0
   bias_init8(acc, fs_bias_off(FS_L0));
-  stage_gemm<8, KPE, P>(pipe, acc, pe);
-  const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-  if (TRAIN) {
-    mask_out[0] = bits;
-    save_frags<16, P>(stage, a.ws.t[T_H0], plane_rows * 256, 256, wrow0, lane, valid, h);
+  stage_gemm<8, KPE, P>(pipe, acc, pe, HOOK(flush(IC(KPE), a.ws.t[T_X], kpew(NET), -1)));
+  {
+    const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
+    save(std::integral_constant<int, 16>{}, a.ws.t[T_H0], 256, h, true, bits, 0);
   }
   // L1..L4
   for (int l = 1; l <= 4; ++l) {
     bias_init8(acc, fs_bias_off(FS_L0) + l * 256);
-    stage_gemm<8, 16, P>(pipe, acc, h);
+    stage_gemm<8, 16, P>(pipe, acc, h, HOOK(flush(IC(16), a.ws.t[T_H0 + l - 1], 256, l - 1)));
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-    if (TRAIN) {
-      mask_out[(size_t)l * nblk32 * 64] = bits;
-      save_frags<16, P>(stage, a.ws.t[T_H0 + l], plane_rows * 256, 256, wrow0, lane, valid, h);
-    }
+    save(std::integral_constant<int, 16>{}, TRAIN ? a.ws.t[T_H0 + l] : nullptr, 256, h, true, bits, l);
   }
   // L5: input = cat(encoded point, h4)                                 nerf_network.py:127-129
   {
@@ -471,32 +646,26 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 #pragma unroll
     for (int c = 0; c < 16; ++c) in5[KPE + c] = h[c];
     bias_init8(acc, fs_bias_off(FS_L5));
-    stage_gemm<8, KPE + 16, P>(pipe, acc, in5);
+    stage_gemm<8, KPE + 16, P>(pipe, acc, in5, HOOK(flush(IC(16), a.ws.t[T_H0 + 4], 256, 4)));
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-    if (TRAIN) {
-      mask_out[(size_t)5 * nblk32 * 64] = bits;
-      save_frags<16, P>(stage, a.ws.t[T_H0 + 5], plane_rows * 256, 256, wrow0, lane, valid, h);
-    }
+    save(std::integral_constant<int, 16>{}, a.ws.t[T_H0 + 5], 256, h, true, bits, 5);
   }
   // L6, L7
   for (int l = 6; l <= 7; ++l) {
     bias_init8(acc, fs_bias_off(FS_L0) + l * 256);
-    stage_gemm<8, 16, P>(pipe, acc, h);
+    stage_gemm<8, 16, P>(pipe, acc, h, HOOK(flush(IC(16), a.ws.t[T_H0 + l - 1], 256, l - 1)));
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-    if (TRAIN) {
-      mask_out[(size_t)l * nblk32 * 64] = bits;
-      save_frags<16, P>(stage, a.ws.t[T_H0 + l], plane_rows * 256, 256, wrow0, lane, valid, h);
-    }
+    save(std::integral_constant<int, 16>{}, TRAIN ? a.ws.t[T_H0 + l] : nullptr, 256, h, true, bits, l);
   }
   // remap (no activation) and sigma, both from h7                       nerf_network.py:131-136
+  // (R is not saved: the weight gradients that need it are derived from M = dG^T H7, nerfpp_optim.hip)
   Frag<P> rm[16];
   bias_init8(acc, fs_bias_off(FS_REMAP));
-  stage_gemm<8, 16, P>(pipe, acc, h);
+  stage_gemm<8, 16, P>(pipe, acc, h, HOOK(flush(IC(16), a.ws.t[T_H0 + 7], 256, 7)));
   acc_to_frags<8, P, ACT_NONE>(acc, rm);
-  // (R is not saved: the weight gradients that need it are derived from M = dG^T H7, nerfpp_optim.hip)
   f32x16 acc1[1];
   bias_init1(acc1, fs_bias_off(FS_SIG));
-  stage_gemm<1, 16, P>(pipe, acc1, h);
+  stage_gemm<1, 16, P>(pipe, acc1, h, NoHook{});
   const float sigma_raw = acc1[0][0];
   // colour head                                                         nerf_network.py:137-138
   Frag<P> g[8];
@@ -506,16 +675,13 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     for (int c = 0; c < 16; ++c) in[c] = rm[c];
     Frag<P> df[2];
     encode_dir<P>(vd, hi, df);
-    if (TRAIN) save_frags<2, P>(stage, a.ws.t[T_DIRX], plane_rows * 32, 32, wrow0, lane, valid, df);
+    save(std::integral_constant<int, 2>{}, a.ws.t[T_DIRX], 32, df, false, nobits, 0);
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
     bias_init4(acc4, fs_bias_off(FS_RGB0));
-    stage_gemm<4, 20, P>(pipe, acc4, in);
+    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(flush(IC(2), a.ws.t[T_DIRX], 32, -1)));
     const uint4 bits = acc_to_frags_relu_bits<4, P>(acc4, g);
-    if (TRAIN) {
-      mask_out[(size_t)8 * nblk32 * 64] = bits;
-      save_frags<8, P>(stage, a.ws.t[T_G], plane_rows * 128, 128, wrow0, lane, valid, g);
-    }
+    save(std::integral_constant<int, 8>{}, a.ws.t[T_G], 128, g, true, bits, 8);
   }
   {
     Frag<P> in[16];
@@ -524,7 +690,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 #pragma unroll
     for (int c = 8; c < 16; ++c) in[c] = zero_frag<P>();
     bias_init1(acc1, fs_bias_off(FS_RGB1));
-    stage_gemm<1, 16, P>(pipe, acc1, in);
+    stage_gemm<1, 16, P>(pipe, acc1, in, HOOK(flush(IC(8), a.ws.t[T_G], 128, 8)));
   }
   if (valid && hi == 0) {
     float4 o;
@@ -542,6 +708,9 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 // ------------------------------------------------------------------------------------------------
 template <int NET, int P, int NW>
 __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpBwdArgs a) {
+  using LD = BwdLds<P, NW>;
+  constexpr int PC = LD::PC;
+  constexpr bool ROLES = LD::ROLES;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
   const size_t row_raw = (size_t)blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
@@ -549,15 +718,69 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   const size_t row = valid ? row_raw : (size_t)a.rows - 1;
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;
-  char* stage = smem + 2 * BLK_FRAGS * P * FRAG_BYTES + wave * STAGE_BYTES;
+  const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
+  char* region = smem + LD::REGION;
+  char* stage = loader ? region : smem + LD::STAGE + wave * stage_bytes<PC>();
   const size_t nblk32 = a.rows_padded / 32;
   const uint4* mask_in = a.masks + (wrow0 / 32) * 64 + lane;
+  const uint32_t lds0 = lds_base_addr();
 
-  WeightPipe<P, NW, false> pipe;
+  // ReLU sign words: PIPE_ROLES has the loader DMA the whole tile's words (NW KiB per stage) into a
+  // 2-slot LDS buffer (slot = stage & 1) two uses ahead; the classic pipe loads them per lane.
+  auto issue_masks = [&](int mstage) __attribute__((always_inline)) {
+    if constexpr (ROLES) {
+      if (loader && mstage >= 0) {
+        const char* src = (const char*)(a.masks + ((size_t)mstage * nblk32 + (size_t)blockIdx.x * NW) * 64) + lane * 16;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) glds16_asm(src + w * 1024, lds0 + LD::MASKS + ((mstage & 1) * NW + w) * 1024);
+      }
+    }
+  };
+  auto get_mask = [&](int mstage) __attribute__((always_inline)) -> uint4 {
+    if constexpr (ROLES) return *(const uint4*)(smem + LD::MASKS + ((mstage & 1) * NW + wave) * 1024 + lane * 16);
+    else return mask_in[(size_t)mstage * nblk32 * 64];
+  };
+  auto flush = [&](auto nch_c, __bf16* base, int ld) __attribute__((always_inline)) {
+    if constexpr (ROLES) {
+      if (partner) handoff_flush<decltype(nch_c)::value>(region, lane, base, ld, wrow0 - 32, nullptr);
+    }
+  };
+  auto save = [&](auto nch_c, __bf16* base, int ld, const auto& frags) __attribute__((always_inline)) {
+    constexpr int NCH = decltype(nch_c)::value;
+    if constexpr (ROLES) {
+      if (loader) handoff_write<NCH>(region, lane, frags);
+      else save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
+    } else {
+      save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
+    }
+  };
+
+  WeightPipe<P, NW, LD::MODE> pipe;
   pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
+  issue_masks(8);
+  issue_masks(7);
 
   float4 d = ((const float4*)a.d_out)[row];
   if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);
+  // dP [rows,32] and dS [rows,32] come straight from d_out: every storer writes its own rows, and
+  // wave 1 also builds and writes the loader's rows (the loader never stores)
+  auto save_dp_ds = [&](const float4& dd, size_t r0) __attribute__((always_inline)) {   // dd == 0 on rows past the end
+    Frag<P> t[2];
+    t[0] = zero_frag<P>(); t[1] = zero_frag<P>();
+    if (hi == 0) { set_slot<P>(t[0], 0, dd.x); set_slot<P>(t[0], 1, dd.y); set_slot<P>(t[0], 2, dd.z); }
+    save_frags<2, P, PC>(stage, a.ws.t[T_DP], plane_rows * 32, 32, r0, lane, t);
+    t[0] = zero_frag<P>();
+    if (hi == 0) set_slot<P>(t[0], 0, dd.w);
+    save_frags<2, P, PC>(stage, a.ws.t[T_DS], plane_rows * 32, 32, r0, lane, t);
+  };
+  {
+    const size_t rr = row_raw - 32;                         // the loader's row of this lane (partner only)
+    const bool ok = partner && rr < (size_t)a.rows;
+    float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) d0 = ((const float4*)a.d_out)[rr];
+    if (!loader) save_dp_ds(d, wrow0);
+    if (partner) save_dp_ds(d0, wrow0 - 32);
+  }
 
   // B0: dG = Wrgb1^T dP, masked by G > 0
   Frag<P> dg[8];
@@ -566,23 +789,19 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
 #pragma unroll
     for (int c = 0; c < 4; ++c) in[c] = zero_frag<P>();
     if (hi == 0) { set_slot<P>(in[0], 0, d.x); set_slot<P>(in[0], 1, d.y); set_slot<P>(in[0], 2, d.z); }
-    {
-      Frag<P> dp[2] = {in[0], in[1]};
-      save_frags<2, P>(stage, a.ws.t[T_DP], plane_rows * 32, 32, wrow0, lane, valid, dp);
-    }
     f32x16 acc4[4];
     init_zero<4>(acc4);
-    stage_gemm<4, 4, P>(pipe, acc4, in);
-    mask_to_frags<4, P>(acc4, mask_in[(size_t)8 * nblk32 * 64], dg);
-    save_frags<8, P>(stage, a.ws.t[T_DG], plane_rows * 128, 128, wrow0, lane, valid, dg);
+    stage_gemm<4, 4, P>(pipe, acc4, in, NoHook{});
+    mask_to_frags<4, P>(acc4, get_mask(8), dg);
+    save(std::integral_constant<int, 8>{}, a.ws.t[T_DG], 128, dg);
   }
   f32x16 acc[8];
   Frag<P> dz[16];
-  // B1: dR = Wrgb0[:, :256]^T dG  (no activation on the remap layer)
+  // B1: dR = Wrgb0[:, :256]^T dG  (no activation on the remap layer; dR is not saved, see nerfpp_optim.hip)
   init_zero<8>(acc);
-  stage_gemm<8, 8, P>(pipe, acc, dg);
+  // (the barrier just passed ends every wave's use of sign words 8: their slot takes words 6)
+  stage_gemm<8, 8, P>(pipe, acc, dg, HOOK(flush(IC(8), a.ws.t[T_DG], 128); issue_masks(6)));
   acc_to_frags<8, P, ACT_NONE>(acc, dz);
-  // (dR is not saved either, same reason)
   // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
   {
     Frag<P> in[18];
@@ -590,21 +809,22 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     for (int c = 0; c < 16; ++c) in[c] = dz[c];
     in[16] = zero_frag<P>(); in[17] = zero_frag<P>();
     if (hi == 0) set_slot<P>(in[16], 0, d.w);
-    {
-      Frag<P> ds[2] = {in[16], in[17]};
-      save_frags<2, P>(stage, a.ws.t[T_DS], plane_rows * 32, 32, wrow0, lane, valid, ds);
-    }
     init_zero<8>(acc);
-    stage_gemm<8, 18, P>(pipe, acc, in);
-    mask_to_frags<8, P>(acc, mask_in[(size_t)7 * nblk32 * 64], dz);
-    save_frags<16, P>(stage, a.ws.t[T_DZ0 + 7], plane_rows * 256, 256, wrow0, lane, valid, dz);
+    stage_gemm<8, 18, P>(pipe, acc, in, NoHook{});
+    mask_to_frags<8, P>(acc, get_mask(7), dz);
+    save(std::integral_constant<int, 16>{}, a.ws.t[T_DZ0 + 7], 256, dz);
   }
   // B3..B9: dH_{l-1} = W_l^T dZ_l, l = 7..1
   for (int l = 7; l >= 1; --l) {
     init_zero<8>(acc);
-    stage_gemm<8, 16, P>(pipe, acc, dz);
-    mask_to_frags<8, P>(acc, mask_in[(size_t)(l - 1) * nblk32 * 64], dz);
-    save_frags<16, P>(stage, a.ws.t[T_DZ0 + l - 1], plane_rows * 256, 256, wrow0, lane, valid, dz);
+    stage_gemm<8, 16, P>(pipe, acc, dz, HOOK(flush(IC(16), a.ws.t[T_DZ0 + l], 256); issue_masks(l - 2)));
+    mask_to_frags<8, P>(acc, get_mask(l - 1), dz);
+    if (l > 1 || !ROLES) save(std::integral_constant<int, 16>{}, a.ws.t[T_DZ0 + l - 1], 256, dz);
+  }
+  if constexpr (ROLES) {
+    // dZ0 is the last tensor and no barrier follows: every wave (the loader too -- its DMA is done)
+    // writes its own tile; the loader stages through the hand-off region
+    save_frags<16, P, PC>(stage, a.ws.t[T_DZ0], plane_rows * 256, 256, wrow0, lane, dz);
   }
 }
 
@@ -622,9 +842,7 @@ static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  constexpr bool RINGMODE = !TRAIN && P == 1;
-  const size_t lds = (RINGMODE ? 4 : 2) * BLK_FRAGS * P * FRAG_BYTES + (TRAIN ? NW * STAGE_BYTES : 0) + NW * kpe(NET) * P * 1024 +
-                     (RINGMODE ? FWD_BIAS_FLOATS * 4 : 0);
+  const size_t lds = FwdLds<NET, P, NW, TRAIN>::TOTAL;
   hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 template <int NET, int P>
@@ -632,7 +850,7 @@ static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  const size_t lds = 2 * BLK_FRAGS * P * FRAG_BYTES + NW * STAGE_BYTES;
+  const size_t lds = BwdLds<P, NW>::TOTAL;
   hipLaunchKernelGGL((mlp_bwd_kernel<NET, P, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 
