@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnerfpp_hip.so')
+LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hip.so')   # override: diagnostic builds
 
 OK = 0
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2

@@ -62,24 +62,29 @@ __device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
 }
 __device__ __forceinline__ uint32_t lds_base_addr() { return (uint32_t)(uintptr_t)(LDS_AS char*)smem; }
 
-template <int P, int NW, int MODE>
+template <int P, int NW, int MODE, int NBUF>
 struct WeightPipe {
   static constexpr int BLK_BYTES = BLK_FRAGS * P * FRAG_BYTES;
-  static constexpr int NBUF = MODE == PIPE_RING ? 4 : 2;
-  static constexpr int PER_BLK = BLK_FRAGS * P / NW;          // DMA wave-instructions per wave per block
+  // DMA wave-instructions per block of the waves that wait for it (roles: the loader issues them all)
+  static constexpr int PER_BLK = MODE == PIPE_ROLES ? BLK_FRAGS * P : BLK_FRAGS * P / NW;
+  static_assert(MODE == PIPE_CLASSIC ? NBUF == 2 : (NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_BLK < 63), "ring depth");
   const char* g;
   int nblk, cur, wave, lane;
+  int slot_cur, slot_issue, next_issue;                        // ring positions (NBUF need not be a power of 2)
   uint32_t lds_base;
   __device__ __forceinline__ void init(const void* stream, int nblk_, int wave_, int lane_) {
     g = (const char*)stream; nblk = nblk_; cur = 0; wave = wave_; lane = lane_;
+    slot_cur = 0; slot_issue = 0; next_issue = 0;
     lds_base = lds_base_addr();
 #pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b) issue(b);
+    for (int b = 0; b < NBUF - 1; ++b) issue();
   }
-  __device__ __forceinline__ void issue(int blk) {
+  __device__ __forceinline__ void issue() {                    // next block of the stream -> next ring slot
+    const int blk = next_issue, slot = slot_issue;
+    ++next_issue;
+    slot_issue = slot_issue + 1 == NBUF ? 0 : slot_issue + 1;
     if (blk >= nblk) return;
     const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
-    const int slot = blk & (NBUF - 1);
     if constexpr (MODE == PIPE_ROLES) {
       if (wave != 0) return;                                   // the loader wave issues the whole block
 #pragma unroll
@@ -87,35 +92,39 @@ struct WeightPipe {
         glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
     } else {
 #pragma unroll
-      for (int f = 0; f < PER_BLK; ++f) {
+      for (int f = 0; f < BLK_FRAGS * P / NW; ++f) {
         const int fi = f * NW + wave;
         if constexpr (MODE == PIPE_RING) glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
         else glds16(src + fi * FRAG_BYTES, smem + slot * BLK_BYTES + fi * FRAG_BYTES);
       }
     }
   }
-  // make block `cur` readable, start fetching the next free slot, return LDS address of block cur
+  // wait until block `cur` has landed, leaving up to NBUF-2 younger blocks in flight.  Valid because
+  // every VMEM op the waiting wave has outstanding is a load (they retire in order); extra loads in
+  // between (sign words, rays) only make the count conservative.
+  __device__ __forceinline__ void wait_counted() {
+    const int younger = nblk - 1 - cur < NBUF - 2 ? nblk - 1 - cur : NBUF - 2;
+    if (NBUF >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_BLK) : "memory");
+    else if (NBUF >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_BLK) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // make block `cur` readable, start fetching into the slot freed by the barrier, return LDS address
   __device__ __forceinline__ const char* acquire() {
     if constexpr (MODE == PIPE_RING) {
-      const int younger = nblk - 1 - cur < NBUF - 2 ? nblk - 1 - cur : NBUF - 2;
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_BLK) : "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_BLK) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_counted();
       __builtin_amdgcn_s_barrier();
-      issue(cur + NBUF - 1);
     } else if constexpr (MODE == PIPE_ROLES) {
-      // loader: every VMEM op it has in flight is a load (weights, bias, masks) -> a full drain is
-      // cheap and exact.  Everybody: LDS writes of the hand-off region must have landed.
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // only the loader has DMA to wait for; everybody: LDS writes of the hand-off region must have landed
+      if (wave == 0) wait_counted();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      issue(cur + 1);
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      issue(cur + 1);
     }
-    const char* l = smem + (cur & (NBUF - 1)) * BLK_BYTES + lane * 16;
+    issue();
+    const char* l = smem + slot_cur * BLK_BYTES + lane * 16;
+    slot_cur = slot_cur + 1 == NBUF ? 0 : slot_cur + 1;
     ++cur;
     return l;
   }
@@ -132,13 +141,19 @@ __device__ __forceinline__ void mfma_p(f32x16& acc, const char* lfrag, const Fra
   }
 }
 
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-#define HOOK(...) [&]() __attribute__((always_inline)) { __VA_ARGS__; }
+#ifndef NERFPP_LDS_PREFETCH
+#define NERFPP_LDS_PREFETCH 4
+#endif
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+#define HOOK(...) [&](int blk) __attribute__((always_inline)) { __VA_ARGS__; }
 #define IC(n) std::integral_constant<int, (n)>{}
 
 // acc[ob] += W_stage[ob-block, :] * B   for one stage of NKC k-chunks x NOB out-blocks.
-// `hook()` runs once, right after the first block's barrier (PIPE_ROLES: wave 1 flushes the loader's
-// tile of the previous stage there; the loader queues the next ReLU-sign DMA).
+// `hook(blk)` runs in every block, after the block's barrier (before or after the block's MFMAs).  The bf16
+// training kernels use it to write out the PREVIOUS stage's output (= this stage's B operand, still in
+// registers) one quarter-tile per block pair, so the LDS transpose and the global stores sit in the
+// shadow of this stage's MFMAs instead of in an epilogue where every wave of the CU idles the matrix
+// pipe at once; wave 1 flushes the loader's tile there and the loader queues the next sign-word DMA.
 template <int NOB, int NKC, int P, typename Pipe, typename Hook>
 __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC], const Hook& hook) {
   constexpr int KPB = BLK_FRAGS / NOB;            // k-chunks per block
@@ -146,12 +161,29 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
 #pragma unroll
   for (int blk = 0; blk < NKC / KPB; ++blk) {
     const char* l = pipe.acquire();
-    if (blk == 0) hook();
+    // the two waves of a SIMD (w, w+4) run the hook at opposite ends of the block, so one of them
+    // always has MFMAs to issue while the other waits on LDS / issues stores
+    if (pipe.wave >= 4) hook(blk);
 #pragma unroll
     for (int kl = 0; kl < KPB; ++kl) {
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob)
         mfma_p<P>(acc[ob], l + (kl * NOB + ob) * P * FRAG_BYTES, b[blk * KPB + kl]);
+    }
+    if (pipe.wave < 4) hook(blk);
+    if constexpr (P == 1 && NERFPP_LDS_PREFETCH > 0) {
+      // shape the block's schedule: NERFPP_LDS_PREFETCH weight fragments in flight ahead of the MFMA
+      // that consumes them (LDS latency is ~2-4 MFMA slots; the default schedule keeps only 1-2 ahead)
+      constexpr int D = NERFPP_LDS_PREFETCH, N = NOB * KPB;
+#pragma unroll
+      for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+      for (int i = 0; i < N - D; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
   }
 }
@@ -297,7 +329,13 @@ __device__ __forceinline__ void lds_wave_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
+// NERFPP_DBG (diagnostic builds only, see tools/probes/README): bit 0 drops the activation stores,
+// bit 1 drops the LDS transposes too
+#ifndef NERFPP_DBG
+#define NERFPP_DBG 0
+#endif
 __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
+  if constexpr ((NERFPP_DBG & 1) != 0) return;
   const u32x4 vv = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(vv, (u32x4*)gptr);
 }
@@ -317,6 +355,7 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
                                            int lane, const Frag<P> (&h)[NCH]) {
   constexpr int SR = stage_row<PC>();
   const int j = lane & 31, hi = lane >> 5;
+  if constexpr ((NERFPP_DBG & 2) != 0) return;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
 #pragma unroll
@@ -339,9 +378,13 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
         const int rpi = 64 / lpr, row = lane / lpr, piece = lane - row * lpr;
         char* gl = g + (size_t)row * ld * 2 + piece * 16;
         const char* sl = stage + row * SR + piece * 16;
+        uint4 v[PC];
 #pragma unroll
         for (int it = 0; it < PC; ++it)
-          if (it < nc) store_nt16(gl + (size_t)it * rpi * ld * 2, *(const uint4*)(sl + it * rpi * SR));
+          if (it < nc) v[it] = *(const uint4*)(sl + it * rpi * SR);
+#pragma unroll
+        for (int it = 0; it < PC; ++it)
+          if (it < nc) store_nt16(gl + (size_t)it * rpi * ld * 2, v[it]);
       } else {
 #pragma unroll
         for (int it = 0; it < PC; ++it) {
@@ -357,6 +400,34 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
   }
 }
 
+// The same save, cut in two halves per 4-chunk pass so a stage can spread it over its blocks (P = 1):
+// pass_write in block 2p, pass_store in block 2p+1 -- no LDS round trip is waited for in place.
+template <int NCH>
+__device__ __forceinline__ void pass_write(char* stage, int lane, const Frag<1> (&h)[NCH], int c0) {
+  constexpr int SR = stage_row<4>();
+  if constexpr ((NERFPP_DBG & 2) != 0) return;
+  char* w = stage + (lane & 31) * SR + 8 * (lane >> 5);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint4 bits = *(const uint4*)&h[c0 + c].v[0];
+    *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
+    *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
+  }
+}
+__device__ __forceinline__ void pass_store(const char* stage, __bf16* base, int ld, size_t wave_row0, int lane, int c0) {
+  constexpr int SR = stage_row<4>();
+  if constexpr ((NERFPP_DBG & 2) != 0) return;
+  lds_wave_sync();
+  const int row = lane >> 3, piece = lane & 7;                // 8 x 16 B per 128-B row segment, 8 rows per store
+  char* gl = (char*)(base + wave_row0 * ld + c0 * 16) + (size_t)row * ld * 2 + piece * 16;
+  const char* sl = stage + row * SR + piece * 16;
+  uint4 v[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) v[it] = *(const uint4*)(sl + it * 8 * SR);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) store_nt16(gl + (size_t)it * 8 * ld * 2, v[it]);
+}
+
 // ---- PIPE_ROLES hand-off: the loader's tile goes to an LDS region, wave 1 writes it out later --------
 constexpr int REGION_ROW = 528;                              // 512 B of data + 16 B pad
 constexpr int REGION_MASK = 32 * REGION_ROW;                 // 64 x 16 B of ReLU sign words after the tile
@@ -365,6 +436,7 @@ constexpr int REGION_BYTES = REGION_MASK + 1024 + 512;       // 18432
 template <int NCH>
 __device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<1> (&h)[NCH]) {
   const int j = lane & 31, hi = lane >> 5;
+  if constexpr ((NERFPP_DBG & 2) != 0) return;
   char* w = region + j * REGION_ROW + 8 * hi;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -396,6 +468,20 @@ __device__ __forceinline__ void handoff_flush(const char* region, int lane, __bf
     }
   }
   if (mask_dst) *mask_dst = *(const uint4*)(region + REGION_MASK + lane * 16);
+}
+// one of PARTS equal slices of the same flush (power-of-two row lengths only)
+template <int NCH, int PARTS>
+__device__ __forceinline__ void handoff_flush_part(const char* region, int lane, __bf16* base, int ld, size_t row0, int part) {
+  constexpr int LPR = 2 * NCH, RPI = 64 / LPR, ITS = NCH / PARTS;
+  static_assert((LPR & (LPR - 1)) == 0 && NCH % PARTS == 0, "power-of-two rows");
+  const int row = lane / LPR, piece = lane - row * LPR;
+  char* gl = (char*)(base + row0 * ld) + (size_t)row * ld * 2 + piece * 16;
+  const char* sl = region + row * REGION_ROW + piece * 16;
+  uint4 v[ITS];
+#pragma unroll
+  for (int k = 0; k < ITS; ++k) v[k] = *(const uint4*)(sl + (part * ITS + k) * RPI * REGION_ROW);
+#pragma unroll
+  for (int k = 0; k < ITS; ++k) store_nt16(gl + (size_t)(part * ITS + k) * RPI * ld * 2, v[k]);
 }
 
 // dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
@@ -523,7 +609,9 @@ struct FwdLds {
   static constexpr bool ROLES = MODE == PIPE_ROLES;
   static constexpr bool BIAS_LDS = MODE != PIPE_CLASSIC;
   static constexpr int PC = ROLES ? 4 : 8;                                   // staging pass width (chunks)
-  static constexpr int W = (MODE == PIPE_RING ? 4 : 2) * BLK_FRAGS * P * FRAG_BYTES;
+  // ring depth: as deep as the 160 KiB of LDS allow (the background net's wider encoding costs a slot)
+  static constexpr int NBUF = MODE == PIPE_CLASSIC ? 2 : MODE == PIPE_RING ? 4 : (NET == 0 ? 4 : 3);
+  static constexpr int W = NBUF * BLK_FRAGS * P * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STAGE = REGION + (ROLES ? REGION_BYTES : 0);
   static constexpr int STASH = STAGE + (TRAIN ? NW * stage_bytes<PC>() : 0);
@@ -535,7 +623,8 @@ struct BwdLds {
   static constexpr int MODE = P == 1 ? PIPE_ROLES : PIPE_CLASSIC;
   static constexpr bool ROLES = MODE == PIPE_ROLES;
   static constexpr int PC = ROLES ? 4 : 8;
-  static constexpr int W = 2 * BLK_FRAGS * P * FRAG_BYTES;
+  static constexpr int NBUF = ROLES ? 4 : 2;
+  static constexpr int W = NBUF * BLK_FRAGS * P * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STAGE = REGION + (ROLES ? REGION_BYTES : 0);
   static constexpr int MASKS = STAGE + NW * stage_bytes<PC>();              // 2 x NW KiB of sign words (ROLES)
@@ -565,7 +654,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   const size_t nblk32 = a.rows_padded / 32;
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
-  WeightPipe<P, NW, LD::MODE> pipe;
+  WeightPipe<P, NW, LD::MODE, LD::NBUF> pipe;
   pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
   if constexpr (LD::BIAS_LDS) {
     for (int i = threadIdx.x; i < FWD_BIAS_FLOATS / 4; i += NW * 64)
@@ -584,11 +673,42 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   };
   // after the first barrier of a stage: wave 1 writes out what the loader handed over at the end of
   // the previous stage (statically known per stage; mask_stage < 0: no sign words)
-  auto flush = [&](auto nch_c, __bf16* base, int ld, int mask_stage) __attribute__((always_inline)) {
+  auto flush = [&](int blk, auto nch_c, __bf16* base, int ld, int mask_stage) __attribute__((always_inline)) {
     if constexpr (ROLES) {
-      if (partner)
+      if (partner && blk == 0)
         handoff_flush<decltype(nch_c)::value>(region, lane, base, ld, wrow0 - 32,
                                               mask_stage >= 0 ? mask_out - 64 + (size_t)mask_stage * nblk32 * 64 : nullptr);
+    }
+  };
+  // [rows,256] trunk activations.  finish_h: what stays in the producing stage's epilogue (sign words,
+  // tail zeroing; the whole save when the pipe has no roles).  psave_h: runs in every block of the
+  // CONSUMING stage (the tile is its B operand): storers transpose + write one quarter per block pair,
+  // the loader hands its tile over in block 0 and wave 1 writes that out in blocks 1..4.
+  auto finish_h = [&](__bf16* base, Frag<P> (&frags)[16], uint4 bits, int mask_stage) __attribute__((always_inline)) {
+    if constexpr (!TRAIN) return;
+    if (tail) zero_invalid(frags, valid);
+    if constexpr (ROLES) {
+      if (loader) *(uint4*)(region + REGION_MASK + lane * 16) = bits;
+      else mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
+    } else {
+      mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
+      save_frags<16, P, PC>(stage, base, plane_rows * 256, 256, wrow0, lane, frags);
+    }
+  };
+  auto psave_h = [&](int blk, const Frag<P> (&frags)[16], __bf16* base, int mask_stage) __attribute__((always_inline)) {
+    if constexpr (TRAIN && ROLES) {
+      if (loader) {
+        if (blk == 0) handoff_write<16>(region, lane, frags);
+      } else {
+        if (blk < 8) {
+          if (!(blk & 1)) pass_write<16>(stage, lane, frags, 4 * (blk >> 1));
+          else pass_store(stage, base, 256, wrow0, lane, 4 * (blk >> 1));
+        }
+        if (partner && blk >= 1 && blk <= 4) {
+          handoff_flush_part<16, 4>(region, lane, base, 256, wrow0 - 32, blk - 1);
+          if (blk == 1) mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + REGION_MASK + lane * 16);
+        }
+      }
     }
   };
   // save one tensor of this stage: storer waves write their own tile, the loader hands its tile over
@@ -622,17 +742,17 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   Frag<P> h[16];
   // L0
   bias_init8(acc, fs_bias_off(FS_L0));
-  stage_gemm<8, KPE, P>(pipe, acc, pe, HOOK(flush(IC(KPE), a.ws.t[T_X], kpew(NET), -1)));
+  stage_gemm<8, KPE, P>(pipe, acc, pe, HOOK(flush(blk, IC(KPE), a.ws.t[T_X], kpew(NET), -1)));
   {
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-    save(std::integral_constant<int, 16>{}, a.ws.t[T_H0], 256, h, true, bits, 0);
+    finish_h(a.ws.t[T_H0], h, bits, 0);
   }
   // L1..L4
   for (int l = 1; l <= 4; ++l) {
     bias_init8(acc, fs_bias_off(FS_L0) + l * 256);
-    stage_gemm<8, 16, P>(pipe, acc, h, HOOK(flush(IC(16), a.ws.t[T_H0 + l - 1], 256, l - 1)));
+    stage_gemm<8, 16, P>(pipe, acc, h, HOOK(psave_h(blk, h, a.ws.t[T_H0 + l - 1], l - 1)));
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-    save(std::integral_constant<int, 16>{}, TRAIN ? a.ws.t[T_H0 + l] : nullptr, 256, h, true, bits, l);
+    finish_h(TRAIN ? a.ws.t[T_H0 + l] : nullptr, h, bits, l);
   }
   // L5: input = cat(encoded point, h4)                                 nerf_network.py:127-129
   {
@@ -646,22 +766,22 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 #pragma unroll
     for (int c = 0; c < 16; ++c) in5[KPE + c] = h[c];
     bias_init8(acc, fs_bias_off(FS_L5));
-    stage_gemm<8, KPE + 16, P>(pipe, acc, in5, HOOK(flush(IC(16), a.ws.t[T_H0 + 4], 256, 4)));
+    stage_gemm<8, KPE + 16, P>(pipe, acc, in5, HOOK(psave_h(blk, h, a.ws.t[T_H0 + 4], 4)));
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-    save(std::integral_constant<int, 16>{}, a.ws.t[T_H0 + 5], 256, h, true, bits, 5);
+    finish_h(a.ws.t[T_H0 + 5], h, bits, 5);
   }
   // L6, L7
   for (int l = 6; l <= 7; ++l) {
     bias_init8(acc, fs_bias_off(FS_L0) + l * 256);
-    stage_gemm<8, 16, P>(pipe, acc, h, HOOK(flush(IC(16), a.ws.t[T_H0 + l - 1], 256, l - 1)));
+    stage_gemm<8, 16, P>(pipe, acc, h, HOOK(psave_h(blk, h, a.ws.t[T_H0 + l - 1], l - 1)));
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
-    save(std::integral_constant<int, 16>{}, TRAIN ? a.ws.t[T_H0 + l] : nullptr, 256, h, true, bits, l);
+    finish_h(TRAIN ? a.ws.t[T_H0 + l] : nullptr, h, bits, l);
   }
   // remap (no activation) and sigma, both from h7                       nerf_network.py:131-136
   // (R is not saved: the weight gradients that need it are derived from M = dG^T H7, nerfpp_optim.hip)
   Frag<P> rm[16];
   bias_init8(acc, fs_bias_off(FS_REMAP));
-  stage_gemm<8, 16, P>(pipe, acc, h, HOOK(flush(IC(16), a.ws.t[T_H0 + 7], 256, 7)));
+  stage_gemm<8, 16, P>(pipe, acc, h, HOOK(psave_h(blk, h, a.ws.t[T_H0 + 7], 7)));
   acc_to_frags<8, P, ACT_NONE>(acc, rm);
   f32x16 acc1[1];
   bias_init1(acc1, fs_bias_off(FS_SIG));
@@ -679,7 +799,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
     bias_init4(acc4, fs_bias_off(FS_RGB0));
-    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(flush(IC(2), a.ws.t[T_DIRX], 32, -1)));
+    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(flush(blk, IC(2), a.ws.t[T_DIRX], 32, -1)));
     const uint4 bits = acc_to_frags_relu_bits<4, P>(acc4, g);
     save(std::integral_constant<int, 8>{}, a.ws.t[T_G], 128, g, true, bits, 8);
   }
@@ -690,7 +810,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 #pragma unroll
     for (int c = 8; c < 16; ++c) in[c] = zero_frag<P>();
     bias_init1(acc1, fs_bias_off(FS_RGB1));
-    stage_gemm<1, 16, P>(pipe, acc1, in, HOOK(flush(IC(8), a.ws.t[T_G], 128, 8)));
+    stage_gemm<1, 16, P>(pipe, acc1, in, HOOK(flush(blk, IC(8), a.ws.t[T_G], 128, 8)));
   }
   if (valid && hi == 0) {
     float4 o;
@@ -740,25 +860,34 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     if constexpr (ROLES) return *(const uint4*)(smem + LD::MASKS + ((mstage & 1) * NW + wave) * 1024 + lane * 16);
     else return mask_in[(size_t)mstage * nblk32 * 64];
   };
-  auto flush = [&](auto nch_c, __bf16* base, int ld) __attribute__((always_inline)) {
+  // dZ tensors are written out while the NEXT stage consumes them (see stage_gemm): storers transpose +
+  // store one 4-chunk pass per block pair; the loader hands its tile over in block 0 and wave 1 writes it
+  // out in the following blocks.  Without roles (split-bf16) the tile is saved in the epilogue instead.
+  auto psave = [&](int blk, auto nch_c, const auto& frags, __bf16* base, int ld) __attribute__((always_inline)) {
+    constexpr int NCH = decltype(nch_c)::value, NPASS = NCH / 4, PARTS = NCH / 4;
     if constexpr (ROLES) {
-      if (partner) handoff_flush<decltype(nch_c)::value>(region, lane, base, ld, wrow0 - 32, nullptr);
+      if (loader) {
+        if (blk == 0) handoff_write<NCH>(region, lane, frags);
+      } else {
+        if (blk < 2 * NPASS) {
+          if (!(blk & 1)) pass_write<NCH>(stage, lane, frags, 4 * (blk >> 1));
+          else pass_store(stage, base, ld, wrow0, lane, 4 * (blk >> 1));
+        }
+        if (partner && blk >= 1 && blk <= PARTS) handoff_flush_part<NCH, PARTS>(region, lane, base, ld, wrow0 - 32, blk - 1);
+      }
     }
   };
   auto save = [&](auto nch_c, __bf16* base, int ld, const auto& frags) __attribute__((always_inline)) {
     constexpr int NCH = decltype(nch_c)::value;
-    if constexpr (ROLES) {
-      if (loader) handoff_write<NCH>(region, lane, frags);
-      else save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
-    } else {
-      save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
-    }
+    if constexpr (!ROLES) save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
   };
 
-  WeightPipe<P, NW, LD::MODE> pipe;
-  pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
+  // sign words 8 and 7 first: they are needed after the first barriers, and the loader's counted waits
+  // only guarantee what is OLDER than the weight blocks they count
   issue_masks(8);
   issue_masks(7);
+  WeightPipe<P, NW, LD::MODE, LD::NBUF> pipe;
+  pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
 
   float4 d = ((const float4*)a.d_out)[row];
   if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -800,7 +929,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   // B1: dR = Wrgb0[:, :256]^T dG  (no activation on the remap layer; dR is not saved, see nerfpp_optim.hip)
   init_zero<8>(acc);
   // (the barrier just passed ends every wave's use of sign words 8: their slot takes words 6)
-  stage_gemm<8, 8, P>(pipe, acc, dg, HOOK(flush(IC(8), a.ws.t[T_DG], 128); issue_masks(6)));
+  stage_gemm<8, 8, P>(pipe, acc, dg, HOOK(psave(blk, IC(8), dg, a.ws.t[T_DG], 128); if (blk == 0) issue_masks(6)));
   acc_to_frags<8, P, ACT_NONE>(acc, dz);
   // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
   {
@@ -817,9 +946,9 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   // B3..B9: dH_{l-1} = W_l^T dZ_l, l = 7..1
   for (int l = 7; l >= 1; --l) {
     init_zero<8>(acc);
-    stage_gemm<8, 16, P>(pipe, acc, dz, HOOK(flush(IC(16), a.ws.t[T_DZ0 + l], 256); issue_masks(l - 2)));
+    stage_gemm<8, 16, P>(pipe, acc, dz, HOOK(psave(blk, IC(16), dz, a.ws.t[T_DZ0 + l], 256); if (blk == 0) issue_masks(l - 2)));
     mask_to_frags<8, P>(acc, get_mask(l - 1), dz);
-    if (l > 1 || !ROLES) save(std::integral_constant<int, 16>{}, a.ws.t[T_DZ0 + l - 1], 256, dz);
+    save(std::integral_constant<int, 16>{}, a.ws.t[T_DZ0 + l - 1], 256, dz);
   }
   if constexpr (ROLES) {
     // dZ0 is the last tensor and no barrier follows: every wave (the loader too -- its DMA is done)
@@ -842,7 +971,8 @@ static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  const size_t lds = FwdLds<NET, P, NW, TRAIN>::TOTAL;
+  constexpr size_t lds = FwdLds<NET, P, NW, TRAIN>::TOTAL;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 template <int NET, int P>
@@ -850,7 +980,8 @@ static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  const size_t lds = BwdLds<P, NW>::TOTAL;
+  constexpr size_t lds = BwdLds<P, NW>::TOTAL;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((mlp_bwd_kernel<NET, P, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 
