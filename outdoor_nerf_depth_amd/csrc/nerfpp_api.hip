@@ -187,12 +187,15 @@ int nerfpp_pack_level(void* stream, int precision, const float* params, const in
   const PackLayout L = pack_layout(precision);
   hipStream_t st = (hipStream_t)stream;
   char* out = (char*)packed;
+  const int32_t* tbl[3 * N_NET];
+  void* outs[3 * N_NET];
+  int64_t n[3 * N_NET];
   for (int net = 0; net < N_NET; ++net) {
-    const float* p = params + (net == 0 ? 0 : FG_PARAMS);
-    launch_pack(st, p, tables + T.fwd[net], (int64_t)fwd_frags(net) * 512, precision, out + L.fwd[net]);
-    launch_pack(st, p, tables + T.bwd[net], (int64_t)BWD_FRAGS * 512, precision, out + L.bwd[net]);
-    launch_gather_f32(st, p, tables + T.bias[net], FWD_BIAS_FLOATS, (float*)(out + L.bias[net]));
+    tbl[3 * net] = tables + T.fwd[net];      outs[3 * net] = out + L.fwd[net];      n[3 * net] = (int64_t)fwd_frags(net) * 512;
+    tbl[3 * net + 1] = tables + T.bwd[net];  outs[3 * net + 1] = out + L.bwd[net];  n[3 * net + 1] = (int64_t)BWD_FRAGS * 512;
+    tbl[3 * net + 2] = tables + T.bias[net]; outs[3 * net + 2] = out + L.bias[net]; n[3 * net + 2] = FWD_BIAS_FLOATS;
   }
+  launch_pack_level(st, params, precision, tbl, outs, n);
   return check_launch("pack_level");
 }
 
@@ -291,12 +294,18 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
   launch_dw(st, P, dw);
   if (a->ev_dw_end) (void)hipEventRecord((hipEvent_t)a->ev_dw_end, st);
-  for (int net = 0; net < N_NET; ++net)
-    launch_unpack_grads(st, dw.slabs[net], L.ksplit, gslab_floats(net), a->tables + T.unpack[net],
-                        net_params(net), a->grad_scale, a->grads + (net == 0 ? 0 : FG_PARAMS));
-  for (int net = 0; net < N_NET; ++net)
-    launch_remap_fixup(st, net, a->grads + (net == 0 ? 0 : FG_PARAMS), a->params + (net == 0 ? 0 : FG_PARAMS),
-                       (float*)(ws + L.fix_m[net]));
+  const float* slabs[N_NET];
+  int64_t slab_floats[N_NET];
+  const int32_t* utbl[N_NET];
+  float* m_out[N_NET];
+  for (int net = 0; net < N_NET; ++net) {
+    slabs[net] = dw.slabs[net];
+    slab_floats[net] = gslab_floats(net);
+    utbl[net] = a->tables + T.unpack[net];
+    m_out[net] = (float*)(ws + L.fix_m[net]);
+  }
+  launch_unpack_grads(st, slabs, slab_floats, L.ksplit, utbl, m_out, a->grad_scale, a->grads);
+  launch_remap_fixup(st, a->grads, a->params, m_out[0], m_out[1]);
   return check_launch("level_backward");
 }
 

@@ -76,10 +76,10 @@ int mlp_tile_rows(int P);
 void launch_dw(hipStream_t st, int P, const nerfpp::DwArgs& a);
 int dw_jobs_total();
 // nerfpp_optim.hip
-void launch_pack(hipStream_t st, const float* params, const int32_t* tbl, int64_t n_elems, int P, void* out);
-void launch_gather_f32(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, float* out);
-void launch_unpack_grads(hipStream_t st, const float* slabs, int ksplit, int64_t slab_floats,
-                         const int32_t* tbl, int64_t n_params, float scale, float* grads);
-void launch_remap_fixup(hipStream_t st, int net, float* grads, const float* params, float* tmp_m);
+void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t* const* tbl, void* const* out,
+                       const int64_t* n);
+void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats, int ksplit,
+                         const int32_t* const* tbl, float* const* m_out, float scale, float* grads_lvl);
+void launch_remap_fixup(hipStream_t st, float* grads_lvl, const float* params_lvl, const float* m0, const float* m1);
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                  double beta1, double beta2, double eps);

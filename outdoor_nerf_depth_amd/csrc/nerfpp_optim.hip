@@ -9,36 +9,65 @@
 
 namespace nerfpp {
 
+// One launch packs a whole level: both nets' forward and backward fragment streams (bf16 hi[/lo]
+// planes) and the forward bias vectors (f32), each a gather through its index table.
+struct PackSegs {
+  static constexpr int N = 3 * N_NET;
+  int blk_end[N];                 // exclusive prefix of 256-thread blocks per segment
+  const int32_t* tbl[N];
+  void* out[N];
+  int64_t n[N];
+  int pbase[N];                   // offset of the net's parameters in the level's flat buffer
+  int is_f32[N];
+};
 template <int P>
-__global__ void pack_kernel(const float* __restrict__ params, const int32_t* __restrict__ tbl, int64_t n,
-                            __bf16* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const int32_t src = tbl[e];
-  const float v = src >= 0 ? params[src] : 0.f;
+__global__ void pack_level_kernel(const float* __restrict__ params, PackSegs sg) {
+  int seg = 0;
+#pragma unroll
+  for (int k = 0; k < PackSegs::N - 1; ++k) seg += (int)blockIdx.x >= sg.blk_end[k];
+  const int blk0 = seg == 0 ? 0 : sg.blk_end[seg - 1];
+  const int64_t e = (int64_t)((int)blockIdx.x - blk0) * blockDim.x + threadIdx.x;
+  if (e >= sg.n[seg]) return;
+  const int32_t src = sg.tbl[seg][e];
+  const float v = src >= 0 ? params[sg.pbase[seg] + src] : 0.f;
+  if (sg.is_f32[seg]) {
+    ((float*)sg.out[seg])[e] = v;
+    return;
+  }
+  __bf16* out = (__bf16*)sg.out[seg];
   const int64_t F = e >> 9, within = e & 511;
   const __bf16 h = (__bf16)v;
   out[(F * P) * 512 + within] = h;
   if (P == 2) out[(F * P + 1) * 512 + within] = (__bf16)(v - (float)h);
 }
 
-__global__ void gather_f32_kernel(const float* __restrict__ params, const int32_t* __restrict__ tbl, int64_t n,
-                                  float* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const int32_t src = tbl[e];
-  out[e] = src >= 0 ? params[src] : 0.f;
-}
-
-__global__ void unpack_grads_kernel(const float* __restrict__ slabs, int ksplit, int64_t slab_floats,
-                                    const int32_t* __restrict__ tbl, int64_t n, float scale,
-                                    float* __restrict__ grads) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t src = tbl[i];
+// Both nets in one launch: deterministic sum over the split-K slabs, internal -> reference order,
+// DDP pre-scale.  The first 256 columns of rgb_layers.0.weight.grad hold M = dG^T H7 at this point
+// (see remap_fixup_kernel); they are also copied to m_out[net] so the fix-up can overwrite them.
+struct UnpackArgs {
+  const float* slabs[N_NET];
+  int64_t slab_floats[N_NET];
+  const int32_t* tbl[N_NET];
+  float* m_out[N_NET];
+};
+__global__ void unpack_grads_kernel(UnpackArgs a, int ksplit, float scale, float* __restrict__ grads) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= LEVEL_PARAMS) return;
+  const int net = gi >= FG_PARAMS;
+  const int i = (int)(gi - (net ? FG_PARAMS : 0));
+  const int32_t src = a.tbl[net][i];
+  const float* sl = a.slabs[net];
+  const int64_t sf = a.slab_floats[net];
   float acc = 0.f;
-  for (int s = 0; s < ksplit; ++s) acc += slabs[(size_t)s * slab_floats + src];
-  grads[i] = acc * scale;
+  for (int s = 0; s < ksplit; ++s) acc += sl[(size_t)s * sf + src];
+  acc *= scale;
+  grads[gi] = acc;
+  const int w_g = ref_w_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);
+  const int r = i - w_g;
+  if (r >= 0 && r < 128 * ldg) {
+    const int o = r / ldg, c = r - o * ldg;
+    if (c < 256) a.m_out[net][o * 256 + c] = acc;
+  }
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -63,17 +92,20 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 //   d base_remap_layers.0.bias     = Wg[:, :256]^T * db_g
 // which removes both 256-wide saves (R, dR) and one 256x256 GEMM over all samples.  float32, fixed
 // summation order.
-__global__ void remap_copy_m_kernel(const float* __restrict__ grads, int w_g, int ldg, float* __restrict__ m) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 128 * 256) m[i] = grads[w_g + (i >> 8) * ldg + (i & 255)];
-}
 // One wave per output row-segment so that every global read is coalesced:
 //   part A (128 x 256 outputs): out[o][j] = sum_i M[o][i] * Wr[j][i] + db_g[o] * b_r[j]
 //           wave = (o, 4 consecutive j): lanes stride over i, 4 dot products, wave reduction
 //   part B (256 x 256): dWr[j][i] = sum_o Wg[o][j] * M[o][i]      thread = (j, i), lanes over i
 //   part C (256):       db_r[j]   = sum_o Wg[o][j] * db_g[o]
-__global__ void remap_fixup_kernel(float* __restrict__ grads, const float* __restrict__ params,
-                                   const float* __restrict__ m, int w_g, int b_g, int ldg, int w_r, int b_r) {
+// blockIdx.y = net; grads / params are the level's flat buffers; m0 / m1 = the nets' M copies.
+__global__ void remap_fixup_kernel(float* __restrict__ grads_lvl, const float* __restrict__ params_lvl,
+                                   const float* __restrict__ m0, const float* __restrict__ m1) {
+  const int net = blockIdx.y;
+  float* grads = grads_lvl + (net ? FG_PARAMS : 0);
+  const float* params = params_lvl + (net ? FG_PARAMS : 0);
+  const float* m = net ? m1 : m0;
+  const int w_g = ref_w_off(net, RT_RGB0), b_g = ref_b_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);
+  const int w_r = ref_w_off(net, RT_REMAP), b_r = ref_b_off(net, RT_REMAP);
   constexpr int A_WAVES = 128 * 64;                       // (o, j-quad)
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (gw < A_WAVES) {
@@ -111,27 +143,35 @@ __global__ void remap_fixup_kernel(float* __restrict__ grads, const float* __res
 
 using namespace nerfpp;
 
-void launch_remap_fixup(hipStream_t st, int net, float* grads, const float* params, float* tmp_m) {
-  const int w_g = ref_w_off(net, RT_RGB0), b_g = ref_b_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);
-  const int w_r = ref_w_off(net, RT_REMAP), b_r = ref_b_off(net, RT_REMAP);
-  hipLaunchKernelGGL(remap_copy_m_kernel, dim3(128), dim3(256), 0, st, grads, w_g, ldg, tmp_m);
+void launch_remap_fixup(hipStream_t st, float* grads_lvl, const float* params_lvl, const float* m0, const float* m1) {
   const int total = 128 * 64 * 64 + 256 * 256 + 256;          // part A waves * 64 + part B + part C threads
-  hipLaunchKernelGGL(remap_fixup_kernel, dim3((total + 255) / 256), dim3(256), 0, st, grads, params, tmp_m, w_g, b_g,
-                     ldg, w_r, b_r);
+  hipLaunchKernelGGL(remap_fixup_kernel, dim3((total + 255) / 256, N_NET), dim3(256), 0, st, grads_lvl, params_lvl, m0, m1);
 }
 
-void launch_pack(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, int P, void* out) {
-  dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (P == 1) hipLaunchKernelGGL(pack_kernel<1>, grid, block, 0, st, params, tbl, n, (__bf16*)out);
-  else hipLaunchKernelGGL(pack_kernel<2>, grid, block, 0, st, params, tbl, n, (__bf16*)out);
+// segs: per net {fwd stream, bwd stream, bias}; tables / outs / sizes in that order
+void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t* const* tbl, void* const* out,
+                       const int64_t* n) {
+  PackSegs sg{};
+  int blk = 0;
+  for (int k = 0; k < PackSegs::N; ++k) {
+    blk += (int)((n[k] + 255) / 256);
+    sg.blk_end[k] = blk;
+    sg.tbl[k] = tbl[k];
+    sg.out[k] = out[k];
+    sg.n[k] = n[k];
+    sg.pbase[k] = (k / 3) == 0 ? 0 : FG_PARAMS;
+    sg.is_f32[k] = (k % 3) == 2;
+  }
+  if (P == 1) hipLaunchKernelGGL(pack_level_kernel<1>, dim3(blk), dim3(256), 0, st, params, sg);
+  else hipLaunchKernelGGL(pack_level_kernel<2>, dim3(blk), dim3(256), 0, st, params, sg);
 }
-void launch_gather_f32(hipStream_t st, const float* params, const int32_t* tbl, int64_t n, float* out) {
-  hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, tbl, n, out);
-}
-void launch_unpack_grads(hipStream_t st, const float* slabs, int ksplit, int64_t slab_floats, const int32_t* tbl,
-                         int64_t n_params, float scale, float* grads) {
-  hipLaunchKernelGGL(unpack_grads_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, st, slabs,
-                     ksplit, slab_floats, tbl, n_params, scale, grads);
+void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats, int ksplit,
+                         const int32_t* const* tbl, float* const* m_out, float scale, float* grads_lvl) {
+  UnpackArgs a{};
+  for (int net = 0; net < N_NET; ++net) {
+    a.slabs[net] = slabs[net]; a.slab_floats[net] = slab_floats[net]; a.tbl[net] = tbl[net]; a.m_out[net] = m_out[net];
+  }
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3((LEVEL_PARAMS + 255) / 256), dim3(256), 0, st, a, ksplit, scale, grads_lvl);
 }
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                  double beta1, double beta2, double eps) {
