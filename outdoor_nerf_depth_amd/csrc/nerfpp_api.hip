@@ -67,11 +67,12 @@ struct WsLayout {
   int64_t rows, rows_padded;
   int ksplit;
 };
-int choose_ksplit(int64_t rows) {
-  int64_t k = rows / 512;
-  if (k < 1) k = 1;
-  if (k > 16) k = 16;
-  return (int)k;
+int choose_ksplit(int64_t rows) {              // slabs to allocate: the most any job of the plan uses
+  const DwPlan pl = dw_plan(rows);
+  int k = 1;
+  for (int net = 0; net < N_NET; ++net)
+    for (int j = 0; j < DW_JOBS; ++j) k = pl.k[net][j] > k ? pl.k[net][j] : k;
+  return k;
 }
 WsLayout ws_layout(int n_rays, int S, int P, bool training) {
   WsLayout L{};
@@ -290,7 +291,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   }
   dw.rows = L.rows;
   dw.rows_padded = L.rows_padded;
-  dw.ksplit = L.ksplit;
+  dw.plan = dw_plan(L.rows);
   if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
   launch_dw(st, P, dw);
   if (a->ev_dw_end) (void)hipEventRecord((hipEvent_t)a->ev_dw_end, st);
@@ -304,7 +305,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
     utbl[net] = a->tables + T.unpack[net];
     m_out[net] = (float*)(ws + L.fix_m[net]);
   }
-  launch_unpack_grads(st, slabs, slab_floats, L.ksplit, utbl, m_out, a->grad_scale, a->grads);
+  launch_unpack_grads(st, slabs, slab_floats, dw.plan, utbl, m_out, a->grad_scale, a->grads);
   launch_remap_fixup(st, a->grads, a->params, m_out[0], m_out[1]);
   return check_launch("level_backward");
 }

@@ -188,6 +188,94 @@ struct DwJob {       // one 128x128 (or smaller) output tile of one weight-gradi
   int16_t gw_ld;                  // row stride of this stage's GW block
   int16_t gb_off;                 // offset of bias o0 in the slab's bias part, or -1
 };
-constexpr int MAX_DW_JOBS = 64;
+constexpr int DW_JOBS = 13;                  // per net (build_all_jobs order)
+constexpr int DW_KMAX = 32;                  // slabs allocated per net; a job uses the first k_job of them
+
+struct JobTable {
+  DwJob jobs[N_NET][DW_JOBS];
+  int count[N_NET];
+};
+constexpr void add_job(JobTable& jt, int net, int s, int b_tensor, int icol, bool bias) {
+  DwJob j{};
+  j.a_tensor = (int16_t)gw_dz_tensor(s);
+  j.b_tensor = (int16_t)b_tensor;
+  j.o0 = 0;
+  j.i0 = 0;
+  j.n_o = (int16_t)gw_O(s);
+  j.n_i = (int16_t)tensor_ld(net, b_tensor);
+  j.gw_off = gw_off(net, s) + icol;
+  j.gw_ld = (int16_t)gw_I(net, s);
+  j.gb_off = (int16_t)(bias ? gb_off(s) : -1);
+  jt.jobs[net][jt.count[net]++] = j;
+}
+// job index per net: 0 L0 | 1-4 L1-L4 | 5 L5 (encoded-point columns) | 6 L5 (h4 columns) | 7,8 L6,L7 |
+// 9 sigma | 10 rgb0 (M = dG^T H7, see remap_fixup_kernel) | 11 rgb0 (view-direction columns) | 12 rgb1
+constexpr JobTable build_all_jobs() {
+  JobTable jt{};
+  for (int net = 0; net < N_NET; ++net) {
+    jt.count[net] = 0;
+    for (int s = 0; s < FS_COUNT; ++s) {
+      if (s == FS_L0) add_job(jt, net, s, T_X, 0, true);
+      else if (s == FS_L5) {
+        add_job(jt, net, s, T_X, 0, true);
+        add_job(jt, net, s, T_H0 + 4, kpew(net), false);
+      } else if (s < 8) add_job(jt, net, s, T_H0 + s - 1, 0, true);
+      else if (s == FS_REMAP) continue;            // dW_remap = Wrgb0r^T * M, derived in remap_fixup_kernel
+      else if (s == FS_SIG) add_job(jt, net, s, T_H0 + 7, 0, true);
+      else if (s == FS_RGB0) {
+        add_job(jt, net, s, T_H0 + 7, 0, true);    // M = dG^T * H7 (NOT dG^T * R), fixed up after the slab sum
+        add_job(jt, net, s, T_DIRX, 256, false);
+      } else add_job(jt, net, s, T_G, 0, true);
+    }
+  }
+  return jt;
+}
+constexpr bool dw_job_is_full(const DwJob& j) { return j.n_o == 256 && j.n_i == 256; }
+// which job wrote element `src` of a gradient slab (-1: nobody -- the remap stage, derived later)
+__host__ __device__ constexpr int slab_job_index(int net, int src) {
+  int s = 0;
+  bool is_bias = false;
+  int col = 0;
+  if (src >= gw_floats(net)) {
+    is_bias = true;
+    const int b = src - gw_floats(net);
+    while (s + 1 < FS_COUNT && gb_off(s + 1) <= b) ++s;
+  } else {
+    while (s + 1 < FS_COUNT && gw_off(net, s + 1) <= src) ++s;
+    col = (src - gw_off(net, s)) % gw_I(net, s);
+  }
+  if (s < 5) return s;
+  if (s == FS_L5) return (is_bias || col < kpew(net)) ? 5 : 6;
+  if (s < 8) return s + 1;
+  if (s == FS_REMAP) return -1;
+  if (s == FS_SIG) return 9;
+  if (s == FS_RGB0) return (is_bias || col < 256) ? 10 : 11;
+  return 12;
+}
+
+// How many row slices (= workgroups = slabs) each job gets.  The full 256x256 jobs all stream the
+// same bytes per row; the narrow ones get slices in proportion to theirs, so that every workgroup
+// of a launch moves about the same number of bytes and each launch fills the 256 CUs once.
+struct DwPlan { int k[N_NET][DW_JOBS]; };
+inline DwPlan dw_plan(int64_t rows) {
+  const JobTable jt = build_all_jobs();
+  int64_t cap = rows / 512;
+  cap = cap < 1 ? 1 : (cap > DW_KMAX ? DW_KMAX : cap);
+  int n_full = 0, w_narrow = 0;
+  for (int net = 0; net < N_NET; ++net)
+    for (int j = 0; j < jt.count[net]; ++j) {
+      if (dw_job_is_full(jt.jobs[net][j])) ++n_full;
+      else w_narrow += jt.jobs[net][j].n_o + jt.jobs[net][j].n_i;
+    }
+  DwPlan pl{};
+  for (int net = 0; net < N_NET; ++net)
+    for (int j = 0; j < jt.count[net]; ++j) {
+      const DwJob& job = jt.jobs[net][j];
+      int64_t k = dw_job_is_full(job) ? 256 / n_full : ((int64_t)256 * (job.n_o + job.n_i) + w_narrow / 2) / w_narrow;
+      k = k < 1 ? 1 : (k > cap ? cap : k);
+      pl.k[net][j] = (int)k;
+    }
+  return pl;
+}
 
 }  // namespace nerfpp

@@ -33,46 +33,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct JobTable {
-  DwJob jobs[N_NET][MAX_DW_JOBS];
-  int count[N_NET];
-};
-
-constexpr void add_job(JobTable& jt, int net, int s, int b_tensor, int icol, bool bias) {
-  DwJob j{};
-  j.a_tensor = (int16_t)gw_dz_tensor(s);
-  j.b_tensor = (int16_t)b_tensor;
-  j.o0 = 0;
-  j.i0 = 0;
-  j.n_o = (int16_t)gw_O(s);
-  j.n_i = (int16_t)tensor_ld(net, b_tensor);
-  j.gw_off = gw_off(net, s) + icol;
-  j.gw_ld = (int16_t)gw_I(net, s);
-  j.gb_off = (int16_t)(bias ? gb_off(s) : -1);
-  jt.jobs[net][jt.count[net]++] = j;
-}
-
-constexpr JobTable build_all_jobs() {
-  JobTable jt{};
-  for (int net = 0; net < N_NET; ++net) {
-    jt.count[net] = 0;
-    for (int s = 0; s < FS_COUNT; ++s) {
-      if (s == FS_L0) add_job(jt, net, s, T_X, 0, true);
-      else if (s == FS_L5) {
-        add_job(jt, net, s, T_X, 0, true);
-        add_job(jt, net, s, T_H0 + 4, kpew(net), false);
-      } else if (s < 8) add_job(jt, net, s, T_H0 + s - 1, 0, true);
-      else if (s == FS_REMAP) continue;            // dW_remap = Wrgb0r^T * M, derived in remap_fixup_kernel
-      else if (s == FS_SIG) add_job(jt, net, s, T_H0 + 7, 0, true);
-      else if (s == FS_RGB0) {
-        add_job(jt, net, s, T_H0 + 7, 0, true);    // M = dG^T * H7 (NOT dG^T * R), fixed up after the slab sum
-        add_job(jt, net, s, T_DIRX, 256, false);
-      } else add_job(jt, net, s, T_G, 0, true);
-    }
-  }
-  return jt;
-}
-
 // FULL jobs (256 x 256, every wave has all 8 of its blocks) get an unguarded kernel instantiation
 constexpr JobTable build_jobs(bool full) {
   const JobTable all = build_all_jobs();
@@ -80,8 +40,7 @@ constexpr JobTable build_jobs(bool full) {
   for (int net = 0; net < N_NET; ++net) {
     jt.count[net] = 0;
     for (int k = 0; k < all.count[net]; ++k) {
-      const bool is_full = all.jobs[net][k].n_o == 256 && all.jobs[net][k].n_i == 256;
-      if (is_full == full) jt.jobs[net][jt.count[net]++] = all.jobs[net][k];
+      if (dw_job_is_full(all.jobs[net][k]) == full) jt.jobs[net][jt.count[net]++] = all.jobs[net][k];
     }
   }
   return jt;
@@ -190,11 +149,20 @@ __device__ __forceinline__ void compute_chunk_rr(lds_addr buf, int wave, int n_i
   }
 }
 
+// workgroup -> (job of this launch, row slice): jobs in table order (net 0 then net 1), k slices each
+struct DwSched {
+  int wg_end[2 * DW_JOBS];       // exclusive prefix of workgroups per job
+  int k[2 * DW_JOBS];
+  int njobs, njobs0;
+};
 template <int P, bool FULL>
-__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, int njobs0, int dbg) {
+__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
-  const int job_id = blockIdx.x / a.ksplit, split = blockIdx.x - job_id * a.ksplit;
+  int job_id = 0;
+  for (int j = 0; j < sc.njobs - 1; ++j) job_id += (int)blockIdx.x >= sc.wg_end[j];
+  const int split = blockIdx.x - (job_id == 0 ? 0 : sc.wg_end[job_id - 1]), ksplit = sc.k[job_id];
+  const int njobs0 = sc.njobs0;
   const int net = job_id < njobs0 ? 0 : 1;
   const DwJob job = (FULL ? c_full : c_narrow).jobs[net][net == 0 ? job_id : job_id - njobs0];
   const int rb_a = tensor_ld(net, job.a_tensor) * 2, rb_b = tensor_ld(net, job.b_tensor) * 2;   // row bytes
@@ -203,7 +171,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, int njobs0, int dbg) 
   const size_t plane_a = (size_t)a.rows_padded * rb_a, plane_b = (size_t)a.rows_padded * rb_b;
 
   const int64_t rows32 = (a.rows + 31) / 32 * 32;
-  int64_t rps = (rows32 + a.ksplit - 1) / a.ksplit;
+  int64_t rps = (rows32 + ksplit - 1) / ksplit;
   rps = (rps + 31) / 32 * 32;
   const int64_t r_begin = split * rps;
   const int64_t r_end = r_begin + rps < rows32 ? r_begin + rps : rows32;
@@ -321,16 +289,38 @@ using namespace nerfpp;
 
 int dw_jobs_total() { return H_FULL.count[0] + H_FULL.count[1] + H_NARROW.count[0] + H_NARROW.count[1]; }
 
+namespace {
+// slices per job of one launch, in that launch's table order; the plan is indexed in build_all_jobs order
+DwSched make_sched(const DwPlan& plan, bool full) {
+  const JobTable all = build_all_jobs();
+  DwSched sc{};
+  int n = 0, wg = 0;
+  for (int net = 0; net < N_NET; ++net) {
+    if (net == 1) sc.njobs0 = n;
+    for (int j = 0; j < all.count[net]; ++j) {
+      if (dw_job_is_full(all.jobs[net][j]) != full) continue;
+      sc.k[n] = plan.k[net][j];
+      wg += plan.k[net][j];
+      sc.wg_end[n] = wg;
+      ++n;
+    }
+  }
+  sc.njobs = n;
+  return sc;
+}
+}  // namespace
+
 void launch_dw(hipStream_t st, int P, const DwArgs& a) {
-  dim3 gfull((H_FULL.count[0] + H_FULL.count[1]) * a.ksplit), gnarrow((H_NARROW.count[0] + H_NARROW.count[1]) * a.ksplit);
+  const DwSched sf = make_sched(a.plan, true), sn = make_sched(a.plan, false);
+  dim3 gfull(sf.wg_end[sf.njobs - 1]), gnarrow(sn.wg_end[sn.njobs - 1]);
   dim3 block(512);
   const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;
   static const int dbg = getenv("NERFPP_DW_DEBUG") ? atoi(getenv("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
   if (P == 1) {
-    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, H_FULL.count[0], dbg);
-    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, H_NARROW.count[0], dbg);
+    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg);
+    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg);
   } else {
-    hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, H_FULL.count[0], dbg);
-    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, lds, st, a, H_NARROW.count[0], dbg);
+    hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, sf, dbg);
+    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, lds, st, a, sn, dbg);
   }
 }

@@ -39,8 +39,8 @@ struct MlpBwdArgs {
 struct DwArgs {
   NetWs ws[N_NET];
   int64_t rows, rows_padded;
-  int ksplit;
-  float* slabs[N_NET];           // [ksplit][gslab_floats(net)]
+  float* slabs[N_NET];           // [DW_KMAX][gslab_floats(net)]; job j fills the first plan.k[net][j] slabs
+  DwPlan plan;
 };
 
 }  // namespace nerfpp
@@ -78,8 +78,9 @@ int dw_jobs_total();
 // nerfpp_optim.hip
 void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t* const* tbl, void* const* out,
                        const int64_t* n);
-void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats, int ksplit,
-                         const int32_t* const* tbl, float* const* m_out, float scale, float* grads_lvl);
+void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats,
+                         const nerfpp::DwPlan& plan, const int32_t* const* tbl, float* const* m_out, float scale,
+                         float* grads_lvl);
 void launch_remap_fixup(hipStream_t st, float* grads_lvl, const float* params_lvl, const float* m0, const float* m1);
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                  double beta1, double beta2, double eps);

@@ -49,8 +49,9 @@ struct UnpackArgs {
   int64_t slab_floats[N_NET];
   const int32_t* tbl[N_NET];
   float* m_out[N_NET];
+  DwPlan plan;                    // slabs filled per job
 };
-__global__ void unpack_grads_kernel(UnpackArgs a, int ksplit, float scale, float* __restrict__ grads) {
+__global__ void unpack_grads_kernel(UnpackArgs a, float scale, float* __restrict__ grads) {
   const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= LEVEL_PARAMS) return;
   const int net = gi >= FG_PARAMS;
@@ -58,6 +59,8 @@ __global__ void unpack_grads_kernel(UnpackArgs a, int ksplit, float scale, float
   const int32_t src = a.tbl[net][i];
   const float* sl = a.slabs[net];
   const int64_t sf = a.slab_floats[net];
+  const int job = slab_job_index(net, src);
+  const int ksplit = job >= 0 ? a.plan.k[net][job] : 0;        // remap stage: filled in by remap_fixup_kernel
   float acc = 0.f;
   for (int s = 0; s < ksplit; ++s) acc += sl[(size_t)s * sf + src];
   acc *= scale;
@@ -165,13 +168,14 @@ void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t
   if (P == 1) hipLaunchKernelGGL(pack_level_kernel<1>, dim3(blk), dim3(256), 0, st, params, sg);
   else hipLaunchKernelGGL(pack_level_kernel<2>, dim3(blk), dim3(256), 0, st, params, sg);
 }
-void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats, int ksplit,
+void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats, const DwPlan& plan,
                          const int32_t* const* tbl, float* const* m_out, float scale, float* grads_lvl) {
   UnpackArgs a{};
+  a.plan = plan;
   for (int net = 0; net < N_NET; ++net) {
     a.slabs[net] = slabs[net]; a.slab_floats[net] = slab_floats[net]; a.tbl[net] = tbl[net]; a.m_out[net] = m_out[net];
   }
-  hipLaunchKernelGGL(unpack_grads_kernel, dim3((LEVEL_PARAMS + 255) / 256), dim3(256), 0, st, a, ksplit, scale, grads_lvl);
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3((LEVEL_PARAMS + 255) / 256), dim3(256), 0, st, a, scale, grads_lvl);
 }
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                  double beta1, double beta2, double eps) {
