@@ -85,6 +85,13 @@ int nerfpp_sample_fine(void* stream, int n_rays, int s_old, int n_new, const flo
                        const float* weights, const float* u, float* z_merged, float* samples,
                        int64_t* above_inds);
 
+/* the same for the foreground and the background volume of a level in one launch (the two calls at
+ * ddp_train_nerf.py:450-457 and :458-465); u may be NULL for both (det=True). */
+int nerfpp_sample_fine_pair(void* stream, int n_rays, int s_old, int n_new, const float* fg_z_old,
+                            const float* fg_weights, const float* fg_u, float* fg_z_merged,
+                            const float* bg_z_old, const float* bg_weights, const float* bg_u,
+                            float* bg_z_merged);
+
 /* ray batch from a GPU-resident frame (nerf_sample_ray_split.py:10-34 get_rays_single_image and
  * :178-221 random_sample): for every flat pixel index pix[i] (int64, row-major H x W)
  *   ray_d = c2w[:3,:3] * K^-1 * [u+.5, v+.5, 1]^T (un-normalised), ray_o = c2w[:3,3],

@@ -48,6 +48,7 @@ SYMBOLS = {
     'nerfpp_perturb_samples': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'nerfpp_sample_pdf': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     'nerfpp_sample_fine': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'nerfpp_sample_fine_pair': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'nerfpp_gather_rays': (C.c_int, [_fp, C.c_int, C.c_int] + [_fp] * 9),
     'nerfpp_table_sizes': (C.c_int, [C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p]),
     'nerfpp_build_tables': (C.c_int, [C.c_int, _i32p, _i32p, _i32p, _i32p]),

@@ -155,6 +155,19 @@ int nerfpp_sample_fine(void* stream, int n_rays, int s_old, int n_new, const flo
   return check_launch("sample_fine");
 }
 
+int nerfpp_sample_fine_pair(void* stream, int n_rays, int s_old, int n_new, const float* fg_z_old,
+                            const float* fg_weights, const float* fg_u, float* fg_z_merged, const float* bg_z_old,
+                            const float* bg_weights, const float* bg_u, float* bg_z_merged) {
+  REQUIRE(n_rays > 0 && s_old >= 3 && n_new >= 1 && s_old + n_new <= 512, "3 <= s_old, s_old + n_new <= 512");
+  REQUIRE(fg_z_old && fg_weights && fg_z_merged && bg_z_old && bg_weights && bg_z_merged, "non-null pointers");
+  const float* z[2] = {fg_z_old, bg_z_old};
+  const float* w[2] = {fg_weights, bg_weights};
+  const float* u[2] = {fg_u, bg_u};
+  float* m[2] = {fg_z_merged, bg_z_merged};
+  launch_sample_fine_pair((hipStream_t)stream, n_rays, s_old - 2, n_new, z, w, u, m);
+  return check_launch("sample_fine_pair");
+}
+
 int nerfpp_gather_rays(void* stream, int n_rays, int width, const float* cam, const int64_t* pix,
                        const float* rgb_img, const float* depth_img, float* ray_o, float* ray_d, float* rgb,
                        float* depth_sup, float* min_depth) {

@@ -232,17 +232,29 @@ constexpr JobTable build_all_jobs() {
 }
 constexpr bool dw_job_is_full(const DwJob& j) { return j.n_o == 256 && j.n_i == 256; }
 // which job wrote element `src` of a gradient slab (-1: nobody -- the remap stage, derived later)
-__host__ __device__ constexpr int slab_job_index(int net, int src) {
+struct SlabMap { int gw[N_NET][FS_COUNT + 1]; int gb[FS_COUNT + 1]; int gi[N_NET][FS_COUNT]; };
+constexpr SlabMap make_slab_map() {
+  SlabMap m{};
+  for (int s = 0; s <= FS_COUNT; ++s) {
+    m.gb[s] = gb_off(s);
+    for (int net = 0; net < N_NET; ++net) {
+      m.gw[net][s] = gw_off(net, s);
+      if (s < FS_COUNT) m.gi[net][s] = gw_I(net, s);
+    }
+  }
+  return m;
+}
+__host__ __device__ constexpr int slab_job_index(const SlabMap& m, int net, int src) {
   int s = 0;
   bool is_bias = false;
   int col = 0;
-  if (src >= gw_floats(net)) {
+  if (src >= m.gw[net][FS_COUNT]) {
     is_bias = true;
-    const int b = src - gw_floats(net);
-    while (s + 1 < FS_COUNT && gb_off(s + 1) <= b) ++s;
+    const int b = src - m.gw[net][FS_COUNT];
+    for (int t = 1; t < FS_COUNT; ++t) s += m.gb[t] <= b;
   } else {
-    while (s + 1 < FS_COUNT && gw_off(net, s + 1) <= src) ++s;
-    col = (src - gw_off(net, s)) % gw_I(net, s);
+    for (int t = 1; t < FS_COUNT; ++t) s += m.gw[net][t] <= src;
+    col = (src - m.gw[net][s]) % m.gi[net][s];
   }
   if (s < 5) return s;
   if (s == FS_L5) return (is_bias || col < kpew(net)) ? 5 : 6;

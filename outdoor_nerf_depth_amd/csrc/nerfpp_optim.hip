@@ -44,6 +44,7 @@ __global__ void pack_level_kernel(const float* __restrict__ params, PackSegs sg)
 // Both nets in one launch: deterministic sum over the split-K slabs, internal -> reference order,
 // DDP pre-scale.  The first 256 columns of rgb_layers.0.weight.grad hold M = dG^T H7 at this point
 // (see remap_fixup_kernel); they are also copied to m_out[net] so the fix-up can overwrite them.
+__constant__ SlabMap c_slab_map = make_slab_map();
 struct UnpackArgs {
   const float* slabs[N_NET];
   int64_t slab_floats[N_NET];
@@ -59,10 +60,16 @@ __global__ void unpack_grads_kernel(UnpackArgs a, float scale, float* __restrict
   const int32_t src = a.tbl[net][i];
   const float* sl = a.slabs[net];
   const int64_t sf = a.slab_floats[net];
-  const int job = slab_job_index(net, src);
+  const int job = slab_job_index(c_slab_map, net, src);
   const int ksplit = job >= 0 ? a.plan.k[net][job] : 0;        // remap stage: filled in by remap_fixup_kernel
-  float acc = 0.f;
-  for (int s = 0; s < ksplit; ++s) acc += sl[(size_t)s * sf + src];
+  float acc = 0.f;                                               // fixed summation order: deterministic
+  int s = 0;
+  for (; s + 4 <= ksplit; s += 4) {                              // 4 independent loads in flight
+    const float v0 = sl[(size_t)s * sf + src], v1 = sl[(size_t)(s + 1) * sf + src];
+    const float v2 = sl[(size_t)(s + 2) * sf + src], v3 = sl[(size_t)(s + 3) * sf + src];
+    acc += (v0 + v1) + (v2 + v3);
+  }
+  for (; s < ksplit; ++s) acc += sl[(size_t)s * sf + src];
   acc *= scale;
   grads[gi] = acc;
   const int w_g = ref_w_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);

@@ -100,11 +100,23 @@ __global__ void perturb_kernel(int n, int S, const float* __restrict__ z, const 
 // ------------------------------------------------------------------------------------------------
 constexpr int SP_MAX = 512;     // max S_old + S_new and max M+1
 
+// blockIdx.y selects one of up to two independent problems (the foreground and background volumes of
+// a cascade level are re-sampled in one launch: with one wave per ray a single volume of 1024 rays
+// occupies 4 waves per CU and is latency-bound, so the second one is free).
+struct SamplePdfProblem {
+  const float* bins_or_zold; const float* weights; const float* u;
+  float* samples; int64_t* above; float* merged;
+};
+struct SamplePdfArgs { SamplePdfProblem p[2]; };
 template <bool FUSED>
-__global__ __launch_bounds__(256) void sample_pdf_kernel(
-    int n, int M, int S_new, const float* __restrict__ bins_or_zold, const float* __restrict__ weights,
-    const float* __restrict__ u_in, float* __restrict__ samples_out, int64_t* __restrict__ above_out,
-    float* __restrict__ merged_out) {
+__global__ __launch_bounds__(256) void sample_pdf_kernel(int n, int M, int S_new, SamplePdfArgs args) {
+  const SamplePdfProblem& pr = args.p[blockIdx.y];
+  const float* __restrict__ bins_or_zold = pr.bins_or_zold;
+  const float* __restrict__ weights = pr.weights;
+  const float* __restrict__ u_in = pr.u;
+  float* __restrict__ samples_out = pr.samples;
+  int64_t* __restrict__ above_out = pr.above;
+  float* __restrict__ merged_out = pr.merged;
   __shared__ float s_cdf[4][SP_MAX];
   __shared__ float s_w[4][SP_MAX];
   __shared__ float s_bins[4][SP_MAX];
@@ -498,12 +510,17 @@ void launch_perturb(hipStream_t st, int n, int S, const float* z, const float* t
 void launch_sample_pdf(hipStream_t st, bool fused, int n, int M, int S_new, const float* bins_or_zold,
                        const float* weights, const float* u, float* samples, int64_t* above, float* merged) {
   dim3 grid((n + 3) / 4), block(256);
-  if (fused)
-    hipLaunchKernelGGL(sample_pdf_kernel<true>, grid, block, 0, st, n, M, S_new, bins_or_zold, weights, u,
-                       samples, above, merged);
-  else
-    hipLaunchKernelGGL(sample_pdf_kernel<false>, grid, block, 0, st, n, M, S_new, bins_or_zold, weights, u,
-                       samples, above, merged);
+  SamplePdfArgs a{};
+  a.p[0] = SamplePdfProblem{bins_or_zold, weights, u, samples, above, merged};
+  if (fused) hipLaunchKernelGGL(sample_pdf_kernel<true>, grid, block, 0, st, n, M, S_new, a);
+  else hipLaunchKernelGGL(sample_pdf_kernel<false>, grid, block, 0, st, n, M, S_new, a);
+}
+void launch_sample_fine_pair(hipStream_t st, int n, int M, int S_new, const float* const* z_old,
+                             const float* const* weights, const float* const* u, float* const* merged) {
+  dim3 grid((n + 3) / 4, 2), block(256);
+  SamplePdfArgs a{};
+  for (int k = 0; k < 2; ++k) a.p[k] = SamplePdfProblem{z_old[k], weights[k], u[k], nullptr, nullptr, merged[k]};
+  hipLaunchKernelGGL(sample_pdf_kernel<true>, grid, block, 0, st, n, M, S_new, a);
 }
 void launch_composite_fwd(hipStream_t st, int n, int S, const float* raw_fg, const float* raw_bg,
                           const float* depth_real_bg, const float* ray_d, const float* fg_far,

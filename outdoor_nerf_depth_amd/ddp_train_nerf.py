@@ -161,8 +161,7 @@ def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size):
         ret = None
         for m, eng in enumerate(trainer.engines):
             if m > 0:
-                fg_z = ops.sample_fine(fg_z, ret['fg_weights'], S1, det=True)
-                bg_z = ops.sample_fine(bg_z, ret['bg_weights'], S1, det=True)
+                fg_z, bg_z = ops.sample_fine_pair(fg_z, ret['fg_weights'], bg_z, ret['bg_weights'], S1, det=True)
             ret = eng.forward(o, d, far, fg_z, bg_z, training=False)
             for k in keys:
                 out[m][k].append(ret[k])

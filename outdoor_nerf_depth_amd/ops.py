@@ -126,6 +126,26 @@ def sample_fine(z_old, weights, N_samples, det=False, u=None, return_all=False):
     return (merged, samples, above) if return_all else merged
 
 
+def sample_fine_pair(fg_z, fg_weights, bg_z, bg_weights, N_samples, det=False, u_fg=None, u_bg=None):
+    """Both volumes of a level in one launch (same arithmetic as two sample_fine calls; the uniforms are
+    drawn fg first, then bg, like the reference's two sample_pdf calls)."""
+    fg_z, fg_weights, bg_z, bg_weights = _f32(fg_z), _f32(fg_weights), _f32(bg_z), _f32(bg_weights)
+    n, S_old = fg_z.shape
+    if fg_weights.shape != (n, S_old) or bg_z.shape != (n, S_old) or bg_weights.shape != (n, S_old):
+        raise L.NerfppError('z / weights must all be [n, S_old]')
+    if det:
+        u_fg = u_bg = None
+    else:
+        u_fg = _f32(u_fg, (n, N_samples)) if u_fg is not None else torch.rand(n, N_samples, device=fg_z.device)
+        u_bg = _f32(u_bg, (n, N_samples)) if u_bg is not None else torch.rand(n, N_samples, device=fg_z.device)
+    fg_m = torch.empty(n, S_old + N_samples, device=fg_z.device)
+    bg_m = torch.empty(n, S_old + N_samples, device=fg_z.device)
+    L.check(L.lib().nerfpp_sample_fine_pair(_stream(), n, S_old, N_samples, _p(fg_z), _p(fg_weights), _p(u_fg),
+                                            _p(fg_m), _p(bg_z), _p(bg_weights), _p(u_bg), _p(bg_m)),
+            'nerfpp_sample_fine_pair')
+    return fg_m, bg_m
+
+
 # ------------------------------------------------------------------------------------- one level
 _TABLES = {}
 

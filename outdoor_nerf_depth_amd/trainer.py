@@ -98,8 +98,8 @@ class NerfppTrainer(object):
             if m > 0:
                 u_fg = u['u_fg'] if 'u_fg' in u else torch.rand(n, S1, device=dev)
                 u_bg = u['u_bg'] if 'u_bg' in u else torch.rand(n, S1, device=dev)
-                fg_z = ops.sample_fine(fg_z, ret['fg_weights'], S1, u=u_fg)
-                bg_z = ops.sample_fine(bg_z, ret['bg_weights'], S1, u=u_bg)
+                fg_z, bg_z = ops.sample_fine_pair(fg_z, ret['fg_weights'], bg_z, ret['bg_weights'], S1,
+                                                  u_fg=u_fg, u_bg=u_bg)
             ev = events[m] if events is not None else None
             ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True,
                               events=ev['fwd'] if ev else None)

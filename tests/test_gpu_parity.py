@@ -113,6 +113,15 @@ def test_sample_fine_merge_sorted_and_matches_oracle(ops, golden):
     det = ops.sample_fine(T(g['fg_z0']), T(g['L0.fg_weights']), 128, det=True)
     m_o, _, _ = O.fine_depths(g['fg_z0'], g['L0.fg_weights'], np.broadcast_to(O.torch_linspace(0, 1, 128), (12, 128)))
     np.testing.assert_array_equal(N(det), m_o)
+    # both volumes in one launch == the two single calls, bit for bit (random and det)
+    fg_m, bg_m = ops.sample_fine_pair(T(g['fg_z0']), T(g['L0.fg_weights']), T(g['bg_z0']), T(g['L0.bg_weights']), 128,
+                                      u_fg=T(g['u_fg']), u_bg=T(g['u_bg']))
+    np.testing.assert_array_equal(N(fg_m), O.fine_depths(g['fg_z0'], g['L0.fg_weights'], g['u_fg'])[0])
+    np.testing.assert_array_equal(N(bg_m), O.fine_depths(g['bg_z0'], g['L0.bg_weights'], g['u_bg'])[0])
+    fg_d, bg_d = ops.sample_fine_pair(T(g['fg_z0']), T(g['L0.fg_weights']), T(g['bg_z0']), T(g['L0.bg_weights']), 128,
+                                      det=True)
+    np.testing.assert_array_equal(N(fg_d), N(det))
+    np.testing.assert_array_equal(N(bg_d), N(ops.sample_fine(T(g['bg_z0']), T(g['L0.bg_weights']), 128, det=True)))
 
 
 # ----------------------------------------------------------------------------------------- forward
