@@ -329,13 +329,14 @@ __device__ __forceinline__ void lds_wave_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
-// NERFPP_DBG (diagnostic builds only, see tools/probes/README): bit 0 drops the activation stores,
-// bit 1 drops the LDS transposes too
+// NERFPP_DBG (diagnostic builds only): bit 0 drops the activation stores, bit 1 the
+// LDS transposes too, bit 2 uses plain instead of non-temporal stores
 #ifndef NERFPP_DBG
 #define NERFPP_DBG 0
 #endif
 __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
   if constexpr ((NERFPP_DBG & 1) != 0) return;
+  if constexpr ((NERFPP_DBG & 4) != 0) { *(uint4*)gptr = v; return; }                                     // plain (temporal) store
   const u32x4 vv = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(vv, (u32x4*)gptr);
 }
