@@ -437,7 +437,7 @@ constexpr int REGION_BYTES = REGION_MASK + 1024 + 512;       // 18432
 template <int NCH>
 __device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<1> (&h)[NCH]) {
   const int j = lane & 31, hi = lane >> 5;
-  if constexpr ((NERFPP_DBG & 2) != 0) return;
+  if constexpr ((NERFPP_DBG & (2 | 16)) != 0) return;
   char* w = region + j * REGION_ROW + 8 * hi;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -453,6 +453,7 @@ __device__ __forceinline__ void handoff_flush(const char* region, int lane, __bf
                                               uint4* mask_dst) {
   constexpr int LPR = 2 * NCH;
   char* g = (char*)(base + row0 * ld);
+  if constexpr ((NERFPP_DBG & 16) != 0) return;
   if constexpr ((LPR & (LPR - 1)) == 0) {
     constexpr int RPI = 64 / LPR;
     const int row = lane / LPR, piece = lane - row * LPR;
@@ -475,6 +476,7 @@ template <int NCH, int PARTS>
 __device__ __forceinline__ void handoff_flush_part(const char* region, int lane, __bf16* base, int ld, size_t row0, int part) {
   constexpr int LPR = 2 * NCH, RPI = 64 / LPR, ITS = NCH / PARTS;
   static_assert((LPR & (LPR - 1)) == 0 && NCH % PARTS == 0, "power-of-two rows");
+  if constexpr ((NERFPP_DBG & 16) != 0) return;
   const int row = lane / LPR, piece = lane - row * LPR;
   char* gl = (char*)(base + row0 * ld) + (size_t)row * ld * 2 + piece * 16;
   const char* sl = region + row * REGION_ROW + piece * 16;
