@@ -32,6 +32,9 @@ PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s measured copy ceiling)
 # algorithmic bytes per sample row read by the weight-gradient GEMMs (every operand once per job):
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
 DW_BYTES_PER_ROW = (5216 + 5280) * 2
+# level-1 dW launch pair at N_rand=1024, bf16: FETCH_SIZE (x2 gfx950 wide-stream correction) + WRITE_SIZE
+DW_TRAFFIC_PMC_BYTES = (2 * 1.5 * (917.6e6 + 425.2e6)) + 1.5 * (64.7e6 + 18.4e6)
+DW_TRAFFIC_SOURCE = 'profiles/r01_e_kernel_stats_timeline_hbm.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
 
 
 def parse():
@@ -110,8 +113,12 @@ def run_mode(args, precision, rank, world, device, batches):
     share = {'mlp_fwd_fg_L1': fwd_ms * 2 * (1 + 64.0 / 192), 'mlp_bwd_fg_L1': bwd_ms * 2 * (1 + 64.0 / 192),
              'dw_both_L1': dw_ms * (1 + 64.0 / 192)}
     dominant = max(share, key=share.get)
+    # HBM bytes of the dominant launch from the PMC passes committed under profiles/ (cannot be collected
+    # inside this process): only quoted for the configuration they were measured on
+    traffic = DW_TRAFFIC_PMC_BYTES if (n == 1024 and precision == 1) else None
     return dict(elapsed=elapsed, ms_per_step=1e3 * elapsed / K, value=n * K * world / elapsed, loss=loss,
-                kernels=kernels, dominant=dominant, share_ms=share)
+                value_per_gpu=n * K / elapsed, kernels=kernels, dominant=dominant, share_ms=share,
+                dw_traffic_pmc=traffic)
 
 
 def roofline(r):
@@ -120,16 +127,19 @@ def roofline(r):
     operand streamed once) against HBM.  Durations are HIP-event times recorded by the library on the
     launch stream inside the timed region."""
     dom = r['kernels'][r['dominant']]
+    # whole-step figure of SURVEY 8(d): 1.797 GFLOP of dense-layer work per ray-step against the bf16 peak
+    whole = {'tflops': r['value_per_gpu'] * 1.797e9 / 1e12, 'frac_of_bf16_mfma_peak': r['value_per_gpu'] * 1.797e9 / 1e12 / PEAK_BF16_TFLOPS}
     allk = {k: {kk: round(vv, 4) for kk, vv in v.items() if kk in ('ms', 'tflops', 'gbs')}
             for k, v in r['kernels'].items()}
     if dom['bound'] == 'hbm':
         return {'bound': 'hbm', 'kernel': r['dominant'], 'achieved': dom['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                'frac': dom['gbs'] / PEAK_HBM_GBS, 'traffic': None, 'launch_ms': dom['ms'],
-                'mfma_tflops_of_same_kernel': dom['tflops'], 'all_kernels': allk,
+                'frac': dom['gbs'] / PEAK_HBM_GBS, 'traffic': r.get('dw_traffic_pmc'), 'launch_ms': dom['ms'],
+                'traffic_source': DW_TRAFFIC_SOURCE if r.get('dw_traffic_pmc') else None,
+                'mfma_tflops_of_same_kernel': dom['tflops'], 'whole_step': whole, 'all_kernels': allk,
                 'share_ms_per_step': {k: round(v, 4) for k, v in r['share_ms'].items()}}
     return {'bound': 'mfma', 'kernel': r['dominant'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
             'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None, 'launch_ms': dom['ms'],
-            'all_kernels': allk, 'share_ms_per_step': {k: round(v, 4) for k, v in r['share_ms'].items()}}
+            'whole_step': whole, 'all_kernels': allk, 'share_ms_per_step': {k: round(v, 4) for k, v in r['share_ms'].items()}}
 
 
 def cpu_baseline(args):

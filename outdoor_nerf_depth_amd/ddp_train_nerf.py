@@ -129,8 +129,6 @@ def validate_args(args):
         raise SystemExit('only netdepth=8 / netwidth=256 (the reference configs) are implemented in HIP')
     if args.max_freq_log2 != 10 or args.max_freq_log2_viewdirs != 4:
         raise SystemExit('only max_freq_log2=10 / max_freq_log2_viewdirs=4 are implemented in HIP')
-    if args.optim_autoexpo:
-        raise SystemExit('--optim_autoexpo is not implemented (unused by every KITTI/Argoverse config)')
     if args.use_depth and args.depth_loss_type in ('los', 'nll'):
         raise SystemExit("depth_loss_type '%s' is dead code in the reference (depth_loss.py:46-76)" %
                          args.depth_loss_type)
@@ -186,6 +184,16 @@ def save_checkpoint(path, trainer, global_step):
                                             state_dict_from_flat(eng.params).items())
         to_save['optim_%d' % m] = adam_state_dict(trainer.exp_avg[m].cpu(), trainer.exp_avg_sq[m].cpu(),
                                                   trainer.step_count, trainer.lrate)
+        if trainer.autoexpo is not None:          # autoexpo_params follow nerf_net in parameters() order
+            ae = trainer.autoexpo[m]
+            for k, v in ae.state_dict_entries():
+                to_save['net_%d' % m][k] = v.cpu()
+            opt = to_save['optim_%d' % m]
+            base = len(opt['param_groups'][0]['params'])
+            for i, st in enumerate(ae.adam_entries()):
+                opt['param_groups'][0]['params'].append(base + i)
+                if st is not None:
+                    opt['state'][base + i] = st
     torch.save(to_save, path)
 
 
@@ -198,6 +206,13 @@ def load_checkpoint(path, trainer):
         if 'optim_%d' % m in ck:
             trainer.step_count = load_adam_state_dict(trainer.exp_avg[m], trainer.exp_avg_sq[m], ck['optim_%d' % m])
         eng.repack()
+        if trainer.autoexpo is not None:
+            ae = trainer.autoexpo[m]
+            ae.load_state_dict_entries(ck['net_%d' % m])
+            if 'optim_%d' % m in ck:
+                from .model import level_param_specs
+                base = len(level_param_specs())
+                ae.load_adam_entries([ck['optim_%d' % m]['state'].get(base + i) for i in range(len(ae.names))])
 
 
 def find_latest_checkpoint(args):
@@ -274,6 +289,13 @@ def ddp_train_nerf(rank, args):
         val_ray_samplers = load_data_split(args.datadir, args.scene, split='test', skip=args.testskip,
                                            depth_sup_type=args.depth_sup_type)
     depth_scale = ray_samplers[0].get_depth_scale() or 1.0
+    img_names = None
+    if args.optim_autoexpo:                       # :394-399 (written before the nets need it, unlike upstream)
+        img_names = [rs.img_path or 'synthetic/train/rgb/%06d.png' % i for i, rs in enumerate(ray_samplers)]
+        if rank == 0:
+            import json
+            with open(os.path.join(exp_dir, 'train_images.json'), 'w') as f:
+                json.dump(img_names, f, indent=2)
     device_samplers = None
     if args.device_sampling:
         from .device_sampler import DeviceRaySamplers
@@ -283,7 +305,9 @@ def ddp_train_nerf(rank, args):
     trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,
                             cascade_samples=cascade, lrate=args.lrate, use_depth=args.use_depth,
                             depth_loss_type=args.depth_loss_type, lambda_depth=args.lambda_depth,
-                            depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world)
+                            depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world,
+                            optim_autoexpo=args.optim_autoexpo, img_names=img_names,
+                            lambda_autoexpo=args.lambda_autoexpo)
     ckpt, start = find_latest_checkpoint(args)
     if ckpt is not None:
         logger.info('Reloading from: {}'.format(ckpt))
@@ -306,6 +330,8 @@ def ddp_train_nerf(rank, args):
         else:
             i = np.random.randint(low=0, high=len(ray_samplers))
             ray_batch = batch_to_device(ray_samplers[i].random_sample(args.N_rand, center_crop=False), device)
+            if img_names is not None:
+                ray_batch['img_name'] = img_names[i]
         scalars = trainer.train_step(ray_batch)
         log_now = rank == 0 and (global_step % args.i_print == 0 or global_step < 10)
         if log_now:
@@ -314,6 +340,9 @@ def ddp_train_nerf(rank, args):
                 sc = sc.cpu().numpy()
                 if args.use_depth:
                     scalars_to_log['level_{}/loss_depth'.format(m)] = float(sc[2])
+                if trainer.last_autoexpo[m] is not None:
+                    scalars_to_log['level_{}/autoexpo_scale'.format(m)] = float(trainer.last_autoexpo[m][0])
+                    scalars_to_log['level_{}/autoexpo_shift'.format(m)] = float(trainer.last_autoexpo[m][1])
                 scalars_to_log['level_{}/rgb_loss'.format(m)] = float(sc[1])
                 scalars_to_log['level_{}/pnsr'.format(m)] = float(mse2psnr(float(sc[1])))
             scalars_to_log['iter_time'] = time.time() - time0

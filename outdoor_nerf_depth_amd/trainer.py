@@ -21,7 +21,8 @@ ALGO_MACS = {            # dense MACs per sample (SURVEY.md 8a / BASELINE.md sec
 class NerfppTrainer(object):
     def __init__(self, device, precision=L.PREC_SPLIT_BF16, cascade_samples=(64, 128), lrate=5e-4,
                  use_depth=True, depth_loss_type='mse', lambda_depth=0.1, depth_sigma=0.01, depth_scale=1.0,
-                 world_size=1, level_params=None, overlap_allreduce=True):
+                 world_size=1, level_params=None, overlap_allreduce=True, optim_autoexpo=False, img_names=None,
+                 lambda_autoexpo=1.0):
         self.device = torch.device(device)
         self.precision = precision
         self.cascade_samples = tuple(cascade_samples)
@@ -40,6 +41,17 @@ class NerfppTrainer(object):
         self.exp_avg_sq = [torch.zeros_like(e.params) for e in self.engines]
         self.grads = [torch.empty_like(e.params) for e in self.engines]
         self.step_count = 0
+        # per-image auto-exposure parameters, one set per level's net (ddp_model.py:161-192)
+        self.autoexpo = None
+        if optim_autoexpo:
+            if not img_names:
+                raise ValueError('optim_autoexpo needs the training image names (ddp_model.py:168)')
+            from .autoexpo import AutoExposure
+            self.img_names = list(img_names)
+            self.autoexpo = [AutoExposure(img_names, self.device, lrate, lambda_autoexpo, world_size)
+                             for _ in self.engines]
+        self._ae_grad = [None] * len(self.engines)
+        self.last_autoexpo = [None] * len(self.engines)
         self.comm_stream = torch.cuda.Stream(device=self.device) if (world_size > 1 and overlap_allreduce) else None
         self._pending = None
 
@@ -51,6 +63,8 @@ class NerfppTrainer(object):
         if self.world_size <= 1:
             return
         import torch.distributed as dist
+        if self._ae_grad[m] is not None:                  # [n_img, 3]: grads | used flag; a few hundred bytes
+            dist.all_reduce(self._ae_grad[m])
         if self.comm_stream is None:
             dist.all_reduce(self.grads[m])
             return
@@ -74,6 +88,9 @@ class NerfppTrainer(object):
         ops.adam_step(eng.params, self.grads[m], self.exp_avg[m], self.exp_avg_sq[m], self.step_count,
                       lr=self.lrate)
         eng.repack()
+        if self._ae_grad[m] is not None:
+            self.autoexpo[m].apply(self._ae_grad[m][:, :2], self._ae_grad[m][:, 2] > 0)
+            self._ae_grad[m] = None
 
     # -- one optimisation step ----------------------------------------------------------------------
     def train_step(self, batch, uniforms=None, events=None):
@@ -94,6 +111,12 @@ class NerfppTrainer(object):
         scalars = []
         ret = None
         deferred = None
+        ae_idx = None
+        if self.autoexpo is not None:
+            name = batch.get('img_name')
+            if name is None and 'frame' in batch:
+                name = self.img_names[int(batch['frame'])]
+            ae_idx = self.autoexpo[0].lookup(name)
         for m, eng in enumerate(self.engines):
             if m > 0:
                 u_fg = u['u_fg'] if 'u_fg' in u else torch.rand(n, S1, device=dev)
@@ -103,8 +126,17 @@ class NerfppTrainer(object):
             ev = events[m] if events is not None else None
             ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True,
                               events=ev['fwd'] if ev else None)
-            sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, batch['rgb'], depth_sup, self.loss_type,
+            ae = self.autoexpo[m] if ae_idx is not None else None
+            rgb_gt = ae.target(ae_idx, batch['rgb']) if ae is not None else batch['rgb']
+            sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, rgb_gt, depth_sup, self.loss_type,
                                                          self.lambda_depth, self.kl_sigma, fg_z, far)
+            if ae is not None:                    # ddp_train_nerf.py:472-479
+                g_ae = ae.finish(ae_idx, ret['rgb'], batch['rgb'], sc, g_rgb, self.lambda_depth)
+                rows = torch.zeros(len(ae.names), 3, device=dev)
+                rows[ae_idx, :2] = g_ae
+                rows[ae_idx, 2] = 1.0
+                self._ae_grad[m] = rows
+                self.last_autoexpo[m] = ae.scale_shift(ae_idx)
             eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m],
                          events=ev['bwd'] if ev else None)
             scalars.append(sc)

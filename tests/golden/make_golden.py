@@ -418,6 +418,60 @@ def gen_rays():
     save('rays', K=K, c2w=c2w, rays_o=o, rays_d=d, depth=depth)
 
 
+def gen_autoexpo():
+    """a11: NerfNetWithAutoExpo with --optim_autoexpo (ddp_model.py:161-192) through 4 steps of the
+    level-0 loop of ddp_train_nerf.py:467-498 (rgb loss on the exposure-corrected prediction + the
+    lambda_autoexpo regulariser + depth mse; Adam over net.parameters()).  Images 0, 2, 0, 1: image 0's
+    parameter is stepped twice, image 1/2 once (per-parameter Adam step counts)."""
+    torch.manual_seed(777)
+    names = ['scene/train/rgb/000000.png', 'scene/train/rgb/000001.png', 'scene/train/rgb/000002.png']
+    net = RM.NerfNetWithAutoExpo(ref_args(), optim_autoexpo=True, img_names=names)
+    optim = torch.optim.Adam(net.parameters(), lr=5e-4)
+    scene = SyntheticKitti(depth_sup_type='gt')
+    lam_ae, lam_d = 0.5, 0.1
+    arrs = {'names': np.array(names), 'lambda_autoexpo': lam_ae, 'lambda_depth': lam_d}
+    for step, img in enumerate((0, 2, 0, 1), start=1):
+        b = scene.random_batch(16, np.random.RandomState(300 + step))
+        b['depth_sup'][:5] = np.float32(0.03 * step)
+        # a colour cast so that the exposure parameters have something to explain
+        b['rgb'] = np.clip(b['rgb'] * np.float32(0.8 + 0.1 * img) + np.float32(0.05 * img), 0, 1).astype(np.float32)
+        bt = {k: T(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+        li = level_inputs(b, 3000 + step)
+        optim.zero_grad()
+        ret = net(bt['ray_o'], bt['ray_d'], li['far'], li['fg0'], li['bg0'], img_name=names[img])
+        scale, shift = ret['autoexpo']                                       # :472-479
+        rgb_pred = (ret['rgb'] - shift) / scale
+        rgb_loss = RU.img2mse(rgb_pred, bt['rgb'])
+        loss = rgb_loss + lam_ae * (torch.abs(scale - 1.) + torch.abs(shift))
+        depth_loss = R.depth_losses_dict['mse'](bt['depth_sup'], ret['depth'])
+        loss = loss + lam_d * depth_loss
+        loss.backward()
+        pname = 'autoexpo_params.' + RM.remap_name(names[img])
+        g = dict(net.named_parameters())[pname].grad.numpy().copy()
+        scale_v, shift_v = scale.item(), shift.item()         # shift is a view of the parameter: read before the step
+        optim.step()
+        for k in ('ray_o', 'ray_d', 'rgb', 'depth_sup', 'min_depth'):
+            arrs['s%d.%s' % (step, k)] = b[k]
+        arrs['s%d.t_fg' % step] = li['t_fg'].numpy()
+        arrs['s%d.t_bg' % step] = li['t_bg'].numpy()
+        arrs['s%d.img' % step] = img
+        arrs['s%d.ret_rgb' % step] = ret['rgb'].detach().numpy()
+        arrs['s%d.ret_depth' % step] = ret['depth'].detach().numpy()
+        arrs['s%d.loss' % step] = loss.item()
+        arrs['s%d.rgb_loss' % step] = rgb_loss.item()
+        arrs['s%d.depth_loss' % step] = depth_loss.item()
+        arrs['s%d.scale' % step] = scale_v
+        arrs['s%d.shift' % step] = shift_v
+        arrs['s%d.grad' % step] = g
+        arrs['s%d.params_after' % step] = np.stack([p.detach().numpy().copy() for k, p in net.named_parameters()
+                                                    if k.startswith('autoexpo_params.')])
+    sd = net.state_dict()
+    arrs['state_keys'] = np.array([k for k in sd.keys() if k.startswith('autoexpo')])
+    w = sd['nerf_net.fg_net.rgb_layers.2.weight'].numpy()
+    arrs['final.fg_rgb2_weight'] = w
+    save('autoexpo', **arrs)
+
+
 if __name__ == '__main__':
     gen_sampling()
     gen_embed()
@@ -430,3 +484,4 @@ if __name__ == '__main__':
     gen_train_steps()
     gen_adam_unit()
     gen_rays()
+    gen_autoexpo()

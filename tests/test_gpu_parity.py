@@ -345,3 +345,27 @@ def test_full_size_properties(ops, levels, prec):
     gb = e1.backward(g_rgb, g_depth, g_w)
     assert torch.equal(ga, gb)
     assert bool(torch.isfinite(ga).all()) and float(ga.abs().max()) > 0
+
+
+def test_autoexposure_training_steps_match_reference(ops, golden):
+    """SURVEY 8a row a11 end to end: NerfppTrainer with optim_autoexpo (one cascade level, split-bf16)
+    through the reference's 4 steps of tests/golden/autoexpo.npz -- losses, exposure parameters after
+    every step, and a network tensor at the end (its gradient goes through the 1/scale^2 factor)."""
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    from outdoor_nerf_depth_amd.model import init_level_params, state_dict_from_flat
+    g = golden('autoexpo')
+    names = [str(x) for x in g['names']]
+    tr = NerfppTrainer(dev(), precision=2, cascade_samples=(64,), use_depth=True, depth_loss_type='mse',
+                       lambda_depth=float(g['lambda_depth']), level_params=init_level_params(1),
+                       optim_autoexpo=True, img_names=names, lambda_autoexpo=float(g['lambda_autoexpo']))
+    for step in range(1, 5):
+        img = int(g['s%d.img' % step])
+        batch = {k: T(g['s%d.%s' % (step, k)]) for k in ('ray_o', 'ray_d', 'rgb', 'depth_sup', 'min_depth')}
+        batch['img_name'] = names[img]
+        sc = tr.train_step(batch, uniforms={'t_fg': T(g['s%d.t_fg' % step]), 't_bg': T(g['s%d.t_bg' % step])})
+        close(N(sc[0])[0], g['s%d.loss' % step], 5e-4, 0)
+        close(N(sc[0])[1], g['s%d.rgb_loss' % step], 5e-4, 1e-7)
+        close(float(tr.last_autoexpo[0][0]), g['s%d.scale' % step], 1e-6, 0)
+        np.testing.assert_allclose(N(tr.autoexpo[0].params), g['s%d.params_after' % step], rtol=2e-4, atol=2e-7)
+    w = state_dict_from_flat(tr.engines[0].params)['module.nerf_net.fg_net.rgb_layers.2.weight']
+    np.testing.assert_allclose(N(w), g['final.fg_rgb2_weight'], rtol=0, atol=2e-4)

@@ -55,3 +55,35 @@ def test_train_cli_checkpoint_resume_and_eval(tmp_path):
     from outdoor_nerf_depth_amd.model import state_dict_from_flat
     assert torch.equal(state_dict_from_flat(got)['module.nerf_net.fg_net.sigma_layers.0.weight'],
                        ck['net_1']['module.nerf_net.fg_net.sigma_layers.0.weight'])
+
+
+def test_train_cli_with_autoexposure(tmp_path):
+    """--optim_autoexpo: train_images.json, autoexpo_params.* in net_m, their Adam
+    entries after the 48 network tensors, resume."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import json
+    from outdoor_nerf_depth_amd import ddp_train_nerf as T
+    base = ['--expname', 'ae', '--basedir', str(tmp_path), '--synthetic', '--synthetic_hw', '24,32',
+            '--synthetic_frames', '10', '--cascade_samples', '64,128', '--world_size', '1', '--N_rand_override', '128',
+            '--i_weights', '4', '--i_print', '1', '--optim_autoexpo', '--lambda_autoexpo', '0.5']
+    args = T.config_parser().parse_args(base + ['--N_iters', '5'])
+    T.validate_args(args)
+    args.world_size = 1
+    T.ddp_train_nerf(0, args)
+    exp = tmp_path / 'ae'
+    names = json.loads((exp / 'train_images.json').read_text())
+    ck = torch.load(exp / 'model_000004.pth', map_location='cpu', weights_only=False)
+    ae_keys = [k for k in ck['net_1'] if 'autoexpo_params' in k]
+    assert len(ae_keys) == len(names) and ae_keys[0] == 'module.autoexpo_params.train/rgb/000000-png'
+    assert list(ck['net_0'].keys())[48] == ae_keys[0]                      # after the network tensors
+    assert len(ck['optim_0']['param_groups'][0]['params']) == 48 + len(names)
+    stepped = [i for i in range(len(names)) if 48 + i in ck['optim_0']['state']]
+    assert 1 <= len(stepped) <= 5
+    moved = [k for k in ae_keys if not torch.equal(ck['net_0'][k], torch.tensor([0.5, 0.]))]
+    assert len(moved) == len(stepped)
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    tr = NerfppTrainer(torch.device('cuda:0'), optim_autoexpo=True, img_names=names)
+    T.load_checkpoint(str(exp / 'model_000004.pth'), tr)
+    assert torch.equal(tr.autoexpo[1].params.cpu()[stepped[0]], ck['net_1'][ae_keys[stepped[0]]])
+    assert float(tr.autoexpo[0].steps[stepped[0]]) >= 1

@@ -43,7 +43,7 @@ def test_config_file_then_command_line_override(tmp_path):
     assert a.scene == 'seq00' and a.cascade_samples == '64,128' and a.use_viewdirs and a.N_rand == 1024
     assert a.trainskip == 4 and a.use_depth and a.expname == 'run1' and a.ckpt_path is None
     T.validate_args(a)
-    for bad in (['--netwidth', '128'], ['--optim_autoexpo'], ['--use_depth', '--depth_loss_type', 'nll']):
+    for bad in (['--netwidth', '128'], ['--use_depth', '--depth_loss_type', 'nll']):
         with pytest.raises(SystemExit):
             T.validate_args(T.config_parser().parse_args(['--expname', 'x'] + bad))
 
@@ -183,3 +183,49 @@ def test_two_rank_gradient_average_gloo(tmp_path):
         mine = avg[off:off + n][g['avg.%s.idx' % k]]
         assert np.abs(mine - g['avg.%s.g' % k]).max() <= 5e-2 * g['avg.%s.rms' % k] + 1e-12, k
         off += n
+
+
+def test_autoexposure_matches_reference_steps(golden):
+    """the per-image (scale, shift) parameters, their part of the loss and their Adam
+    update (host-side torch) against 4 steps of the reference (tests/golden/autoexpo.npz).  The HIP loss
+    kernel is emulated here by its definition: mse + its gradient on (rgb, gt')."""
+    from outdoor_nerf_depth_amd.autoexpo import AutoExposure, remap_name
+    g = golden('autoexpo')
+    names = [str(x) for x in g['names']]
+    assert ['autoexpo_params.' + remap_name(n) for n in names] == [str(k) for k in g['state_keys']]
+    lam_d = float(g['lambda_depth'])
+    ae = AutoExposure(names, 'cpu', lrate=5e-4, lambda_autoexpo=float(g['lambda_autoexpo']))
+    for step in range(1, 5):
+        img = int(g['s%d.img' % step])
+        idx = ae.lookup('some/prefix/' + names[img])
+        assert idx == img
+        rgb, gt = torch.from_numpy(g['s%d.ret_rgb' % step]), torch.from_numpy(g['s%d.rgb' % step])
+        scale, shift = ae.scale_shift(idx)
+        np.testing.assert_allclose(float(scale), g['s%d.scale' % step], rtol=1e-6)
+        np.testing.assert_allclose(float(shift), g['s%d.shift' % step], rtol=1e-6, atol=1e-9)
+        gtp = ae.target(idx, gt)
+        mse = ((rgb - gtp) ** 2).mean()
+        depth_loss = float(g['s%d.depth_loss' % step])
+        scalars = torch.tensor([float(mse) + lam_d * depth_loss, float(mse), depth_loss, 0.])
+        g_rgb = 2.0 * (rgb - gtp) / rgb.numel()
+        want_g_rgb = 2.0 * ((rgb - shift) / scale - gt) / rgb.numel() / scale
+        grad = ae.finish(idx, rgb, gt, scalars, g_rgb, lam_d)
+        np.testing.assert_allclose(g_rgb.numpy(), want_g_rgb.numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(float(scalars[1]), g['s%d.rgb_loss' % step], rtol=1e-5)
+        np.testing.assert_allclose(float(scalars[0]), g['s%d.loss' % step], rtol=1e-5)
+        np.testing.assert_allclose(grad.numpy(), g['s%d.grad' % step], rtol=2e-4, atol=1e-7)
+        rows = torch.zeros(len(names), 2)
+        rows[idx] = grad
+        used = torch.zeros(len(names), dtype=torch.bool)
+        used[idx] = True
+        ae.apply(rows, used)
+        np.testing.assert_allclose(ae.params.numpy(), g['s%d.params_after' % step], rtol=1e-6, atol=1e-9)
+    # checkpoint entries: reference key names; never-stepped parameters have no optimiser state
+    keys = [k for k, _ in ae.state_dict_entries()]
+    assert keys == ['module.' + str(k) for k in g['state_keys']]
+    st = ae.adam_entries()
+    assert float(st[0]['step']) == 2 and float(st[1]['step']) == 1 and float(st[2]['step']) == 1
+    ae2 = AutoExposure(names, 'cpu')
+    ae2.load_state_dict_entries(dict(ae.state_dict_entries()))
+    ae2.load_adam_entries(st)
+    assert torch.equal(ae2.params, ae.params) and torch.equal(ae2.exp_avg_sq, ae.exp_avg_sq)
