@@ -80,6 +80,10 @@ def lib():
                 'libnerfpp_hip.so not found at %s -- build it with `python -c "import '
                 '__graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950). There is no '
                 'CPU fallback for the NeRF++ hot path.' % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64; device pointers and streams only make sense inside ONE
+        # HIP runtime, so torch's must be the copy already in the process when our library resolves
+        # its libamdhip64 dependency (whichever is loaded first wins the SONAME).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)         # AttributeError if the .so is stale
