@@ -343,50 +343,102 @@ __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
 
 // fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements).
 // The accumulator layout gives every lane 8-byte pieces of 32 DIFFERENT rows, so the tile is first
-// transposed through a per-wave LDS staging area ([32 rows][PC*16 cols], row stride PC*32+16 B) and
-// then written with 16 B per lane (whole 128..256-byte row segments per instruction), non-temporal.
+// transposed through LDS and then written with 16 B per lane (128-byte row segments), non-temporal.
 // (Rows past the end of the batch (tile tail, < rows_padded) must be written as zeros so the
 // weight-gradient GEMMs can run over whole 32-row chunks without masking: the kernels zero those
 // lanes' fragments -- zero_invalid, last tile only -- before they get here.)
-template <int PC> constexpr int stage_row() { return PC * 32 + 16; }
+//
+// Bank-conflict-free transposition image (bf16 kernels; PMC SQ_LDS_BANK_CONFLICT ~ 0):
+//   * a row of the image holds one sample's 128-byte segment (per-wave staging) or its whole 512 bytes
+//     (loader hand-off region), with a row stride of 2 (mod 32) dwords: 34 dwords = 136 B / 130 dwords
+//     = 520 B.  ds_write_b64 is served in groups of 16 consecutive lanes = 16 consecutive rows over 32
+//     banks: bank = 2*row + const, all distinct.
+//   * rows are only 8-byte aligned then, so the read side uses 8-byte reads, and the lanes of a 32-lane
+//     read group take rows {a, a+1, a+16, a+17} (8 sixteen-byte pieces each): their row offsets are
+//     {0, 2, 32, 34} (mod 64) dwords and the pieces step by 4, which tiles the 64 banks exactly.
+template <int PC> constexpr int stage_row() { return PC == 4 ? 136 : PC * 32 + 16; }
 template <int PC> constexpr int stage_bytes() { return 32 * stage_row<PC>(); }
+constexpr int REGION_ROW = 520;
+constexpr int REGION_MASK = 32 * REGION_ROW;                 // 64 x 16 B of ReLU sign words after the tile
+constexpr int REGION_BYTES = 18432;
+static_assert(REGION_MASK + 1024 <= REGION_BYTES, "hand-off region");
+
+// read-side lane map: lane -> (row within a 4-row step, 16-byte piece of the 128-byte segment)
+__device__ __forceinline__ int xp_row(int lane) { return (lane >> 5) * 2 + ((lane >> 3) & 1) + 16 * ((lane >> 4) & 1); }
+__device__ __forceinline__ int xp_piece(int lane) { return lane & 7; }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// image [32 rows][ROWB] -> global rows: segment `seg` (128 B) of all 32 rows, 4 wave-stores; only the
+// first seg_bytes of the segment exist (narrow tensors).  The reads are 8 x ds_read_b64 issued through
+// inline asm (2 LDS cycles each over 64 banks; left to itself the compiler fuses each pair into a
+// ds_read2_b64: 8 cycles over 32 banks) followed by one lgkmcnt(0) that carries the values as operands.
+template <int ROWB>
+__device__ __forceinline__ void xp_store_segment(const char* img, char* g_seg, int ld, int lane, int seg, int seg_bytes) {
+  const int row = xp_row(lane), piece = xp_piece(lane);
+  if (piece * 16 >= seg_bytes) return;
+  const uint32_t sl = (uint32_t)(uintptr_t)(img + row * ROWB + seg * 128 + piece * 16);   // low 32 bits = LDS address
+  char* gl = g_seg + (size_t)row * ld * 2 + piece * 16;
+  u32x2 lo[4], hi[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo[it]) : "v"(sl), "n"(it * 4 * ROWB) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi[it]) : "v"(sl), "n"(it * 4 * ROWB + 8) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]));
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+    store_nt16(gl + (size_t)it * 4 * ld * 2, make_uint4(lo[it][0], lo[it][1], hi[it][0], hi[it][1]));
+}
+// write side: lane (j, hi) puts its 8-byte pieces of chunks [c0, c0+n) into row j of the image
+template <int ROWB, int NCH, int P>
+__device__ __forceinline__ void xp_write(char* img, int lane, const Frag<P> (&h)[NCH], int p, int c0, int n, int col0) {
+  char* w = img + (lane & 31) * ROWB + 8 * (lane >> 5) + col0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < n) {
+      const uint4 bits = *(const uint4*)&h[c0 + c].v[p];
+      *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
+      *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
+    }
+  }
+}
 
 template <int NCH, int P, int PC>
 __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t plane, int ld, size_t wave_row0,
                                            int lane, const Frag<P> (&h)[NCH]) {
   constexpr int SR = stage_row<PC>();
-  const int j = lane & 31, hi = lane >> 5;
   if constexpr ((NERFPP_DBG & 2) != 0) return;
+  if constexpr (PC == 4) {
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
+    for (int p = 0; p < P; ++p) {
 #pragma unroll
-    for (int c0 = 0; c0 < NCH; c0 += PC) {
-      const int nc = NCH - c0 < PC ? NCH - c0 : PC;           // chunks in this pass (compile-time after unroll)
-      char* w = stage + j * SR + 8 * hi;
-#pragma unroll
-      for (int c = 0; c < PC; ++c) {
-        if (c < nc) {
-          const uint4 bits = *(const uint4*)&h[c0 + c].v[p];
-          *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
-          *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
-        }
+      for (int c0 = 0; c0 < NCH; c0 += 4) {
+        const int nc = NCH - c0 < 4 ? NCH - c0 : 4;
+        xp_write<SR, NCH, P>(stage, lane, h, p, c0, nc, 0);
+        lds_wave_sync();
+        xp_store_segment<SR>(stage, (char*)(base + p * plane + wave_row0 * ld + c0 * 16), ld, lane, 0, nc * 32);
+        lds_wave_sync();
       }
-      lds_wave_sync();
-      const int lpr = 2 * nc;                               // 16-byte pieces per row
-      char* g = (char*)(base + p * plane + wave_row0 * ld + c0 * 16);
-      if ((lpr & (lpr - 1)) == 0) {
-        // power-of-two row length: one per-lane base address + compile-time offsets
-        const int rpi = 64 / lpr, row = lane / lpr, piece = lane - row * lpr;
-        char* gl = g + (size_t)row * ld * 2 + piece * 16;
-        const char* sl = stage + row * SR + piece * 16;
-        uint4 v[PC];
+    }
+  } else {
+    const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
-        for (int it = 0; it < PC; ++it)
-          if (it < nc) v[it] = *(const uint4*)(sl + it * rpi * SR);
+    for (int p = 0; p < P; ++p) {
 #pragma unroll
-        for (int it = 0; it < PC; ++it)
-          if (it < nc) store_nt16(gl + (size_t)it * rpi * ld * 2, v[it]);
-      } else {
+      for (int c0 = 0; c0 < NCH; c0 += PC) {
+        const int nc = NCH - c0 < PC ? NCH - c0 : PC;           // chunks in this pass (compile-time after unroll)
+        char* w = stage + j * SR + 8 * hi;
+#pragma unroll
+        for (int c = 0; c < PC; ++c) {
+          if (c < nc) {
+            const uint4 bits = *(const uint4*)&h[c0 + c].v[p];
+            *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
+            *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
+          }
+        }
+        lds_wave_sync();
+        const int lpr = 2 * nc;                               // 16-byte pieces per row
+        char* g = (char*)(base + p * plane + wave_row0 * ld + c0 * 16);
 #pragma unroll
         for (int it = 0; it < PC; ++it) {
           const int idx = it * 64 + lane;
@@ -395,8 +447,8 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
             store_nt16(g + (size_t)row * ld * 2 + piece * 16, *(const uint4*)(stage + row * SR + piece * 16));
           }
         }
+        lds_wave_sync();
       }
-      lds_wave_sync();
     }
   }
 }
@@ -405,86 +457,40 @@ __device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t pla
 // pass_write in block 2p, pass_store in block 2p+1 -- no LDS round trip is waited for in place.
 template <int NCH>
 __device__ __forceinline__ void pass_write(char* stage, int lane, const Frag<1> (&h)[NCH], int c0) {
-  constexpr int SR = stage_row<4>();
   if constexpr ((NERFPP_DBG & 2) != 0) return;
-  char* w = stage + (lane & 31) * SR + 8 * (lane >> 5);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const uint4 bits = *(const uint4*)&h[c0 + c].v[0];
-    *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
-    *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
-  }
+  xp_write<stage_row<4>(), NCH, 1>(stage, lane, h, 0, c0, 4, 0);
 }
 __device__ __forceinline__ void pass_store(const char* stage, __bf16* base, int ld, size_t wave_row0, int lane, int c0) {
-  constexpr int SR = stage_row<4>();
   if constexpr ((NERFPP_DBG & 2) != 0) return;
   lds_wave_sync();
-  const int row = lane >> 3, piece = lane & 7;                // 8 x 16 B per 128-B row segment, 8 rows per store
-  char* gl = (char*)(base + wave_row0 * ld + c0 * 16) + (size_t)row * ld * 2 + piece * 16;
-  const char* sl = stage + row * SR + piece * 16;
-  uint4 v[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) v[it] = *(const uint4*)(sl + it * 8 * SR);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) store_nt16(gl + (size_t)it * 8 * ld * 2, v[it]);
+  xp_store_segment<stage_row<4>()>(stage, (char*)(base + wave_row0 * ld + c0 * 16), ld, lane, 0, 128);
 }
 
 // ---- PIPE_ROLES hand-off: the loader's tile goes to an LDS region, wave 1 writes it out later --------
-constexpr int REGION_ROW = 528;                              // 512 B of data + 16 B pad
-constexpr int REGION_MASK = 32 * REGION_ROW;                 // 64 x 16 B of ReLU sign words after the tile
-constexpr int REGION_BYTES = REGION_MASK + 1024 + 512;       // 18432
-
 template <int NCH>
 __device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<1> (&h)[NCH]) {
-  const int j = lane & 31, hi = lane >> 5;
   if constexpr ((NERFPP_DBG & (2 | 16)) != 0) return;
-  char* w = region + j * REGION_ROW + 8 * hi;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const uint4 bits = *(const uint4*)&h[c].v[0];
-    *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
-    *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
-  }
+  for (int c0 = 0; c0 < NCH; c0 += 4) xp_write<REGION_ROW, NCH, 1>(region, lane, h, 0, c0, NCH - c0 < 4 ? NCH - c0 : 4, c0 * 32);
 }
 // wave 1, after the barrier that follows the loader's handoff_write: region -> HBM (mask_dst: this lane's
 // slot of the loader's sign-word block, or nullptr)
 template <int NCH>
 __device__ __forceinline__ void handoff_flush(const char* region, int lane, __bf16* base, int ld, size_t row0,
                                               uint4* mask_dst) {
-  constexpr int LPR = 2 * NCH;
-  char* g = (char*)(base + row0 * ld);
   if constexpr ((NERFPP_DBG & 16) != 0) return;
-  if constexpr ((LPR & (LPR - 1)) == 0) {
-    constexpr int RPI = 64 / LPR;
-    const int row = lane / LPR, piece = lane - row * LPR;
-    char* gl = g + (size_t)row * ld * 2 + piece * 16;
-    const char* sl = region + row * REGION_ROW + piece * 16;
+  char* g = (char*)(base + row0 * ld);
 #pragma unroll
-    for (int it = 0; it < NCH; ++it) store_nt16(gl + (size_t)it * RPI * ld * 2, *(const uint4*)(sl + it * RPI * REGION_ROW));
-  } else {
-#pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-      const int idx = it * 64 + lane;
-      const int row = idx / LPR, piece = idx - row * LPR;
-      store_nt16(g + (size_t)row * ld * 2 + piece * 16, *(const uint4*)(region + row * REGION_ROW + piece * 16));
-    }
-  }
+  for (int seg = 0; seg < (NCH + 3) / 4; ++seg)
+    xp_store_segment<REGION_ROW>(region, g + seg * 128, ld, lane, seg, NCH * 32 - seg * 128);
   if (mask_dst) *mask_dst = *(const uint4*)(region + REGION_MASK + lane * 16);
 }
-// one of PARTS equal slices of the same flush (power-of-two row lengths only)
+// one 128-byte segment (= 4 chunks) of the same flush: part in [0, NCH/4)
 template <int NCH, int PARTS>
 __device__ __forceinline__ void handoff_flush_part(const char* region, int lane, __bf16* base, int ld, size_t row0, int part) {
-  constexpr int LPR = 2 * NCH, RPI = 64 / LPR, ITS = NCH / PARTS;
-  static_assert((LPR & (LPR - 1)) == 0 && NCH % PARTS == 0, "power-of-two rows");
+  static_assert(NCH % 4 == 0 && PARTS == NCH / 4, "one part per 128-byte segment");
   if constexpr ((NERFPP_DBG & 16) != 0) return;
-  const int row = lane / LPR, piece = lane - row * LPR;
-  char* gl = (char*)(base + row0 * ld) + (size_t)row * ld * 2 + piece * 16;
-  const char* sl = region + row * REGION_ROW + piece * 16;
-  uint4 v[ITS];
-#pragma unroll
-  for (int k = 0; k < ITS; ++k) v[k] = *(const uint4*)(sl + (part * ITS + k) * RPI * REGION_ROW);
-#pragma unroll
-  for (int k = 0; k < ITS; ++k) store_nt16(gl + (size_t)(part * ITS + k) * RPI * ld * 2, v[k]);
+  xp_store_segment<REGION_ROW>(region, (char*)(base + row0 * ld) + part * 128, ld, lane, part, 128);
 }
 
 // dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
