@@ -31,7 +31,7 @@ PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s measured copy ceiling)
 # algorithmic bytes per sample row read by the weight-gradient GEMMs (every operand once per job):
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
-DW_BYTES_PER_ROW = (5216 + 5280) * 2
+DW_BYTES_PER_ROW = (4960 + 5024) * 2
 # level-1 dW launch pair at N_rand=1024, bf16: FETCH_SIZE (x2 gfx950 wide-stream correction) + WRITE_SIZE
 DW_TRAFFIC_PMC_BYTES = (2 * 1.5 * (917.6e6 + 425.2e6)) + 1.5 * (64.7e6 + 18.4e6)
 DW_TRAFFIC_SOURCE = 'profiles/r01_e_kernel_stats_timeline_hbm.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
@@ -115,7 +115,7 @@ def run_mode(args, precision, rank, world, device, batches):
     dominant = max(share, key=share.get)
     # HBM bytes of the dominant launch from the PMC passes committed under profiles/ (cannot be collected
     # inside this process): only quoted for the configuration they were measured on
-    traffic = DW_TRAFFIC_PMC_BYTES if (n == 1024 and precision == 1) else None
+    traffic = DW_TRAFFIC_PMC_BYTES if (DW_TRAFFIC_PMC_BYTES and n == 1024 and precision == 1) else None
     return dict(elapsed=elapsed, ms_per_step=1e3 * elapsed / K, value=n * K * world / elapsed, loss=loss,
                 value_per_gpu=n * K / elapsed, kernels=kernels, dominant=dominant, share_ms=share,
                 dw_traffic_pmc=traffic)

@@ -86,6 +86,8 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
       L.d_out[net] = off; off = align_up(off + (size_t)L.rows_padded * 16, 256);
       for (int t = 0; t < T_COUNT; ++t) {
         L.tensor[net][t] = off;
+        if (t == T_R || t == T_DR) continue;     // never materialised (remap_fixup_kernel derives their gradients)
+        if (t == T_DG) continue;                 // columns 32..159 of the [dS | dG] tensor allocated as T_DS
         off = align_up(off + (size_t)L.rows_padded * tensor_ld(net, t) * 2 * P, 256);
       }
       L.slabs[net] = off; off = align_up(off + (size_t)L.ksplit * gslab_floats(net) * 4, 256);
@@ -101,6 +103,7 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
 NetWs make_netws(char* ws, const WsLayout& L, int net) {
   NetWs w;
   for (int t = 0; t < T_COUNT; ++t) w.t[t] = (__bf16*)(ws + L.tensor[net][t]);
+  w.t[T_DG] = w.t[T_DS] + DG_COL0;
   return w;
 }
 

@@ -146,9 +146,12 @@ enum Tensor {
   T_X = 0, T_H0 = 1, /* .. T_H7 = 8 */ T_R = 9, T_G = 10, T_DIRX = 11,
   T_DZ0 = 12, /* .. T_DZ7 = 19 */ T_DR = 20, T_DS = 21, T_DG = 22, T_DP = 23, T_COUNT = 24
 };
+// dS (32 columns) and dG (128 columns) share one row-major tensor [rows][160]: T_DS points at column 0,
+// T_DG at column 32 of it, so the weight-gradient job that contracts both with H7 reads H7 once.
+constexpr int DSG_LD = 160, DG_COL0 = 32;
 __host__ __device__ constexpr int tensor_ld(int net, int t) {
   return t == T_X ? kpew(net) : (t >= T_H0 && t <= T_R) ? 256 : t == T_G ? 128 : t == T_DIRX ? 32
-       : (t >= T_DZ0 && t <= T_DR) ? 256 : t == T_DS ? 32 : t == T_DG ? 128 : 32;
+       : (t >= T_DZ0 && t <= T_DR) ? 256 : (t == T_DS || t == T_DG) ? DSG_LD : 32;
 }
 __host__ __device__ constexpr int tensor_off_cols(int net, int t) {   // column offset in a row "super-struct"
   int off = 0;
@@ -187,8 +190,12 @@ struct DwJob {       // one 128x128 (or smaller) output tile of one weight-gradi
   int32_t gw_off;                 // offset of element (o0, i_global0) in the slab
   int16_t gw_ld;                  // row stride of this stage's GW block
   int16_t gb_off;                 // offset of bias o0 in the slab's bias part, or -1
+  // optional second output segment: out-blocks >= o_split go to (gw_off2, gw_ld2, gb_off2), rows re-based
+  int16_t o_split;                // in 32-row blocks; 0 = single segment
+  int16_t gw_ld2, gb_off2;
+  int32_t gw_off2;
 };
-constexpr int DW_JOBS = 13;                  // per net (build_all_jobs order)
+constexpr int DW_JOBS = 12;                  // per net (build_all_jobs order)
 constexpr int DW_KMAX = 32;                  // slabs allocated per net; a job uses the first k_job of them
 
 struct JobTable {
@@ -209,7 +216,8 @@ constexpr void add_job(JobTable& jt, int net, int s, int b_tensor, int icol, boo
   jt.jobs[net][jt.count[net]++] = j;
 }
 // job index per net: 0 L0 | 1-4 L1-L4 | 5 L5 (encoded-point columns) | 6 L5 (h4 columns) | 7,8 L6,L7 |
-// 9 sigma | 10 rgb0 (M = dG^T H7, see remap_fixup_kernel) | 11 rgb0 (view-direction columns) | 12 rgb1
+// 9 [dS | dG]^T H7 = sigma weights + M (M = dG^T H7, see remap_fixup_kernel) | 10 rgb0 (view-direction
+// columns) | 11 rgb1
 constexpr JobTable build_all_jobs() {
   JobTable jt{};
   for (int net = 0; net < N_NET; ++net) {
@@ -221,9 +229,16 @@ constexpr JobTable build_all_jobs() {
         add_job(jt, net, s, T_H0 + 4, kpew(net), false);
       } else if (s < 8) add_job(jt, net, s, T_H0 + s - 1, 0, true);
       else if (s == FS_REMAP) continue;            // dW_remap = Wrgb0r^T * M, derived in remap_fixup_kernel
-      else if (s == FS_SIG) add_job(jt, net, s, T_H0 + 7, 0, true);
+      else if (s == FS_SIG) continue;              // merged into the next job
       else if (s == FS_RGB0) {
-        add_job(jt, net, s, T_H0 + 7, 0, true);    // M = dG^T * H7 (NOT dG^T * R), fixed up after the slab sum
+        // [dS | dG]^T * H7: rows 0..31 -> sigma stage, rows 32..159 -> M (NOT dG^T * R; fixed up after the slab sum)
+        add_job(jt, net, FS_SIG, T_H0 + 7, 0, true);
+        DwJob& m = jt.jobs[net][jt.count[net] - 1];
+        m.n_o = DSG_LD;
+        m.o_split = 1;
+        m.gw_off2 = gw_off(net, FS_RGB0);
+        m.gw_ld2 = (int16_t)gw_I(net, FS_RGB0);
+        m.gb_off2 = (int16_t)gb_off(FS_RGB0);
         add_job(jt, net, s, T_DIRX, 256, false);
       } else add_job(jt, net, s, T_G, 0, true);
     }
@@ -261,8 +276,8 @@ __host__ __device__ constexpr int slab_job_index(const SlabMap& m, int net, int 
   if (s < 8) return s + 1;
   if (s == FS_REMAP) return -1;
   if (s == FS_SIG) return 9;
-  if (s == FS_RGB0) return (is_bias || col < 256) ? 10 : 11;
-  return 12;
+  if (s == FS_RGB0) return (is_bias || col < 256) ? 9 : 10;
+  return 11;
 }
 
 // How many row slices (= workgroups = slabs) each job gets.  The full 256x256 jobs all stream the

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) 
       const int id = x * 8 + wave;                 // 0 .. 32P-1
       const int op = id / (16 * P), rem = id - op * 16 * P, pl = rem >> 4, seg = rem & 15;
       const int rb = op == 0 ? rb_a : rb_b;
-      if (dma_col < rb) {
+      if (dma_col < (op == 0 ? job.n_o : job.n_i) * 2) {       // only the job's columns of the (possibly wider) rows
         const char* src = (op == 0 ? ga + pl * plane_a : gb + pl * plane_b) +
                           (size_t)(r0 + 2 * seg + dma_row) * rb + dma_col;
         glds16(src, buf + (op * P + pl) * OPER_BYTES + seg * SEG);
@@ -250,14 +250,19 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) 
       const int b = wave + 8 * k;
       if (b >= nblk) break;
       const int bo = b / n_ib, bi = b - bo * n_ib;
+      // output segment of this out-block (a job may feed two stages, see DwJob::o_split)
+      const bool seg2 = job.o_split > 0 && bo >= job.o_split;
+      const int sbo = seg2 ? bo - job.o_split : bo;
+      const int s_off = seg2 ? job.gw_off2 : job.gw_off, s_ld = seg2 ? job.gw_ld2 : job.gw_ld;
+      const int s_gb = seg2 ? job.gb_off2 : job.gb_off;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = 32 * bo + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        slab[job.gw_off + o * job.gw_ld + 32 * bi + li] = acc_rr[k][r];
+        const int o = 32 * sbo + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        slab[s_off + o * s_ld + 32 * bi + li] = acc_rr[k][r];
       }
       if (job.gb_off >= 0 && bi == 0) {
         const float tot = bsum_rr[k] + __shfl_xor(bsum_rr[k], 32, 64);
-        if (hi == 0) slab[gw_floats(net) + job.gb_off + 32 * bo + li] = tot;
+        if (hi == 0) slab[gw_floats(net) + s_gb + 32 * sbo + li] = tot;
       }
     }
     return;

@@ -909,7 +909,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     save_frags<2, P, PC>(stage, a.ws.t[T_DP], plane_rows * 32, 32, r0, lane, t);
     t[0] = zero_frag<P>();
     if (hi == 0) set_slot<P>(t[0], 0, dd.w);
-    save_frags<2, P, PC>(stage, a.ws.t[T_DS], plane_rows * 32, 32, r0, lane, t);
+    save_frags<2, P, PC>(stage, a.ws.t[T_DS], plane_rows * DSG_LD, DSG_LD, r0, lane, t);   // columns 0..31 of [dS | dG]
   };
   {
     const size_t rr = row_raw - 32;                         // the loader's row of this lane (partner only)
@@ -931,14 +931,14 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     init_zero<4>(acc4);
     stage_gemm<4, 4, P>(pipe, acc4, in, NoHook{});
     mask_to_frags<4, P>(acc4, get_mask(8), dg);
-    save(std::integral_constant<int, 8>{}, a.ws.t[T_DG], 128, dg);
+    save(std::integral_constant<int, 8>{}, a.ws.t[T_DG], DSG_LD, dg);
   }
   f32x16 acc[8];
   Frag<P> dz[16];
   // B1: dR = Wrgb0[:, :256]^T dG  (no activation on the remap layer; dR is not saved, see nerfpp_optim.hip)
   init_zero<8>(acc);
   // (the barrier just passed ends every wave's use of sign words 8: their slot takes words 6)
-  stage_gemm<8, 8, P>(pipe, acc, dg, HOOK(psave(blk, IC(8), dg, a.ws.t[T_DG], 128); if (blk == 0) issue_masks(6)));
+  stage_gemm<8, 8, P>(pipe, acc, dg, HOOK(psave(blk, IC(8), dg, a.ws.t[T_DG], DSG_LD); if (blk == 0) issue_masks(6)));
   acc_to_frags<8, P, ACT_NONE>(acc, dz);
   // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
   {
