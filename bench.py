@@ -70,6 +70,7 @@ def run_mode(args, precision, rank, world, device, batches):
         events.append(per_level)
     for i in range(W):
         tr.train_step(batches[i])
+    tr.flush()
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -79,6 +80,7 @@ def run_mode(args, precision, rank, world, device, batches):
     last = None
     for i in range(K):
         last = tr.train_step(batches[W + i], events=events[i])
+    tr.flush()                                   # the last step's level-1 all-reduce + Adam belong to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -143,6 +143,7 @@ def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size):
     import torch
     from . import ops
     from .dist_utils import shard_sizes, gather_ragged
+    trainer.flush()
     b = ray_sampler.get_all()
     n = b['ray_d'].shape[0]
     sizes = shard_sizes(n, world_size)
@@ -178,6 +179,7 @@ def save_checkpoint(path, trainer, global_step):
     """{net_m: state_dict (DDP-prefixed keys), optim_m: Adam state_dict}   ddp_train_nerf.py:642-652"""
     import torch
     from .model import state_dict_from_flat, adam_state_dict
+    trainer.flush()
     to_save = OrderedDict()
     for m, eng in enumerate(trainer.engines):
         to_save['net_%d' % m] = OrderedDict((k, v.clone().cpu()) for k, v in

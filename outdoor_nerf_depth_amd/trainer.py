@@ -53,7 +53,8 @@ class NerfppTrainer(object):
         self._ae_grad = [None] * len(self.engines)
         self.last_autoexpo = [None] * len(self.engines)
         self.comm_stream = torch.cuda.Stream(device=self.device) if (world_size > 1 and overlap_allreduce) else None
-        self._pending = None
+        self._pending = {}
+        self._late = None                 # last level whose all-reduce + Adam are finished at its next use
 
     # -- distributed -------------------------------------------------------------------------------
     def _allreduce_begin(self, m):
@@ -75,18 +76,26 @@ class NerfppTrainer(object):
             dist.all_reduce(self.grads[m])
             done = torch.cuda.Event()
             done.record()
-        self._pending = (m, done)
+        self._pending[m] = done
 
     def _allreduce_end(self, m):
-        if self._pending is not None and self._pending[0] == m:
-            torch.cuda.current_stream().wait_event(self._pending[1])
-            self._pending = None
+        done = self._pending.pop(m, None)
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
 
-    def _apply(self, m):
+    def flush(self):
+        """Finish the parameter update a multi-GPU step left in flight (the last level's all-reduce is
+        overlapped with the NEXT step's level-0 work).  Call before reading parameters: checkpoints,
+        rendering, end of a timed region."""
+        if self._late is not None:
+            self._apply(*self._late)
+            self._late = None
+
+    def _apply(self, m, step=None):
         self._allreduce_end(m)
         eng = self.engines[m]
-        ops.adam_step(eng.params, self.grads[m], self.exp_avg[m], self.exp_avg_sq[m], self.step_count,
-                      lr=self.lrate)
+        ops.adam_step(eng.params, self.grads[m], self.exp_avg[m], self.exp_avg_sq[m],
+                      self.step_count if step is None else step, lr=self.lrate)
         eng.repack()
         if self._ae_grad[m] is not None:
             self.autoexpo[m].apply(self._ae_grad[m][:, :2], self._ae_grad[m][:, 2] > 0)
@@ -118,6 +127,9 @@ class NerfppTrainer(object):
                 name = self.img_names[int(batch['frame'])]
             ae_idx = self.autoexpo[0].lookup(name)
         for m, eng in enumerate(self.engines):
+            if self._late is not None and self._late[0] == m:     # this level's update from the previous step
+                self._apply(*self._late)
+                self._late = None
             if m > 0:
                 u_fg = u['u_fg'] if 'u_fg' in u else torch.rand(n, S1, device=dev)
                 u_bg = u['u_bg'] if 'u_bg' in u else torch.rand(n, S1, device=dev)
@@ -144,8 +156,11 @@ class NerfppTrainer(object):
                 self._apply(deferred)
                 deferred = None
             self._allreduce_begin(m)
-            if self.world_size > 1 and self.comm_stream is not None and m + 1 < len(self.engines):
-                deferred = m                      # overlap this level's all-reduce with the next level
+            if self.world_size > 1 and self.comm_stream is not None:
+                if m + 1 < len(self.engines):
+                    deferred = m                  # overlap this level's all-reduce with the next level
+                else:
+                    self._late = (m, self.step_count)   # ... and the last level's with the next step's level 0
             else:
                 self._apply(m)
         return scalars

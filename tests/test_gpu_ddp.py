@@ -50,6 +50,7 @@ def _worker(rank, world, port, out_dir, overlap):
                        overlap_allreduce=overlap)
     for b, uni in _batches(rank):
         tr.train_step(_to_dev(b, dev), uniforms=_to_dev(uni, dev))
+    tr.flush()
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, 'params_rank%d.npy' % rank),
             np.stack([e.params.cpu().numpy() for e in tr.engines]))
