@@ -45,6 +45,7 @@ def parse():
     p.add_argument('--n_rand', type=int, default=1024, help='rays per GPU per step (reference forces 1024)')
     p.add_argument('--precision', choices=['both', 'bf16', 'split'], default='both')
     p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--large_batch', type=int, default=8192, help='also report this N_rand (0 = skip)')
     p.add_argument('--cpu_rays', type=int, default=128)
     return p.parse_args()
 
@@ -201,6 +202,8 @@ def main():
                for _ in range(args.steps + args.warmup)]
 
     res = {}
+    if world > 1 and args.precision == 'both':
+        args.precision = 'bf16'                  # the scaling runs measure the headline precision only
     if args.precision in ('both', 'bf16'):
         res['bf16'] = run_mode(args, L.PREC_BF16, rank, world, device, batches)
     if args.precision in ('both', 'split'):
@@ -229,6 +232,16 @@ def main():
         out['parity_mode'] = {'dtype': 'split-bf16 (hi+lo, 3 MFMA passes): the precision the 1e-4 parity tests use',
                               'value': s['value'], 'ms_per_step': s['ms_per_step'],
                               'roofline': roofline(s)}
+    if world == 1 and args.large_batch > 0 and main_key == 'bf16':
+        # "report at N_rand=1024 (reference value) and at the largest N_rand that fits, labelled"
+        import copy
+        a2 = copy.copy(args)
+        a2.n_rand, a2.steps, a2.warmup = args.large_batch, 5, 2
+        b2 = [batch_to_device(scene.random_batch(a2.n_rand, rng), device) for _ in range(a2.steps + a2.warmup)]
+        r2 = run_mode(a2, L.PREC_BF16, rank, world, device, b2)
+        out['large_batch'] = {'n_rand_per_gpu': a2.n_rand, 'value': r2['value'], 'unit': 'rays/s',
+                              'ms_per_step': r2['ms_per_step'], 'steps': a2.steps,
+                              'note': 'same workload at a larger ray batch than the 1024 of the reference (labelled, not the headline)'}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out))
