@@ -22,9 +22,9 @@ from outdoor_nerf_depth_amd.ddp_train_nerf import render_single_image, mse2psnr 
 from outdoor_nerf_depth_amd.trainer import NerfppTrainer                       # noqa: E402
 
 
-def run(prec, args, train, test, dev):
-    torch.manual_seed(777)
-    np.random.seed(777)
+def run(prec, args, train, test, dev, seed=777):
+    torch.manual_seed(seed)             # ray / uniform draws; the network init stays manual_seed(777) (model.py)
+    np.random.seed(seed)
     ds = DeviceRaySamplers(train, dev)
     tr = NerfppTrainer(dev, precision=prec, use_depth=True, depth_loss_type='mse', lambda_depth=0.1,
                        depth_scale=ds.depth_scale or 1.0)
@@ -56,6 +56,7 @@ def main():
     p.add_argument('--frames', type=int, default=40)
     p.add_argument('--n_rand', type=int, default=1024)
     p.add_argument('--evals', type=str, default='')
+    p.add_argument('--seeds', type=str, default='777', help='comma list: one training run per seed and precision')
     a = p.parse_args()
     a.eval_at = set(int(x) for x in a.evals.split(',') if x)
     H, W = [int(x) for x in a.hw.split(',')]
@@ -63,9 +64,23 @@ def main():
     train = synthetic_ray_samplers('train', 1, 'mono_crop', a.frames, H, W)
     test = synthetic_ray_samplers('test', 1, 'mono_crop', a.frames, H, W)
     out = {'config': {k: v for k, v in vars(a).items() if k != 'eval_at'}, 'n_train_frames': len(train), 'n_test_frames': len(test)}
-    out['split_bf16'] = run(L.PREC_SPLIT_BF16, a, train, test, dev)
-    out['bf16'] = run(L.PREC_BF16, a, train, test, dev)
-    out['psnr_gap_db'] = out['bf16']['psnr'] - out['split_bf16']['psnr']
+    seeds = [int(x) for x in a.seeds.split(',')]
+    if len(seeds) == 1:
+        out['split_bf16'] = run(L.PREC_SPLIT_BF16, a, train, test, dev, seeds[0])
+        out['bf16'] = run(L.PREC_BF16, a, train, test, dev, seeds[0])
+        out['psnr_gap_db'] = out['bf16']['psnr'] - out['split_bf16']['psnr']
+    else:
+        # several data-order seeds per precision: mean and standard error of the final held-out PSNR
+        runs = {'split_bf16': [run(L.PREC_SPLIT_BF16, a, train, test, dev, s) for s in seeds],
+                'bf16': [run(L.PREC_BF16, a, train, test, dev, s) for s in seeds]}
+        for k, rs in runs.items():
+            ps = np.array([r['psnr'] for r in rs])
+            out[k] = {'psnr_per_seed': ps.tolist(), 'psnr_mean': float(ps.mean()),
+                      'psnr_stderr': float(ps.std(ddof=1) / np.sqrt(len(ps))),
+                      'depth_rmse_m_mean': float(np.mean([r['depth_rmse_m'] for r in rs])),
+                      'it_per_s': float(np.mean([r['it_per_s'] for r in rs]))}
+        d = np.array(out['bf16']['psnr_per_seed']) - np.array(out['split_bf16']['psnr_per_seed'])
+        out['psnr_gap_db'] = {'mean': float(d.mean()), 'stderr': float(d.std(ddof=1) / np.sqrt(len(d))), 'seeds': seeds}
     print(json.dumps(out))
 
 
