@@ -84,6 +84,9 @@ struct WeightPipe {
     ++next_issue;
     slot_issue = slot_issue + 1 == NBUF ? 0 : slot_issue + 1;
     if (blk >= nblk) return;
+#ifdef NERFPP_DBG_NO_DMA
+    return;                                   // timing experiment only: no weight traffic (garbage results)
+#endif
     const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
     if constexpr (MODE == PIPE_ROLES) {
       if (wave != 0) return;                                   // the loader wave issues the whole block
