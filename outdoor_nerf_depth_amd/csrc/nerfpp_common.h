@@ -183,10 +183,10 @@ __host__ __device__ constexpr int gw_dz_tensor(int s) {
   return s < 8 ? T_DZ0 + s : s == FS_REMAP ? T_DR : s == FS_SIG ? T_DS : s == FS_RGB0 ? T_DG : T_DP;
 }
 
-struct DwJob {       // one 128x128 (or smaller) output tile of one weight-gradient GEMM
+struct DwJob {       // one weight-gradient GEMM: the whole (<= 256 x 256) output, contracted over a row slice
   int16_t a_tensor, b_tensor;     // dZ tensor, input tensor
   int16_t o0, i0;                 // first column in each tensor
-  int16_t n_o, n_i;               // valid columns (multiples of 32, <= 128)
+  int16_t n_o, n_i;               // valid columns (multiples of 32, <= 256)
   int32_t gw_off;                 // offset of element (o0, i_global0) in the slab
   int16_t gw_ld;                  // row stride of this stage's GW block
   int16_t gb_off;                 // offset of bias o0 in the slab's bias part, or -1

@@ -16,9 +16,12 @@
 //     16-lane group reads a [4 samples x 16 features] block and receives it transposed
 //     (lane = feature, 4 samples per lane).  Both operands use the same sample->slot map, so the
 //     contraction is exact whatever that map is.
-//   * 8 waves; wave (wo = w>>2, wi = w&3) owns out-blocks [4wo, 4wo+4) x in-blocks [2wi, 2wi+2):
-//     8 accumulators of 32x32 (128 VGPRs); double-buffered 32-row chunks, one barrier per chunk.
-//   * bias gradients: the A fragments of the wi == 0 waves are summed on the VALU.
+//   * 8 waves; full 256x256 jobs: wave (wo = w>>2, wi = w&3) owns out-blocks [4wo, 4wo+4) x in-blocks
+//     [2wi, 2wi+2), 8 accumulators of 32x32 (128 VGPRs); narrow jobs deal their blocks round-robin.
+//     32-row chunks through a 4-deep LDS ring (inline-asm DMA, counted vmcnt), one raw barrier per chunk.
+//   * the number of row slices is per job (dw_plan, nerfpp_common.h): every launch fills the 256 CUs
+//     once with workgroups that move about the same number of bytes.
+//   * bias gradients: VALU column sums of the A fragments, split over the waves that share them.
 // Rows beyond `rows` up to the next multiple of 32 are zero in every saved tensor (the MLP kernels
 // zero-fill their tile tails), so no masking is needed.
 #include <hip/hip_runtime.h>
@@ -45,8 +48,6 @@ constexpr JobTable build_jobs(bool full) {
   }
   return jt;
 }
-constexpr JobTable H_FULL = build_jobs(true);
-constexpr JobTable H_NARROW = build_jobs(false);
 __constant__ JobTable c_full = build_jobs(true);
 __constant__ JobTable c_narrow = build_jobs(false);
 
@@ -181,7 +182,6 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) 
   int nbo = job.n_o / 32 - 4 * wo, nbi = job.n_i / 32 - 2 * wi;       // valid blocks of this wave
   nbo = nbo < 0 ? 0 : (nbo > 4 ? 4 : nbo);
   nbi = nbi < 0 ? 0 : (nbi > 2 ? 2 : nbi);
-  const bool active = nbo > 0 && nbi > 0;
   const bool do_bias = job.gb_off >= 0 && wi < nbo;       // wave wi owns the bias of its out-block 4wo+wi
   f32x16 acc[4][2];
 #pragma unroll
@@ -291,8 +291,6 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) 
 }  // namespace nerfpp
 
 using namespace nerfpp;
-
-int dw_jobs_total() { return H_FULL.count[0] + H_FULL.count[1] + H_NARROW.count[0] + H_NARROW.count[1]; }
 
 namespace {
 // slices per job of one launch, in that launch's table order; the plan is indexed in build_all_jobs order

@@ -73,10 +73,8 @@ void launch_gather_rays(hipStream_t st, int n, int W, const float* cam, const in
 // nerfpp_mlp.hip
 void launch_mlp_fwd(hipStream_t st, int net, int P, bool train, const nerfpp::MlpFwdArgs& a);
 void launch_mlp_bwd(hipStream_t st, int net, int P, const nerfpp::MlpBwdArgs& a);
-int mlp_tile_rows(int P);
 // nerfpp_dw.hip
 void launch_dw(hipStream_t st, int P, const nerfpp::DwArgs& a);
-int dw_jobs_total();
 // nerfpp_optim.hip
 void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t* const* tbl, void* const* out,
                        const int64_t* n);

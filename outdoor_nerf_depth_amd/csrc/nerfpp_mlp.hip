@@ -1010,4 +1010,3 @@ void launch_mlp_bwd(hipStream_t st, int net, int P, const MlpBwdArgs& a) {
   if (net == 0) { if (P == 1) launch_bwd_t<0, 1>(st, a); else launch_bwd_t<0, 2>(st, a); }
   else          { if (P == 1) launch_bwd_t<1, 1>(st, a); else launch_bwd_t<1, 2>(st, a); }
 }
-int mlp_tile_rows(int P) { return MLP_WAVES(P) * 32; }
