@@ -46,6 +46,10 @@ def parse():
     p.add_argument('--precision', choices=['both', 'bf16', 'split'], default='both')
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--large_batch', type=int, default=8192, help='also report this N_rand (0 = skip)')
+    # BASELINE.json configs[1] by default (gt / mse / 0.1); configs[2] = mono_crop / kl, configs[3] = stereo_crop / l1
+    p.add_argument('--depth_sup_type', default='gt')
+    p.add_argument('--depth_loss_type', default='mse', choices=['mse', 'l1', 'kl'])
+    p.add_argument('--lambda_depth', type=float, default=0.1)
     p.add_argument('--cpu_rays', type=int, default=128)
     return p.parse_args()
 
@@ -56,7 +60,8 @@ def run_mode(args, precision, rank, world, device, batches):
     from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
 
     scale = float(SyntheticKitti().depth_scale)
-    tr = NerfppTrainer(device, precision=precision, use_depth=True, depth_loss_type='mse', lambda_depth=0.1,
+    tr = NerfppTrainer(device, precision=precision, use_depth=True, depth_loss_type=args.depth_loss_type,
+                       lambda_depth=args.lambda_depth,
                        depth_scale=scale, world_size=world)
     K, W = args.steps, args.warmup
     mk = lambda: torch.cuda.Event(enable_timing=True)
@@ -195,7 +200,7 @@ def main():
     from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
     from outdoor_nerf_depth_amd.trainer import batch_to_device
     from outdoor_nerf_depth_amd import _lib as L
-    scene = SyntheticKitti(depth_sup_type='gt')
+    scene = SyntheticKitti(depth_sup_type=args.depth_sup_type)
     rng = np.random.RandomState((rank + 1) * 777)                 # ddp_train_nerf.py:406
     torch.manual_seed((rank + 1) * 777)                           # :408
     batches = [batch_to_device(scene.random_batch(args.n_rand, rng), device)
@@ -220,9 +225,10 @@ def main():
         'dtype': 'bf16 MFMA operands, f32 accumulate / f32 master weights' if main_key == 'bf16'
                  else 'split-bf16 (hi+lo, 3 MFMA passes), f32 accumulate',
         'data': 'synthetic',
-        'config': {'workload': 'NeRF++ KITTI seq00-shaped (295 fr, 375x1242), depth_sup_type=gt, '
-                               'depth_loss_type=mse, lambda_depth=0.1, N_rand=%d rays/GPU/step, cascade 64+128, '
-                               'both levels fwd+bwd+Adam' % args.n_rand,
+        'config': {'workload': 'NeRF++ KITTI seq00-shaped (295 fr, 375x1242), depth_sup_type=%s, '
+                               'depth_loss_type=%s, lambda_depth=%g, N_rand=%d rays/GPU/step, cascade 64+128, '
+                               'both levels fwd+bwd+Adam' % (args.depth_sup_type, args.depth_loss_type,
+                                                             args.lambda_depth, args.n_rand),
                    'n_rand_per_gpu': args.n_rand, 'parallelism': 'dp%d (ray batches, RCCL grad all-reduce)' % world},
         'roofline': roofline(r),
         'final_loss': r['loss'],

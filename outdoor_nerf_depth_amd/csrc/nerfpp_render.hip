@@ -414,6 +414,39 @@ __device__ double block_sum(double v, double* sh) {
   return r;
 }
 
+// depth_kl (depth_loss.py:20-44) per-sample work, one wave per ray (coalesced over the samples):
+//   term[n,s] = -log(w + 1e-5) * exp(-(z - gt)^2 / (2 sigma)) * dists,   masked by 0 < gt < fg_far
+//   g_w[n,s]  = d(lambda * sum(term) / S) / d w   -- needs no global normaliser (the reference divides by S)
+// The per-ray sums go to ray_sum (the caller passes g_depth, which is all zeros for this loss type and is
+// overwritten by loss_kernel afterwards); loss_kernel adds them up in a fixed order.
+__global__ __launch_bounds__(256) void kl_terms_kernel(
+    int n, int S, float lambda_depth, float kl_sigma, const float* __restrict__ depth_sup,
+    const float* __restrict__ fg_weights, const float* __restrict__ fg_z, const float* __restrict__ fg_dists,
+    const float* __restrict__ fg_far, float* __restrict__ ray_sum, float* __restrict__ g_fg_weights) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + wave;
+  if (ray >= n) return;
+  const float gt = depth_sup[ray];
+  const bool m = gt > 0.f && gt < fg_far[ray];
+  const float inv2s = 1.f / (2.f * kl_sigma);
+  double acc = 0.0;
+  for (int s = lane; s < S; s += 64) {
+    const size_t i = (size_t)ray * S + s;
+    float g = 0.f;
+    if (m) {
+      const float dz = fg_z[i] - gt;
+      const float w = fg_weights[i] + 1e-5f;
+      const float e = expf(-(dz * dz) * inv2s);
+      acc += (double)(-logf(w) * e * fg_dists[i]);
+      g = -lambda_depth * e * fg_dists[i] / (w * (float)S);
+    }
+    g_fg_weights[i] = g;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane == 0) ray_sum[ray] = (float)acc;
+}
+
 __global__ __launch_bounds__(1024) void loss_kernel(
     int n, int S, int type, float lambda_depth, float kl_sigma, const float* __restrict__ rgb,
     const float* __restrict__ rgb_gt, const float* __restrict__ depth, const float* __restrict__ depth_sup,
@@ -422,7 +455,6 @@ __global__ __launch_bounds__(1024) void loss_kernel(
     float* __restrict__ g_depth, float* __restrict__ g_fg_weights) {
   __shared__ double sh[1024];
   double s_rgb = 0, s_dep = 0, s_cnt = 0;
-  const float inv2s = 1.f / (2.f * kl_sigma);
   for (int r = threadIdx.x; r < n; r += blockDim.x) {
     for (int c = 0; c < 3; ++c) {
       const float d = rgb[r * 3 + c] - rgb_gt[r * 3 + c];
@@ -434,11 +466,7 @@ __global__ __launch_bounds__(1024) void loss_kernel(
       const bool m = gt > 0.f && gt < fg_far[r];
       if (m) {
         s_cnt += 1;
-        for (int s = 0; s < S; ++s) {
-          const size_t i = (size_t)r * S + s;
-          const float dz = fg_z[i] - gt;
-          s_dep += (double)(-logf(fg_weights[i] + 1e-5f) * expf(-(dz * dz) * inv2s) * fg_dists[i]);
-        }
+        s_dep += (double)g_depth[r];             // per-ray sum left there by kl_terms_kernel
       }
     } else if (gt > 0.f) {
       const float d = gt - depth[r];
@@ -471,19 +499,8 @@ __global__ __launch_bounds__(1024) void loss_kernel(
       }
     }
     g_depth[r] = gd;
-    if (g_fg_weights) {
-      const float gt = type == 3 ? depth_sup[r] : 0.f;
-      const bool m = type == 3 && gt > 0.f && gt < fg_far[r];
-      for (int s = 0; s < S; ++s) {
-        const size_t i = (size_t)r * S + s;
-        float g = 0.f;
-        if (m) {
-          const float dz = fg_z[i] - gt;
-          g = -lambda_depth * expf(-(dz * dz) * inv2s) * fg_dists[i] / ((fg_weights[i] + 1e-5f) * (float)S);
-        }
-        g_fg_weights[i] = g;
-      }
-    }
+    if (g_fg_weights && type != 3)               // (KL: written by kl_terms_kernel)
+      for (int s = 0; s < S; ++s) g_fg_weights[(size_t)r * S + s] = 0.f;
   }
 }
 
@@ -543,6 +560,9 @@ void launch_loss(hipStream_t st, int n, int S, int type, float lambda_depth, flo
                  const float* rgb_gt, const float* depth, const float* depth_sup, const float* fg_weights,
                  const float* fg_z, const float* fg_dists, const float* fg_far, float* scalars, float* g_rgb,
                  float* g_depth, float* g_fg_weights) {
+  if (type == 3)
+    hipLaunchKernelGGL(kl_terms_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, S, lambda_depth, kl_sigma, depth_sup,
+                       fg_weights, fg_z, fg_dists, fg_far, g_depth, g_fg_weights);
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, st, n, S, type, lambda_depth, kl_sigma, rgb, rgb_gt,
                      depth, depth_sup, fg_weights, fg_z, fg_dists, fg_far, scalars, g_rgb, g_depth,
                      g_fg_weights);
