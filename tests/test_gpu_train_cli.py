@@ -16,7 +16,7 @@ def test_train_cli_checkpoint_resume_and_eval(tmp_path):
     base = ['--expname', 'run', '--basedir', str(tmp_path), '--synthetic', '--synthetic_hw', '24,32',
             '--synthetic_frames', '20', '--cascade_samples', '64,128', '--use_depth', '--depth_loss_type', 'kl',
             '--depth_sup_type', 'mono_crop', '--lambda_depth', '0.1', '--sample_every', '2', '--world_size', '1',
-            '--N_rand_override', '256', '--i_weights', '5', '--i_test', '5', '--testskip', '1', '--i_print', '1']
+            '--N_rand_override', '256', '--i_weights', '5', '--i_test', '5', '--testskip', '1', '--i_print', '1', '--host_sampling']
     args = T.config_parser().parse_args(base + ['--N_iters', '6'])
     T.validate_args(args)
     args.world_size = 1
