@@ -5,13 +5,13 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${1:-rXX}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout 400 python $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 10 --warmup 2 --no_cpu_baseline > $O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 10 --warmup 2 --no_cpu_baseline --large_batch 0 > $O/trace.log 2>&1
 DB=$(ls $O/trace/*/*.db | head -1)
 python $R/tools/rocpd_stats.py $DB > $O/kernel_stats.md
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace1 -- python $R/bench.py --steps 6 --warmup 2 --no_cpu_baseline --precision bf16 > $O/trace1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace1 -- python $R/bench.py --steps 6 --warmup 2 --no_cpu_baseline --large_batch 0 --precision bf16 > $O/trace1.log 2>&1
 python $R/tools/rocpd_timeline.py $(ls $O/trace1/*/*.db | head -1) > $O/timeline_bf16.md
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 1 --no_cpu_baseline --precision bf16 > $O/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 1 --no_cpu_baseline --large_batch 0 --precision bf16 > $O/pmc_$c.log 2>&1
   python $R/tools/rocpd_pmc.py $(ls $O/pmc_$c/*/*.db | head -1) _kernel >> $O/hbm_traffic.txt 2>&1
 done
 rm -rf $O/trace $O/trace1 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
