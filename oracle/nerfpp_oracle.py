@@ -514,6 +514,25 @@ def loss_and_grads(ret, fg_z_vals, fg_far_depth, rgb_gt, depth_sup, use_depth, d
 # --------------------------------------------------------------------------------------
 # a15  Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay)
 # --------------------------------------------------------------------------------------
+def autoexpo_loss_and_grads(rgb, rgb_gt, p, lambda_autoexpo):
+    """--optim_autoexpo (ddp_model.py:186-190, ddp_train_nerf.py:472-479): p = the image's parameter
+    [p0, p1]; scale = |p0| + 0.5, shift = p1; rgb_pred = (rgb - shift) / scale;
+    rgb_loss = img2mse(rgb_pred, rgb_gt); loss = rgb_loss + lambda * (|scale - 1| + |shift|).
+    Returns (loss without the depth term, rgb_loss, scale, shift, d loss / d rgb [N,3], d loss / d p [2])."""
+    rgb, rgb_gt = np.asarray(rgb, f32), np.asarray(rgb_gt, f32)
+    p = np.asarray(p, f32)
+    scale, shift = f32(np.abs(p[0]) + f32(0.5)), p[1]
+    pred = (rgb - shift) / scale
+    rgb_loss = img2mse(pred, rgb_gt)
+    reg = f32(lambda_autoexpo) * (np.abs(scale - f32(1.)) + np.abs(shift))
+    r = (pred - rgb_gt) * f32(2.0 / rgb.size)                      # d rgb_loss / d pred
+    g_rgb = (r / scale).astype(f32)
+    d_scale = -(r * pred).sum(dtype=np.float64) / scale + lambda_autoexpo * np.sign(scale - f32(1.))
+    d_shift = -r.sum(dtype=np.float64) / scale + lambda_autoexpo * np.sign(shift)
+    g_p = np.array([d_scale * np.sign(p[0]), d_shift], f32)
+    return f32(rgb_loss + reg), rgb_loss, scale, shift, g_rgb, g_p
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8):
     """In-place torch.optim.Adam single-tensor update, `step` is the 1-based step count."""
     grad = np.asarray(grad, f32)

@@ -239,3 +239,20 @@ def test_ddp_two_rank_average(golden):
         mine = (acc[k] / 2).reshape(-1)[g['avg.%s.idx' % k]]
         ref = g['avg.%s.g' % k]
         assert np.abs(mine - ref).max() <= 5e-2 * g['avg.%s.rms' % k] + 1e-12, k
+
+
+def test_autoexposure_loss_and_param_grads(golden):
+    """a11: the oracle's restatement of ddp_train_nerf.py:472-479 against 4 reference steps."""
+    g = golden('autoexpo')
+    lam, lam_d = float(g['lambda_autoexpo']), float(g['lambda_depth'])
+    params = np.tile(np.array([0.5, 0.0], np.float32), (3, 1))
+    for step in range(1, 5):
+        img = int(g['s%d.img' % step])
+        loss, rgb_loss, scale, shift, g_rgb, g_p = O.autoexpo_loss_and_grads(g['s%d.ret_rgb' % step], g['s%d.rgb' % step],
+                                                                          params[img], lam)
+        np.testing.assert_allclose(scale, g['s%d.scale' % step], rtol=1e-6)
+        np.testing.assert_allclose(shift, g['s%d.shift' % step], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(rgb_loss, g['s%d.rgb_loss' % step], rtol=1e-5)
+        np.testing.assert_allclose(loss + lam_d * g['s%d.depth_loss' % step], g['s%d.loss' % step], rtol=1e-5)
+        np.testing.assert_allclose(g_p, g['s%d.grad' % step], rtol=2e-4, atol=1e-7)
+        params = g['s%d.params_after' % step].copy()          # the reference's own Adam result feeds the next step
