@@ -333,12 +333,19 @@ __device__ __forceinline__ void lds_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 // NERFPP_DBG (diagnostic builds only): bit 0 drops the activation stores, bit 1 the
-// LDS transposes too, bit 2 uses plain instead of non-temporal stores
+// LDS transposes too, bit 2 uses plain instead of non-temporal stores, bit 4 drops the loader hand-off,
+// bit 5 folds every activation store into a 2 MiB window of out_raw (forward kernel; no HBM write traffic)
 #ifndef NERFPP_DBG
 #define NERFPP_DBG 0
 #endif
+#if (NERFPP_DBG & 32)
+__device__ char* dbg_sink;      // timing experiment: every activation store folded into a 2 MiB window of out_raw
+#endif
 __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
   if constexpr ((NERFPP_DBG & 1) != 0) return;
+#if (NERFPP_DBG & 32)
+  gptr = dbg_sink + ((uintptr_t)gptr & 0x1FFFF0);
+#endif
   if constexpr ((NERFPP_DBG & 4) != 0) { *(uint4*)gptr = v; return; }                                     // plain (temporal) store
   const u32x4 vv = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(vv, (u32x4*)gptr);
@@ -659,6 +666,10 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;          // this wave's first tile row
   const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
+#if (NERFPP_DBG & 32)
+  if (threadIdx.x == 0) dbg_sink = (char*)a.out_raw;
+  __syncthreads();
+#endif
   const bool tail = wrow0 + 32 > (size_t)a.rows;                            // wave-uniform
   char* region = smem + LD::REGION;
   char* stage = loader ? region : smem + LD::STAGE + wave * stage_bytes<PC>();   // the loader never stages
