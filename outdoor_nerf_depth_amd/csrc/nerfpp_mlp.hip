@@ -334,7 +334,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 }
 // NERFPP_DBG (diagnostic builds only): bit 0 drops the activation stores, bit 1 the
 // LDS transposes too, bit 2 uses plain instead of non-temporal stores, bit 4 drops the loader hand-off,
-// bit 5 folds every activation store into a 2 MiB window of out_raw (forward kernel; no HBM write traffic)
+// bit 5 folds every activation store into a 2 MiB window of out_raw (forward kernel; no HBM write traffic),
+// bit 6 keeps the LDS reads and address math of the saves but drops the store instructions
 #ifndef NERFPP_DBG
 #define NERFPP_DBG 0
 #endif
@@ -345,6 +346,10 @@ __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
   if constexpr ((NERFPP_DBG & 1) != 0) return;
 #if (NERFPP_DBG & 32)
   gptr = dbg_sink + ((uintptr_t)gptr & 0x1FFFF0);
+#endif
+#if (NERFPP_DBG & 64)
+  asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(gptr));   // keep the LDS reads + address math, drop the store
+  return;
 #endif
   if constexpr ((NERFPP_DBG & 4) != 0) { *(uint4*)gptr = v; return; }                                     // plain (temporal) store
   const u32x4 vv = {v.x, v.y, v.z, v.w};
