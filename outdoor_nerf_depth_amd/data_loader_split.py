@@ -30,6 +30,14 @@ def _imread(path):
     return np.array(Image.open(path))
 
 
+def _imread_resized(path, W, H, nearest):
+    from PIL import Image
+    im = Image.open(path)
+    if im.size != (W, H):
+        im = im.resize((W, H), Image.NEAREST if nearest else Image.BILINEAR)
+    return np.array(im)
+
+
 def get_rays_single_image(H, W, intrinsics, c2w):
     """nerf_sample_ray_split.py:10-34 (half-pixel centres, un-normalised directions)."""
     u, v = np.meshgrid(np.arange(W), np.arange(H))
@@ -48,7 +56,8 @@ class RaySamplerSingleImage(object):
     reference's keys (nerf_sample_ray_split.py:131-221)."""
 
     def __init__(self, H, W, intrinsics, c2w, img_path=None, depth_gt_path=None, depth_sup_path=None,
-                 depth_scale=None, img=None, depth_gt=None, depth_sup=None):
+                 depth_scale=None, img=None, depth_gt=None, depth_sup=None, mask_path=None, min_depth_path=None,
+                 max_depth=None):
         self.H, self.W = H, W
         self.intrinsics, self.c2w_mat = intrinsics, c2w
         self.img_path, self.depth_gt_path, self.depth_sup_path = img_path, depth_gt_path, depth_sup_path
@@ -63,6 +72,15 @@ class RaySamplerSingleImage(object):
             self.depth_gt = depth_scale * (_imread(depth_gt_path).astype(np.float32) / 256.0).reshape((-1))
         if depth_sup_path is not None:
             self.depth_sup = depth_scale * (_imread(depth_sup_path).astype(np.float32) / 256.0).reshape((-1))
+        # optional per-pixel mask / near bound (nerf_sample_ray_split.py:81-92): mask = png / 255 (nearest),
+        # min_depth = png / 255 * max_depth + 1e-4 (bilinear; PIL here, cv2 upstream -- only differs when the
+        # file is not already H x W)
+        self.mask = self.min_depth = None
+        if mask_path is not None:
+            self.mask = _imread_resized(mask_path, W, H, nearest=True).astype(np.float32).reshape((-1)) / 255.
+        if min_depth_path is not None:
+            self.min_depth = (_imread_resized(min_depth_path, W, H, nearest=False).astype(np.float32) / 255. *
+                              max_depth + 1e-4).reshape((-1)).astype(np.float32)
         self.rays_o, self.rays_d, self.depth = get_rays_single_image(H, W, intrinsics, c2w)
 
     def get_img(self):
@@ -77,7 +95,9 @@ class RaySamplerSingleImage(object):
     def _select(self, idx):
         ret = OrderedDict([('ray_o', self.rays_o[idx]), ('ray_d', self.rays_d[idx]), ('depth', self.depth[idx]),
                            ('rgb', None if self.img is None else self.img[idx]),
-                           ('min_depth', 1e-4 * np.ones_like(self.rays_d[idx][..., 0]))])
+                           ('mask', None if self.mask is None else self.mask[idx]),
+                           ('min_depth', self.min_depth[idx] if self.min_depth is not None
+                            else 1e-4 * np.ones_like(self.rays_d[idx][..., 0]))])
         if self.depth_gt is not None:
             ret['depth_gt'] = self.depth_gt[idx]
         if self.depth_sup is not None:
@@ -123,12 +143,23 @@ def load_data_split(basedir, scene, split, skip=1, try_load_min_depth=True, only
     depth_sup_files = find_files('{}/depth{}'.format(split_dir, suffix), exts=['*.png', '*.jpg'])
     depth_sup_files = depth_sup_files[::skip] if depth_sup_files else [None] * cam_cnt
     assert len(depth_sup_files) == cam_cnt
+    mask_files = find_files('{}/mask'.format(split_dir), exts=['*.png', '*.jpg'])
+    mask_files = mask_files[::skip] if mask_files else [None] * cam_cnt
+    assert len(mask_files) == cam_cnt
+    mindepth_files = find_files('{}/min_depth'.format(split_dir), exts=['*.png', '*.jpg'])
+    mindepth_files = mindepth_files[::skip] if (try_load_min_depth and mindepth_files) else [None] * cam_cnt
+    assert len(mindepth_files) == cam_cnt
+    try:                                                                      # data_loader_split.py:111-114
+        max_depth = float(open('{}/max_depth.txt'.format(split_dir)).readline().strip())
+    except Exception:
+        max_depth = None
     train_imgfile = find_files('{}/{}/train/rgb'.format(basedir, scene), exts=['*.png', '*.jpg'])[0]
     H, W = _imread(train_imgfile).shape[:2]
     return [RaySamplerSingleImage(H=H, W=W, intrinsics=parse_txt(intrinsics_files[i]), c2w=parse_txt(pose_files[i]),
                                   img_path=img_files[i], depth_gt_path=depth_gt_files[i],
                                   depth_sup_path=depth_sup_files[i] if depth_scale is not None else None,
-                                  depth_scale=depth_scale) for i in range(cam_cnt)]
+                                  depth_scale=depth_scale, mask_path=mask_files[i], min_depth_path=mindepth_files[i],
+                                  max_depth=max_depth) for i in range(cam_cnt)]
 
 
 def synthetic_ray_samplers(split, skip=1, depth_sup_type='gt', n_frames=295, H=None, W=None):

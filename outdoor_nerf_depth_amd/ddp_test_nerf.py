@@ -50,7 +50,7 @@ def ddp_test_nerf(rank, args):
                                               hw[0], hw[1])
         else:
             samplers = load_data_split(args.datadir, args.scene, split, skip=args.testskip,
-                                       depth_sup_type=args.depth_sup_type)
+                                       try_load_min_depth=args.load_min_depth, depth_sup_type=args.depth_sup_type)
         psnrs, rmses, abs_rels = [], [], []
         for idx, sampler in enumerate(samplers):
             ret = render_single_image(rank, world, trainer, sampler, args.chunk_size)

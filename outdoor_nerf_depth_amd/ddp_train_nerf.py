@@ -290,9 +290,9 @@ def ddp_train_nerf(rank, args):
                                                   args.synthetic_frames, hw[0], hw[1])
     else:
         ray_samplers = load_data_split(args.datadir, args.scene, split='train', skip=args.trainskip,
-                                       depth_sup_type=args.depth_sup_type)
+                                       try_load_min_depth=args.load_min_depth, depth_sup_type=args.depth_sup_type)
         val_ray_samplers = load_data_split(args.datadir, args.scene, split='test', skip=args.testskip,
-                                           depth_sup_type=args.depth_sup_type)
+                                           try_load_min_depth=args.load_min_depth, depth_sup_type=args.depth_sup_type)
     depth_scale = ray_samplers[0].get_depth_scale() or 1.0
     img_names = None
     if args.optim_autoexpo:                       # :394-399 (written before the nets need it, unlike upstream)

@@ -38,6 +38,11 @@ class DeviceRaySamplers(object):
             self.depth_sup = torch.stack([torch.from_numpy(np.ascontiguousarray(s.depth_sup, np.float32))
                                           for s in ray_samplers]).to(self.device)      # [F, H*W]
         self.depth_scale = s0.get_depth_scale()
+        # optional per-pixel near bound (min_depth/ pngs): gathered with torch indexing after the kernel
+        self.min_depth = None
+        if getattr(s0, 'min_depth', None) is not None:
+            self.min_depth = torch.stack([torch.from_numpy(np.ascontiguousarray(s.min_depth, np.float32))
+                                          for s in ray_samplers]).to(self.device)      # [F, H*W]
 
     def gather(self, frame, pix):
         """Ray batch of `frame` at the flat pixel indices `pix` (int64 device tensor)."""
@@ -56,6 +61,8 @@ class DeviceRaySamplers(object):
                                            p(self.cams[frame]), p(pix), p(rgb_img), p(dep_img), p(out['ray_o']),
                                            p(out['ray_d']), p(out.get('rgb')), p(out.get('depth_sup')),
                                            p(out['min_depth'])), 'nerfpp_gather_rays')
+        if self.min_depth is not None:
+            out['min_depth'] = self.min_depth[frame][pix]
         if 'depth_sup' in out:
             out['depth_gt'] = out['depth_sup']
         return out

@@ -115,6 +115,22 @@ def test_ray_generation_and_dataset_reader(golden, tmp_path):
     np.testing.assert_allclose(full['ray_d'], g['rays_d'], rtol=1e-5, atol=1e-6)
     raw = np.array(Image.open(root / 'train' / 'depth' / '000.png')).astype(np.float32).reshape(-1)
     np.testing.assert_allclose(full['depth_gt'], 0.005 * raw / 256.0, rtol=1e-6)
+    assert full['mask'] is None                                   # key present like upstream, no mask/ dir
+    # optional mask/ and min_depth/ (+ max_depth.txt): nerf_sample_ray_split.py:81-92, data_loader_split.py:72-75,111-114
+    for sub in ('mask', 'min_depth'):
+        os.makedirs(root / 'train' / sub)
+    md = rs.randint(0, 255, (4, 6), dtype=np.uint8)
+    mk = (rs.rand(4, 6) > 0.5).astype(np.uint8) * 255
+    for i in range(3):
+        Image.fromarray(md).save(root / 'train' / 'min_depth' / ('%03d.png' % i))
+        Image.fromarray(mk).save(root / 'train' / 'mask' / ('%03d.png' % i))
+    (root / 'train' / 'max_depth.txt').write_text('2.5\n')
+    s2 = DL.load_data_split(str(tmp_path / 'data'), 'scene', 'train', skip=1, depth_sup_type='mono_crop')
+    full = s2[1].get_all()
+    np.testing.assert_allclose(full['min_depth'], md.reshape(-1).astype(np.float32) / 255. * 2.5 + 1e-4, rtol=1e-6)
+    np.testing.assert_array_equal(full['mask'], mk.reshape(-1).astype(np.float32) / 255.)
+    s3 = DL.load_data_split(str(tmp_path / 'data'), 'scene', 'train', try_load_min_depth=False, depth_sup_type='mono_crop')
+    assert np.all(s3[0].get_all()['min_depth'] == np.float32(1e-4))
 
 
 def test_shard_sizes_ragged_and_reference_behaviour():
