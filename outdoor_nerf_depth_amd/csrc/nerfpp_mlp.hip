@@ -629,12 +629,12 @@ __device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P>
 // LDS carve-up shared by kernel and launcher
 template <int NET, int P, int NW, bool TRAIN>
 struct FwdLds {
-  static constexpr int MODE = !TRAIN ? (P == 1 ? PIPE_RING : PIPE_CLASSIC) : (P == 1 ? PIPE_ROLES : PIPE_CLASSIC);
+  static constexpr int MODE = !TRAIN ? PIPE_RING : (P == 1 ? PIPE_ROLES : PIPE_CLASSIC);
   static constexpr bool ROLES = MODE == PIPE_ROLES;
   static constexpr bool BIAS_LDS = MODE != PIPE_CLASSIC;
   static constexpr int PC = ROLES ? 4 : 8;                                   // staging pass width (chunks)
   // ring depth: as deep as the 160 KiB of LDS allow (the background net's wider encoding costs a slot)
-  static constexpr int NBUF = MODE == PIPE_CLASSIC ? 2 : MODE == PIPE_RING ? 4 : (NET == 0 ? 4 : 3);
+  static constexpr int NBUF = MODE == PIPE_CLASSIC ? 2 : MODE == PIPE_RING ? (P == 1 ? 4 : 3) : (NET == 0 ? 4 : 3);
   static constexpr int W = NBUF * BLK_FRAGS * P * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STAGE = REGION + (ROLES ? REGION_BYTES : 0);
