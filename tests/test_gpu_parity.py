@@ -124,6 +124,28 @@ def test_sample_fine_merge_sorted_and_matches_oracle(ops, golden):
     np.testing.assert_array_equal(N(bg_d), N(ops.sample_fine(T(g['bg_z0']), T(g['L0.bg_weights']), 128, det=True)))
 
 
+@pytest.mark.parametrize('n_rays,S_old,n_new', [(1, 64, 128), (7, 64, 128), (5, 33, 17), (9, 100, 156)])
+def test_sample_fine_ragged_shapes_bit_exact(ops, n_rays, S_old, n_new):
+    """ray counts that do not fill a 4-ray block, sample counts that are not multiples of 64: the fused
+    mids -> sample_pdf -> merge kernel against the oracle, bit for bit, single and paired launches."""
+    rs = np.random.RandomState(n_rays * 1000 + S_old)
+    z = np.sort(rs.rand(n_rays, S_old).astype(np.float32) * 3 + 0.1, axis=-1)
+    w = (rs.rand(n_rays, S_old).astype(np.float32) ** 4)
+    w[:, ::7] = 0
+    u = rs.rand(n_rays, n_new).astype(np.float32)
+    m_o, s_o, a_o = O.fine_depths(z, w, u)
+    merged, samples, above = ops.sample_fine(T(z), T(w), n_new, u=T(u), return_all=True)
+    np.testing.assert_array_equal(N(above), a_o)
+    np.testing.assert_array_equal(N(samples), s_o)
+    np.testing.assert_array_equal(N(merged), m_o)
+    z2 = np.sort(rs.rand(n_rays, S_old).astype(np.float32), axis=-1)
+    w2 = rs.rand(n_rays, S_old).astype(np.float32)
+    u2 = rs.rand(n_rays, n_new).astype(np.float32)
+    a, b = ops.sample_fine_pair(T(z), T(w), T(z2), T(w2), n_new, u_fg=T(u), u_bg=T(u2))
+    np.testing.assert_array_equal(N(a), m_o)
+    np.testing.assert_array_equal(N(b), O.fine_depths(z2, w2, u2)[0])
+
+
 # ----------------------------------------------------------------------------------------- forward
 RET_TOL = {2: dict(rtol=1e-4, atol=2e-6), 1: dict(rtol=3e-2, atol=3e-3)}
 
