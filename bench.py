@@ -108,7 +108,7 @@ def run_mode(args, precision, rank, world, device, batches):
     fwd_ms = med([events[i][1]['fwd'][0].elapsed_time(events[i][1]['fwd'][1]) for i in tapped])
     bwd_ms = med([events[i][1]['bwd'][0].elapsed_time(events[i][1]['bwd'][1]) for i in tapped])
     dw_ms = med([events[i][1]['bwd'][2].elapsed_time(events[i][1]['bwd'][3]) for i in tapped])
-    P = 1 if precision == 1 else 2
+    P = 2 if precision == 2 else 1            # precision of the backward kernels / saved planes the dW GEMM reads
     kernels = {
         'mlp_fwd_fg_L1': dict(ms=fwd_ms, flop=2.0 * ALGO_MACS['fwd'][0] * rows, bound='mfma'),
         'mlp_bwd_fg_L1': dict(ms=bwd_ms, flop=2.0 * ALGO_MACS['dx'][0] * rows, bound='mfma'),
@@ -235,6 +235,11 @@ def main():
         'roofline': roofline(r),
         'final_loss': r['loss'],
     }
+    if world == 1 and args.precision == 'both':
+        # split-bf16 forward (rendered RGB / depth / loss within 1e-4 of float32) + bf16 backward over its hi planes
+        h = run_mode(args, L.PREC_SPLIT_FWD, rank, world, device, batches)
+        out['parity_forward_mode'] = {'dtype': 'split-bf16 forward (outputs and loss at 1e-4), bf16 backward / weight gradients',
+                                      'value': h['value'], 'ms_per_step': h['ms_per_step']}
     if 'split' in res and main_key != 'split':
         s = res['split']
         out['parity_mode'] = {'dtype': 'split-bf16 (hi+lo, 3 MFMA passes): the precision the 1e-4 parity tests use',

@@ -165,7 +165,10 @@ int nerfpp_loss(void* stream, int n_rays, int n_samples, int loss_type, float la
 
 typedef struct {
   int32_t n_rays, n_samples;
-  int32_t precision, reserved;
+  int32_t precision;               /* of the backward kernels and of `packed` */
+  int32_t workspace_precision;     /* precision of the forward that filled `workspace`; 0 = same as
+                                      `precision`.  2 with precision 1: split-bf16 forward (1e-4 outputs and
+                                      loss), single-pass bf16 backward over the hi planes it saved */
   const float* ray_d;
   const float* fg_far;
   const float* fg_z;

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hi
 
 OK = 0
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2
+PREC_SPLIT_FWD = 3        # host-side combination: split-bf16 forward, bf16 backward (ops.LevelEngine)
 LOSS_RGB_ONLY, LOSS_MSE, LOSS_L1, LOSS_KL = 0, 1, 2, 3
 LOSS_TYPES = {'rgbonly': LOSS_RGB_ONLY, 'mse': LOSS_MSE, 'l1': LOSS_L1, 'kl': LOSS_KL}
 FG_PARAMS, BG_PARAMS, LEVEL_PARAMS = 595844, 606596, 1202440
@@ -32,7 +33,7 @@ class ForwardArgs(C.Structure):
 
 class BackwardArgs(C.Structure):
     _fields_ = [('n_rays', C.c_int32), ('n_samples', C.c_int32), ('precision', C.c_int32),
-                ('reserved', C.c_int32)] + \
+                ('workspace_precision', C.c_int32)] + \
                [(k, _fp) for k in ('ray_d', 'fg_far', 'fg_z', 'bg_z', 'packed', 'workspace', 'tables',
                                    'g_rgb', 'g_depth', 'g_fg_weights')] + \
                [('grad_scale', C.c_float), ('grads', _fp)] + \

@@ -281,7 +281,9 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   REQUIRE(a->g_rgb && a->g_depth && a->grads && a->params, "gradients / params");
   hipStream_t st = (hipStream_t)stream;
   const int P = a->precision;
-  const WsLayout L = ws_layout(a->n_rays, a->n_samples, P, true);
+  const int WP = a->workspace_precision ? a->workspace_precision : P;     // precision of the forward's saves
+  REQUIRE(prec_ok(WP) && WP >= P, "workspace_precision must be 0, or >= precision");
+  const WsLayout L = ws_layout(a->n_rays, a->n_samples, WP, true);
   const PackLayout PL = pack_layout(P);
   const TblLayout T = tbl_layout();
   char* ws = (char*)a->workspace;

@@ -33,7 +33,7 @@ def ddp_test_nerf(rank, args):
         os.environ['MASTER_PORT'] = str(args.port)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
-    trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,
+    trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,   # forward only
                             cascade_samples=cascade, use_depth=False, world_size=1)
     ckpt, start = find_latest_checkpoint(args)
     if ckpt is None:

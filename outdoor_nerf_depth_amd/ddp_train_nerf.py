@@ -110,8 +110,9 @@ def config_parser():
     p.add_argument('--depth_sigma', type=float, default=0.01)
     p.add_argument('--port', type=int, default=12345)
     # --- additions of this implementation
-    p.add_argument('--precision', choices=['bf16', 'split'], default='split',
-                   help='MLP arithmetic: single-pass bf16 MFMA or split-bf16 (1e-4 parity with float32)')
+    p.add_argument('--precision', choices=['bf16', 'split', 'split_fwd'], default='split',
+                   help='MLP arithmetic: single-pass bf16 MFMA, split-bf16 (1e-4 parity with float32), or split_fwd = '
+                        'split-bf16 forward (rendered outputs and loss at 1e-4) with the bf16 backward')
     p.add_argument('--synthetic', action='store_true', help='KITTI-shaped procedural scene, no datadir')
     p.add_argument('--synthetic_hw', type=str, default=None, help="'H,W' of the synthetic frames (default 375,1242)")
     p.add_argument('--synthetic_frames', type=int, default=295)
@@ -310,7 +311,7 @@ def ddp_train_nerf(rank, args):
             logger.info('frames of different sizes: falling back to host-side ray sampling')
 
     cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
-    trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,
+    trainer = NerfppTrainer(device, precision={'bf16': L.PREC_BF16, 'split': L.PREC_SPLIT_BF16, 'split_fwd': L.PREC_SPLIT_FWD}[args.precision],
                             cascade_samples=cascade, lrate=args.lrate, use_depth=args.use_depth,
                             depth_loss_type=args.depth_loss_type, lambda_depth=args.lambda_depth,
                             depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world,

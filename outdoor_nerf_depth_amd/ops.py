@@ -167,14 +167,20 @@ class LevelEngine(object):
     NerfNet.parameters() order, their packed MFMA streams, and the forward / backward calls."""
 
     def __init__(self, params_flat, precision=L.PREC_SPLIT_BF16):
+        """precision: PREC_BF16, PREC_SPLIT_BF16, or PREC_SPLIT_FWD = split-bf16 forward (rendered outputs
+        and loss within 1e-4 of float32) with the single-pass bf16 backward over the hi planes it saved."""
         if params_flat.numel() != L.LEVEL_PARAMS:
             raise L.NerfppError('expected %d parameters, got %d' % (L.LEVEL_PARAMS, params_flat.numel()))
         self.params = _f32(params_flat)
         self.device = self.params.device
-        self.precision = int(precision)
+        precision = int(precision)
+        self.precision = L.PREC_SPLIT_BF16 if precision == L.PREC_SPLIT_FWD else precision        # forward
+        self.bwd_precision = L.PREC_BF16 if precision == L.PREC_SPLIT_FWD else precision
         self.tables = level_tables(self.device)
         self.packed = torch.empty(L.lib().nerfpp_packed_bytes(self.precision), dtype=torch.uint8,
                                   device=self.device)
+        self.packed_bwd = self.packed if self.bwd_precision == self.precision else \
+            torch.empty(L.lib().nerfpp_packed_bytes(self.bwd_precision), dtype=torch.uint8, device=self.device)
         self.workspace = None
         self._fwd = None
         self.repack()
@@ -183,6 +189,9 @@ class LevelEngine(object):
         """Re-derive the bf16 weight streams from the float32 master parameters (after Adam)."""
         L.check(L.lib().nerfpp_pack_level(_stream(), self.precision, _p(self.params), _p(self.tables),
                                           _p(self.packed)), 'nerfpp_pack_level')
+        if self.packed_bwd is not self.packed:
+            L.check(L.lib().nerfpp_pack_level(_stream(), self.bwd_precision, _p(self.params), _p(self.tables),
+                                              _p(self.packed_bwd)), 'nerfpp_pack_level')
 
     def _workspace(self, n, S, training):
         need = L.lib().nerfpp_workspace_bytes(n, S, self.precision, int(training))
@@ -230,9 +239,10 @@ class LevelEngine(object):
         g_fg_weights = _f32(g_fg_weights, (n, S)) if g_fg_weights is not None else None
         grads = out if out is not None else torch.empty(L.LEVEL_PARAMS, device=self.device)
         a = L.BackwardArgs()
-        a.n_rays, a.n_samples, a.precision = n, S, self.precision
+        a.n_rays, a.n_samples, a.precision = n, S, self.bwd_precision
+        a.workspace_precision = self.precision
         a.ray_d, a.fg_far, a.fg_z, a.bg_z = [t.data_ptr() for t in (ray_d, fg_far, fg_z, bg_z)]
-        a.packed, a.workspace, a.tables = self.packed.data_ptr(), self.workspace.data_ptr(), self.tables.data_ptr()
+        a.packed, a.workspace, a.tables = self.packed_bwd.data_ptr(), self.workspace.data_ptr(), self.tables.data_ptr()
         a.g_rgb, a.g_depth = g_rgb.data_ptr(), g_depth.data_ptr()
         a.g_fg_weights = g_fg_weights.data_ptr() if g_fg_weights is not None else None
         a.grad_scale = float(grad_scale)

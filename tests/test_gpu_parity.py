@@ -427,3 +427,30 @@ def test_autoexposure_training_steps_match_reference(ops, golden):
         np.testing.assert_allclose(N(tr.autoexpo[0].params), g['s%d.params_after' % step], rtol=2e-4, atol=2e-7)
     w = state_dict_from_flat(tr.engines[0].params)['module.nerf_net.fg_net.rgb_layers.2.weight']
     np.testing.assert_allclose(N(w), g['final.fg_rgb2_weight'], rtol=0, atol=2e-4)
+
+
+def test_split_forward_bf16_backward_mode(ops, golden, levels):
+    """PREC_SPLIT_FWD: the forward is the split-bf16 one bit for bit (so rendered outputs and loss keep the
+    1e-4 contract); the backward is the single-pass bf16 chain over the hi planes it saved (bf16-mode
+    gradient bounds against the float64 reference run)."""
+    from outdoor_nerf_depth_amd import _lib as L
+    g = golden('grads_mse')
+    for m in range(2):
+        fz, bz = g['L%d.fg_z' % m], g['L%d.bg_z' % m]
+        e_split = ops.LevelEngine(T(flat(levels[m])), precision=2)
+        e_hyb = ops.LevelEngine(T(flat(levels[m])), precision=L.PREC_SPLIT_FWD)
+        e_bf16 = ops.LevelEngine(T(flat(levels[m])), precision=1)
+        args = (T(g['ray_o']), T(g['ray_d']), T(g['fg_far']), T(fz), T(bz))
+        r_s, r_h = e_split.forward(*args, training=True), e_hyb.forward(*args, training=True)
+        for k in r_s:
+            assert torch.equal(r_s[k], r_h[k]), k
+        sc, g_rgb, g_depth, g_w = ops.loss_and_grads(r_h, T(g['rgb_gt']), T(g['depth_sup']), 'mse', 0.1)
+        gh = unflat(N(e_hyb.backward(g_rgb, g_depth, g_w)))
+        e_bf16.forward(*args, training=True)
+        gb = unflat(N(e_bf16.backward(g_rgb, g_depth, g_w)))
+        for k in O.param_order():
+            ref = g['L%d.%s.g64' % (m, k)] if ('L%d.%s.g64' % (m, k)) in g else None
+            # same upstream gradients, same masks up to bf16 sign flips: the two bf16 backward results agree closely
+            rel = np.linalg.norm(gh[k] - gb[k]) / (np.linalg.norm(gb[k]) + 1e-30)
+            assert rel <= 0.3, (m, k, rel)
+            assert np.isfinite(gh[k]).all()
