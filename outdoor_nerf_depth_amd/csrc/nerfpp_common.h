@@ -196,7 +196,7 @@ struct DwJob {       // one weight-gradient GEMM: the whole (<= 256 x 256) outpu
   int32_t gw_off2;
 };
 constexpr int DW_JOBS = 12;                  // per net (build_all_jobs order)
-constexpr int DW_KMAX = 32;                  // slabs allocated per net; a job uses the first k_job of them
+constexpr int DW_KMAX = 48;                  // slabs allocated per net; a job uses the first k_job of them
 
 struct JobTable {
   DwJob jobs[N_NET][DW_JOBS];
@@ -295,13 +295,36 @@ inline DwPlan dw_plan(int64_t rows) {
       else w_narrow += jt.jobs[net][j].n_o + jt.jobs[net][j].n_i;
     }
   DwPlan pl{};
+  // full jobs: equal shares of 256 workgroups.  Narrow jobs: largest-remainder apportionment of exactly
+  // <= 256 workgroups in proportion to their bytes per row (a 257th workgroup would wait for a whole
+  // second round of the launch).
+  int64_t rem[N_NET][DW_JOBS] = {};
+  int used = 0;
   for (int net = 0; net < N_NET; ++net)
     for (int j = 0; j < jt.count[net]; ++j) {
       const DwJob& job = jt.jobs[net][j];
-      int64_t k = dw_job_is_full(job) ? 256 / n_full : ((int64_t)256 * (job.n_o + job.n_i) + w_narrow / 2) / w_narrow;
+      int64_t k;
+      if (dw_job_is_full(job)) {
+        k = 256 / n_full;
+      } else {
+        const int64_t num = (int64_t)256 * (job.n_o + job.n_i);
+        k = num / w_narrow;
+        rem[net][j] = num - k * w_narrow;
+      }
       k = k < 1 ? 1 : (k > cap ? cap : k);
       pl.k[net][j] = (int)k;
+      if (!dw_job_is_full(job)) used += (int)k;
     }
+  for (int left = 256 - used; left > 0; --left) {            // hand the leftover workgroups to the largest remainders
+    int bn = -1, bj = -1;
+    for (int net = 0; net < N_NET; ++net)
+      for (int j = 0; j < jt.count[net]; ++j)
+        if (!dw_job_is_full(jt.jobs[net][j]) && pl.k[net][j] < cap && rem[net][j] >= 0 &&
+            (bn < 0 || rem[net][j] > rem[bn][bj])) { bn = net; bj = j; }
+    if (bn < 0) break;
+    ++pl.k[bn][bj];
+    rem[bn][bj] = -1;
+  }
   return pl;
 }
 

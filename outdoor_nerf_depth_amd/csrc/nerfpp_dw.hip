@@ -68,11 +68,36 @@ __device__ __forceinline__ void glds16(const void* g, uint32_t lds_abs) {
 // (a flat pointer would drag a flat->LDS null check into divergent code and trips a backend bug).
 extern __shared__ __attribute__((aligned(16))) char dw_smem[];
 typedef uint32_t lds_addr;
-__device__ __forceinline__ bf16x8 tr_frag(lds_addr off) {
+// row2 = byte distance between the two rows of a segment (512 in the full-width image)
+__device__ __forceinline__ bf16x8 tr_frag(lds_addr off, uint32_t row2 = 512) {
   __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)dw_smem;
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + 512));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + row2));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// Narrow jobs size their LDS images by the operand width: a segment holds 2 rows of W bytes (W = the
+// job's column bytes rounded up to 64 / 128 / 256 / 512) + 64 B of padding, so that consecutive segments
+// sit 16 banks apart like in the full-width image; 16 segments per 32-row chunk.  Smaller chunks leave
+// room for a deeper ring in the same LDS (the narrow jobs are bound by bytes in flight).
+struct NarrowGeom {
+  uint32_t w[2];        // image row bytes of A, B
+  uint32_t segw[2];     // 2 * w + 64
+  uint32_t img[2];      // 16 * segw
+  uint32_t chunk;       // P * (img[0] + img[1])
+  int nbuf;             // ring depth: min(8, LDS bytes / chunk)
+};
+__device__ __forceinline__ uint32_t pow2_width(int bytes) { return bytes <= 64 ? 64u : bytes <= 128 ? 128u : bytes <= 256 ? 256u : 512u; }
+template <int P>
+__device__ __forceinline__ NarrowGeom narrow_geom(const DwJob& job, uint32_t lds_bytes) {
+  NarrowGeom g;
+  g.w[0] = pow2_width(job.n_o * 2);
+  g.w[1] = pow2_width(job.n_i * 2);
+#pragma unroll
+  for (int o = 0; o < 2; ++o) { g.segw[o] = 2 * g.w[o] + 64; g.img[o] = 16 * g.segw[o]; }
+  g.chunk = P * (g.img[0] + g.img[1]);
+  const int n = (int)(lds_bytes / g.chunk);
+  g.nbuf = n > 8 ? 8 : n;
+  return g;
 }
 __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
   const uint4 w = *(const uint4*)&v;
@@ -122,8 +147,8 @@ __device__ __forceinline__ void compute_chunk(lds_addr buf, int wo, int wi, int 
 // Narrow jobs (fewer than 8x8 blocks): blocks are dealt round-robin to the 8 waves (wave w owns blocks
 // w, w+8, ...; block b = (bo = b / n_ib, bi = b % n_ib)), so every wave has work between barriers.
 template <int P>
-__device__ __forceinline__ void compute_chunk_rr(lds_addr buf, int wave, int n_ib, int nblk, bool has_bias,
-                                                 f32x16 (&acc)[8], float (&bsum)[8]) {
+__device__ __forceinline__ void compute_chunk_rr(lds_addr buf_a, lds_addr buf_b, const NarrowGeom& gm, int wave, int n_ib,
+                                                 int nblk, bool has_bias, f32x16 (&acc)[8], float (&bsum)[8]) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -134,8 +159,8 @@ __device__ __forceinline__ void compute_chunk_rr(lds_addr buf, int wave, int n_i
       bf16x8 fa[P], fb[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        fa[p] = tr_frag(buf + p * OPER_BYTES + kk * 8 * SEG + bo * 64);
-        fb[p] = tr_frag(buf + (P + p) * OPER_BYTES + kk * 8 * SEG + bi * 64);
+        fa[p] = tr_frag(buf_a + p * gm.img[0] + kk * 8 * gm.segw[0] + bo * 64, gm.w[0]);
+        fb[p] = tr_frag(buf_b + p * gm.img[1] + kk * 8 * gm.segw[1] + bi * 64, gm.w[1]);
       }
       acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[k], 0, 0, 0);
       if constexpr (P == 2) {
@@ -157,7 +182,7 @@ struct DwSched {
   int njobs, njobs0;
 };
 template <int P, bool FULL>
-__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) {
+__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, uint32_t lds_bytes) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
   int job_id = 0;
@@ -199,48 +224,104 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) 
   const int n_ib = job.n_i / 32, nblk = (job.n_o / 32) * n_ib;
 
   // DMA: 2 operands x P planes x 16 segments per chunk, 4P wave-instructions per wave
-  const int dma_col = (lane & 31) * 16, dma_row = lane >> 5;
-  constexpr int NBUF = P == 1 ? 4 : 2;           // LDS ring depth (P=1: 4 x 34 KiB, P=2: 2 x 68 KiB)
   constexpr int DMA_PER_CHUNK = 4 * P;           // wave-instructions per wave per chunk
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
-  auto issue = [&](int c) {
-    if (c >= nchunk || dbg == 2) return;
-    const int64_t r0 = r_begin + (int64_t)c * 32;
-    const uint32_t buf = lds_base + (c % NBUF) * (2 * P * OPER_BYTES);
-#pragma unroll
-    for (int x = 0; x < 4 * P; ++x) {
-      const int id = x * 8 + wave;                 // 0 .. 32P-1
-      const int op = id / (16 * P), rem = id - op * 16 * P, pl = rem >> 4, seg = rem & 15;
-      const int rb = op == 0 ? rb_a : rb_b;
-      if (dma_col < (op == 0 ? job.n_o : job.n_i) * 2) {       // only the job's columns of the (possibly wider) rows
-        const char* src = (op == 0 ? ga + pl * plane_a : gb + pl * plane_b) +
-                          (size_t)(r0 + 2 * seg + dma_row) * rb + dma_col;
-        glds16(src, buf + (op * P + pl) * OPER_BYTES + seg * SEG);
-      }
-    }
-  };
-  // per-lane byte offset inside an operand image for the transposed reads (see header comment):
+  // per-lane position inside an operand image for the transposed reads (see header comment):
   // 16-lane group g: lane-half hi = g>>1, feature sub-block g&1; lane a16: sample a16>>2, piece a16&3
   const int g = lane >> 4, a16 = lane & 15;
-  const int lane_off = (4 * (g >> 1) + (a16 >> 2)) * SEG + (16 * (g & 1) + 4 * (a16 & 3)) * 2;
+  const int lane_seg = 4 * (g >> 1) + (a16 >> 2), lane_col = (16 * (g & 1) + 4 * (a16 & 3)) * 2;
 
   // Ring pipeline: chunks c+1 .. c+NBUF-2 stay in flight while chunk c is consumed.  All VMEM ops of
   // this kernel's main loop are LDS-DMA loads (same type, in-order), so a COUNTED vmcnt is exact:
   // "at most k*DMA_PER_CHUNK outstanding" == "chunk c has landed" when k younger chunks were issued.
   // Raw s_barrier (a __syncthreads() would drain vmcnt to 0 and kill the overlap).
+  if constexpr (FULL) {
+    const int dma_col = (lane & 31) * 16, dma_row = lane >> 5;
+    constexpr int NBUF = P == 1 ? 4 : 2;         // LDS ring depth (P=1: 4 x 34 KiB, P=2: 2 x 68 KiB)
+    auto issue = [&](int c) {
+      if (c >= nchunk || dbg == 2) return;
+      const int64_t r0 = r_begin + (int64_t)c * 32;
+      const uint32_t buf = lds_base + (c % NBUF) * (2 * P * OPER_BYTES);
 #pragma unroll
-  for (int c = 0; c < NBUF - 1; ++c) issue(c);
-  for (int c = 0; c < nchunk; ++c) {
-    const int younger = nchunk - 1 - c < NBUF - 2 ? nchunk - 1 - c : NBUF - 2;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(c + NBUF - 1);
-    if (dbg == 1) continue;
-    const lds_addr buf = (c % NBUF) * (2 * P * OPER_BYTES) + lane_off;
-    if constexpr (FULL) compute_chunk<P, true>(buf, wo, wi, nbo, nbi, do_bias, acc, bsum);
-    else compute_chunk_rr<P>(buf, wave, n_ib, nblk, job.gb_off >= 0, acc_rr, bsum_rr);
+      for (int x = 0; x < 4 * P; ++x) {
+        const int id = x * 8 + wave;               // 0 .. 32P-1
+        const int op = id / (16 * P), rem = id - op * 16 * P, pl = rem >> 4, seg = rem & 15;
+        const int rb = op == 0 ? rb_a : rb_b;
+        const char* src = (op == 0 ? ga + pl * plane_a : gb + pl * plane_b) +
+                          (size_t)(r0 + 2 * seg + dma_row) * rb + dma_col;
+        glds16(src, buf + (op * P + pl) * OPER_BYTES + seg * SEG);
+      }
+    };
+    const int lane_off = lane_seg * SEG + lane_col;
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c) issue(c);
+    for (int c = 0; c < nchunk; ++c) {
+      const int younger = nchunk - 1 - c < NBUF - 2 ? nchunk - 1 - c : NBUF - 2;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(c + NBUF - 1);
+      if (dbg == 1) continue;
+      const lds_addr buf = (c % NBUF) * (2 * P * OPER_BYTES) + lane_off;
+      compute_chunk<P, true>(buf, wo, wi, nbo, nbi, do_bias, acc, bsum);
+    }
+  } else {
+    const NarrowGeom gm = narrow_geom<P>(job, lds_bytes);
+    const int NB = gm.nbuf;
+    // DMA lane map: the first w/16 lanes carry row 0 of the segment, the next w/16 row 1, the rest idle
+    int d_row[2], d_col[2];
+    bool d_on[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int half = gm.w[o] / 16;
+      d_row[o] = lane / half;
+      d_col[o] = (lane - d_row[o] * half) * 16;
+      d_on[o] = d_row[o] < 2 && d_col[o] < (o == 0 ? job.n_o : job.n_i) * 2;
+    }
+    int slot_i = 0, next_i = 0;
+    auto issue = [&]() {                           // next chunk of the slice -> next ring slot
+      const int c = next_i, slot = slot_i;
+      ++next_i;
+      slot_i = slot_i + 1 == NB ? 0 : slot_i + 1;
+      if (c >= nchunk || dbg == 2) return;
+      const int64_t r0 = r_begin + (int64_t)c * 32;
+      const uint32_t buf = lds_base + slot * gm.chunk;
+#pragma unroll
+      for (int x = 0; x < 4 * P; ++x) {
+        // id = x * 8 + wave (0 .. 32P-1): operand and plane depend on x only (wave < 8), so they are
+        // compile-time after unrolling -- the geometry arrays must not be indexed dynamically (scratch
+        // loads would sit in vmcnt between the DMA ops)
+        const int op = (x * 8) / (16 * P), rem0 = x * 8 - op * 16 * P, pl = rem0 >> 4, seg = (rem0 & 15) + wave;
+        if (d_on[op]) {
+          const int rb = op == 0 ? rb_a : rb_b;
+          const char* src = (op == 0 ? ga + pl * plane_a : gb + pl * plane_b) +
+                            (size_t)(r0 + 2 * seg + d_row[op]) * rb + d_col[op];
+          glds16(src, buf + (op == 0 ? 0u : P * gm.img[0]) + pl * gm.img[op] + seg * gm.segw[op]);
+        }
+      }
+    };
+    const lds_addr off_a = lane_seg * gm.segw[0] + lane_col, off_b = P * gm.img[0] + lane_seg * gm.segw[1] + lane_col;
+    for (int c = 0; c < NB - 1; ++c) issue();
+    int slot_c = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      const int younger = nchunk - 1 - c < NB - 2 ? nchunk - 1 - c : NB - 2;
+      switch (younger) {                           // wave-uniform; the count must be an immediate
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * DMA_PER_CHUNK) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DMA_PER_CHUNK) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_PER_CHUNK) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * DMA_PER_CHUNK) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * DMA_PER_CHUNK) : "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();
+      issue();
+      const lds_addr buf = slot_c * gm.chunk;
+      slot_c = slot_c + 1 == NB ? 0 : slot_c + 1;
+      if (dbg == 1) continue;
+      compute_chunk_rr<P>(buf + off_a, buf + off_b, gm, wave, n_ib, nblk, job.gb_off >= 0, acc_rr, bsum_rr);
+    }
   }
 
   float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
@@ -320,10 +401,10 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;
   static const int dbg = getenv("NERFPP_DW_DEBUG") ? atoi(getenv("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
   if (P == 1) {
-    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg);
-    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg);
+    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);
+    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg, (uint32_t)lds);
   } else {
-    hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, sf, dbg);
-    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, lds, st, a, sn, dbg);
+    hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);
+    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, lds, st, a, sn, dbg, (uint32_t)lds);
   }
 }
