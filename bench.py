@@ -33,7 +33,7 @@ PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s measured copy ceiling)
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
 DW_BYTES_PER_ROW = (4960 + 5024) * 2
 # level-1 dW launch pair at N_rand=1024, bf16: FETCH_SIZE (x2 gfx950 wide-stream correction) + WRITE_SIZE
-DW_TRAFFIC_PMC_BYTES = (2 * 1.5 * (917.6e6 + 356.1e6)) + 1.5 * (64.7e6 + 21.2e6)
+DW_TRAFFIC_PMC_BYTES = (2 * 1.5 * (917.6e6 + 356.3e6)) + 1.5 * (64.7e6 + 23.1e6)
 DW_TRAFFIC_SOURCE = 'profiles/r01_j_kernel_stats_timeline_hbm.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
 
 
