@@ -333,7 +333,9 @@ def ddp_train_nerf(rank, args):
             logger.info('tensorboardX not installed: scalars go to the console only')
 
     for global_step in range(start + 1, start + 1 + args.N_iters):
-        time0 = time.time()
+        if global_step == start + 1:
+            t_log, n_log = time.time(), 0
+        n_log += 1
         if device_samplers is not None:
             ray_batch = device_samplers.random_sample(args.N_rand)
         else:
@@ -354,7 +356,10 @@ def ddp_train_nerf(rank, args):
                     scalars_to_log['level_{}/autoexpo_shift'.format(m)] = float(trainer.last_autoexpo[m][1])
                 scalars_to_log['level_{}/rgb_loss'.format(m)] = float(sc[1])
                 scalars_to_log['level_{}/pnsr'.format(m)] = float(mse2psnr(float(sc[1])))
-            scalars_to_log['iter_time'] = time.time() - time0
+            # the steps are queued asynchronously; reading the scalars above synchronised, so the wall time
+            # since the previous log line over the steps it covers is the true time per iteration
+            scalars_to_log['iter_time'] = (time.time() - t_log) / max(n_log, 1)
+            t_log, n_log = time.time(), 0
             logstr = '{} step: {} '.format(args.expname, global_step)
             for k, v in scalars_to_log.items():
                 logstr += ' {}: {:.6f}'.format(k, v)
