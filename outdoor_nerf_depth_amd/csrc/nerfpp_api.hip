@@ -195,6 +195,18 @@ int nerfpp_build_level_tables(int32_t* host_tables) {
   return NERFPP_OK;
 }
 
+int nerfpp_dw_plan(int64_t rows, int32_t* k_out, int32_t* is_full_out) {
+  if (!k_out || rows <= 0) return -1;
+  const DwPlan pl = dw_plan(rows);
+  const JobTable jt = build_all_jobs();
+  for (int net = 0; net < N_NET; ++net)
+    for (int j = 0; j < DW_JOBS; ++j) {
+      k_out[net * DW_JOBS + j] = pl.k[net][j];
+      if (is_full_out) is_full_out[net * DW_JOBS + j] = dw_job_is_full(jt.jobs[net][j]) ? 1 : 0;
+    }
+  return DW_JOBS;
+}
+
 int64_t nerfpp_packed_bytes(int precision) { return prec_ok(precision) ? (int64_t)pack_layout(precision).total : -1; }
 
 int nerfpp_pack_level(void* stream, int precision, const float* params, const int32_t* tables, void* packed) {

@@ -228,3 +228,24 @@ def test_level_tables_concatenate_both_nets():
     f0, b0, w0, u0, _ = L.build_net_tables(0)
     f1, b1, w1, u1, _ = L.build_net_tables(1)
     np.testing.assert_array_equal(tables, np.concatenate([f0, b0, w0, u0, f1, b1, w1, u1]))
+
+
+def test_weight_gradient_launch_plan():
+    """Host code of the dW launch plan (nerfpp_dw_plan): every job gets >= 1 row slice, the 14 full 256x256
+    jobs get equal shares, the narrow jobs' workgroups add up to at most one round of the 256 CUs and follow
+    their bytes per row; small batches are capped at rows / 512 slices."""
+    import ctypes as C
+    lib = L.lib()
+    for rows, cap in ((1024 * 192, 48), (1024 * 64, 48), (128 * 64, 16), (7 * 33, 1)):
+        k = np.zeros(24, np.int32)
+        full = np.zeros(24, np.int32)
+        n = lib.nerfpp_dw_plan(rows, k.ctypes.data_as(C.POINTER(C.c_int32)), full.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert n == 12 and (k >= 1).all() and (k <= cap).all()
+        assert full.sum() == 14
+        if cap == 48:
+            assert (k[full == 1] == 18).all()
+            nk = k[full == 0]
+            assert 240 <= nk.sum() <= 256
+            # [sigma | rgb0 M] (160 + 256 columns) is the widest narrow job, rgb1 (32 + 128) the narrowest
+            assert nk.max() == k[9] == k[12 + 9] and nk.min() == min(k[10], k[11], k[22], k[23])
+            assert nk.sum() == 256
