@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERFPP_ABI_VERSION 1
+#define NERFPP_ABI_VERSION 2
 
 #define NERFPP_OK 0
 #define NERFPP_ERR_ARG 1          /* bad argument (null pointer, size out of range) */
@@ -68,6 +68,18 @@ int nerfpp_sample_coarse(void* stream, int n_rays, int n_samples, const float* r
                          const float* t_rand_bg, float* fg_far, float* fg_z, float* bg_z,
                          int* bad_count);
 
+/* The same with the stratified jitter drawn inside the kernel: t_rand = Philox4x32-10 keyed by `seed`,
+ * counter (element index, stream id, step) -- what torch.rand_like does in the reference
+ * (ddp_train_nerf.py:71), without the two extra launches and [n,S] buffers.  Stream ids: 0 fg, 1 bg. */
+int nerfpp_sample_coarse_rng(void* stream, int n_rays, int n_samples, const float* ray_o,
+                             const float* ray_d, const float* min_depth, uint64_t seed, uint64_t step,
+                             float* fg_far, float* fg_z, float* bg_z, int* bad_count);
+
+/* n uniforms of stream `stream_id` (0 fg jitter, 1 bg jitter, 2 fg sample_pdf u, 3 bg sample_pdf u) of
+ * (seed, step): exactly the values the *_rng entry points consume, element i = flat index [ray, sample].
+ * Exposed so a caller (and the parity tests) can replay a step through the explicit-uniform calls. */
+int nerfpp_rng_uniform(void* stream, uint64_t seed, uint64_t step, int stream_id, int64_t n, float* out);
+
 /* perturb_samples(z_vals) with explicit uniforms                   ddp_train_nerf.py:69-78 */
 int nerfpp_perturb_samples(void* stream, int n_rays, int n_samples, const float* z_vals,
                            const float* t_rand, float* out);
@@ -91,6 +103,12 @@ int nerfpp_sample_fine_pair(void* stream, int n_rays, int s_old, int n_new, cons
                             const float* fg_weights, const float* fg_u, float* fg_z_merged,
                             const float* bg_z_old, const float* bg_weights, const float* bg_u,
                             float* bg_z_merged);
+
+/* the same with u = torch.rand(N_rays, N_samples) (ddp_train_nerf.py:104) drawn inside the kernel
+ * (Philox streams 2 = fg, 3 = bg of (seed, step)). */
+int nerfpp_sample_fine_pair_rng(void* stream, int n_rays, int s_old, int n_new, const float* fg_z_old,
+                                const float* fg_weights, float* fg_z_merged, const float* bg_z_old,
+                                const float* bg_weights, float* bg_z_merged, uint64_t seed, uint64_t step);
 
 /* ray batch from a GPU-resident frame (nerf_sample_ray_split.py:10-34 get_rays_single_image and
  * :178-221 random_sample): for every flat pixel index pix[i] (int64, row-major H x W)
@@ -151,8 +169,9 @@ typedef struct {
   float* bg_rgb;                   /* [n,3] */
   float* bg_depth;                 /* [n]   */
   float* bg_lambda;                /* [n]   */
-  /* optional profiling taps: hipEvent_t handles (or NULL) recorded on `stream` immediately before
-   * and after the foreground-net MLP kernel, so a caller can time that kernel live */
+  /* optional profiling taps: hipEvent_t handles (or NULL) recorded on `stream` immediately before the
+   * first and after the last MLP kernel of this call (foreground + background net), so a caller can
+   * time the level's MLP forward live */
   void* ev_mlp_begin;
   void* ev_mlp_end;
 } nerfpp_forward_args;
@@ -187,8 +206,8 @@ typedef struct {
   const float* g_fg_weights;       /* [n,S] dL/d fg_weights or NULL */
   float grad_scale;                /* multiplies every gradient (1/world_size pre-scaling) */
   float* grads;                    /* [NERFPP_LEVEL_PARAMS] dL/d params, parameters() order */
-  /* optional profiling taps (hipEvent_t or NULL): around the foreground dX-chain kernel and around
-   * the weight-gradient GEMM kernel */
+  /* optional profiling taps (hipEvent_t or NULL): around the dX-chain kernels (both nets) and around
+   * the weight-gradient GEMM kernels (both launches) */
   void* ev_bwd_begin;
   void* ev_bwd_end;
   void* ev_dw_begin;

@@ -96,6 +96,37 @@ def perturb_samples(z_vals, t_rand):
     return (lower + (upper - lower) * np.asarray(t_rand, f32)).astype(f32)
 
 
+def philox_uniform(seed, step, stream_id, n):
+    """The sampling uniforms of the in-kernel generator (csrc/nerfpp_common.h: philox_uniform):
+    Philox4x32-10, key = (seed lo, seed hi), counter = (i lo, i hi, stream_id, step lo); the value is
+    (word0 >> 8) * 2^-24.  Stream ids follow the reference's RNG consumption order per step
+    (SURVEY 8c): 0 = rand_like(fg_z), 1 = rand_like(bg_z) (ddp_train_nerf.py:71 via :444,449),
+    2 = fg sample_pdf u, 3 = bg sample_pdf u (:104 via :455,463).  Returns float32 [n]."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    i = np.arange(n, dtype=np.uint64)
+    c0, c1 = i & mask, i >> np.uint64(32)
+    c2 = np.full(n, stream_id, np.uint64)
+    c3 = np.full(n, int(step) & 0xFFFFFFFF, np.uint64)
+    k0, k1 = np.uint64(int(seed) & 0xFFFFFFFF), np.uint64((int(seed) >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        h0, l0 = p0 >> np.uint64(32), p0 & mask
+        h1, l1 = p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = h1 ^ c1 ^ k0, l1, h0 ^ c3 ^ k1, l0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return ((c0 >> np.uint64(8)).astype(np.float32) * f32(2.0 ** -24)).astype(f32)
+
+
+def step_uniforms(seed, step, n, S0, S1):
+    """The four uniform tensors one training step of the HIP trainer draws in its kernels."""
+    return dict(t_fg=philox_uniform(seed, step, 0, n * S0).reshape(n, S0),
+                t_bg=philox_uniform(seed, step, 1, n * S0).reshape(n, S0),
+                u_fg=philox_uniform(seed, step, 2, n * S1).reshape(n, S1),
+                u_bg=philox_uniform(seed, step, 3, n * S1).reshape(n, S1))
+
+
 # --------------------------------------------------------------------------------------
 # a4  sample_pdf                                                ddp_train_nerf.py:81-130
 # --------------------------------------------------------------------------------------
@@ -222,13 +253,33 @@ def mlp_param_shapes(input_ch, input_ch_viewdirs, netdepth=8, netwidth=256, skip
     return shapes
 
 
-def _linear(x, W, b):
+def round_bf16(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32."""
+    u = np.ascontiguousarray(x, f32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(f32)
+
+
+def _linear(x, W, b, bf16=False):
+    if bf16:
+        return (round_bf16(x) @ round_bf16(W).T + b).astype(f32)
     return (x @ W.T + b).astype(f32)
 
 
-def mlp_forward(p, inp, input_ch, input_ch_viewdirs, netdepth=8, skips=(4,), cache=None):
+def mlp_forward(p, inp, input_ch, input_ch_viewdirs, netdepth=8, skips=(4,), cache=None, bf16=False):
     """p: dict name -> array.  inp: [R, input_ch + input_ch_viewdirs].  Returns rgb [R,3],
-    sigma [R].  If `cache` is a dict the intermediates needed by mlp_backward are stored."""
+    sigma [R].  If `cache` is a dict the intermediates needed by mlp_backward are stored.
+    bf16=True models the single-pass bf16 precision of the HIP kernels (NERFPP_PREC_BF16): both operands of
+    every linear layer are rounded to bfloat16, products accumulate in float32, biases are added in float32
+    -- a structural check for that mode at ~1e-3 instead of the 3e-2 a float32 comparison allows."""
+    if bf16:
+        _lin = lambda x, W, b: _linear(x, W, b, True)
+    else:
+        _lin = _linear
+    return _mlp_forward(p, inp, input_ch, input_ch_viewdirs, netdepth, skips, cache, _lin)
+
+
+def _mlp_forward(p, inp, input_ch, input_ch_viewdirs, netdepth, skips, cache, _linear):
     input_pts = inp[:, :input_ch]
     input_dirs = inp[:, -input_ch_viewdirs:]
     acts_in = []
@@ -255,30 +306,42 @@ def mlp_forward(p, inp, input_ch, input_ch_viewdirs, netdepth=8, skips=(4,), cac
     return rgb, sigma.astype(f32)
 
 
-def mlp_backward(p, cache, d_rgb, d_sigma, netdepth=8, skips=(4,)):
+def mlp_backward(p, cache, d_rgb, d_sigma, netdepth=8, skips=(4,), bf16=False):
     """Closed-form backward of mlp_forward (the reference relies on autograd).
     d_rgb [R,3] (w.r.t. the post-sigmoid colour), d_sigma [R] (w.r.t. sigma=|raw|).
-    Returns dict name -> gradient."""
+    Returns dict name -> gradient.  bf16=True: every GEMM operand (dZ, weights, saved activations)
+    rounded to bfloat16, float32 accumulation (the NERFPP_PREC_BF16 backward)."""
+    if bf16:
+        class _B(dict):
+            def __getitem__(self, k):
+                v = dict.__getitem__(self, k)
+                return [round_bf16(a) for a in v] if isinstance(v, list) else \
+                    (round_bf16(v) if k in ('g', 'rgb_in', 'h_last') else v)
+        cache = _B(cache)
+        p = {k: (round_bf16(v) if k.endswith('weight') else v) for k, v in p.items()}
+        rb = round_bf16
+    else:
+        rb = lambda a: a
     g = OrderedDict()
     rgb = cache['rgb']
-    d_rgb_pre = (d_rgb * rgb * (f32(1.) - rgb)).astype(f32)
+    d_rgb_pre = rb((d_rgb * rgb * (f32(1.) - rgb)).astype(f32))
     g['rgb_layers.2.weight'] = d_rgb_pre.T @ cache['g']
     g['rgb_layers.2.bias'] = d_rgb_pre.sum(0)
     d_g = d_rgb_pre @ p['rgb_layers.2.weight']
-    d_g_pre = (d_g * (cache['g_pre'] > 0)).astype(f32)
+    d_g_pre = rb((d_g * (cache['g_pre'] > 0)).astype(f32))
     g['rgb_layers.0.weight'] = d_g_pre.T @ cache['rgb_in']
     g['rgb_layers.0.bias'] = d_g_pre.sum(0)
-    d_remap = (d_g_pre @ p['rgb_layers.0.weight'])[:, :256]
+    d_remap = rb((d_g_pre @ p['rgb_layers.0.weight'])[:, :256])
     g['base_remap_layers.0.weight'] = d_remap.T @ cache['h_last']
     g['base_remap_layers.0.bias'] = d_remap.sum(0)
-    d_sigma_raw = (d_sigma * np.sign(cache['sigma_raw'])).astype(f32)
+    d_sigma_raw = rb((d_sigma * np.sign(cache['sigma_raw'])).astype(f32))
     g['sigma_layers.0.weight'] = d_sigma_raw[None, :] @ cache['h_last']
     g['sigma_layers.0.bias'] = d_sigma_raw.sum(keepdims=True)
     d_h = d_remap @ p['base_remap_layers.0.weight'] + \
         d_sigma_raw[:, None] * p['sigma_layers.0.weight']
     input_ch = cache['input_ch']
     for i in reversed(range(netdepth)):
-        d_z = (d_h * (cache['pre'][i] > 0)).astype(f32)
+        d_z = rb((d_h * (cache['pre'][i] > 0)).astype(f32))
         g['base_layers.%d.0.weight' % i] = d_z.T @ cache['acts_in'][i]
         g['base_layers.%d.0.bias' % i] = d_z.sum(0)
         if i == 0:
@@ -302,9 +365,9 @@ def _cumprod_f64(x):
     return np.cumprod(x.astype(np.float64), -1).astype(f32)
 
 
-def nerf_forward(params, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, cache=None):
+def nerf_forward(params, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, cache=None, bf16=False):
     """params: {'fg_net.<name>': arr, 'bg_net.<name>': arr}.  Returns the reference's
-    OrderedDict (same keys, same order)."""
+    OrderedDict (same keys, same order).  bf16: see mlp_forward."""
     ray_o = np.asarray(ray_o, f32)
     ray_d = np.asarray(ray_d, f32)
     fg_z_max = np.asarray(fg_z_max, f32)
@@ -322,7 +385,7 @@ def nerf_forward(params, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, cache=Non
     inp = np.concatenate([embed(fg_pts, POS_FREQS),
                           np.broadcast_to(dir_enc[:, None, :], (N, S, DIR_IN))], -1)
     cf = {} if cache is not None else None
-    fg_rgb_s, fg_sigma = mlp_forward(pf, inp.reshape(N * S, -1), FG_IN, DIR_IN, cache=cf)
+    fg_rgb_s, fg_sigma = mlp_forward(pf, inp.reshape(N * S, -1), FG_IN, DIR_IN, cache=cf, bf16=bf16)
     fg_rgb_s = fg_rgb_s.reshape(N, S, 3)
     fg_sigma = fg_sigma.reshape(N, S)
     fg_dists = fg_z_vals[..., 1:] - fg_z_vals[..., :-1]
@@ -349,7 +412,7 @@ def nerf_forward(params, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, cache=Non
     bg_dists = np.concatenate([bg_dists, np.full_like(bg_dists[..., :1], HUGE_NUMBER)], -1)
     cb = {} if cache is not None else None
     bg_rgb_s, bg_sigma = mlp_forward(pb, np.ascontiguousarray(inp).reshape(N * S_bg, -1),
-                                     BG_IN, DIR_IN, cache=cb)
+                                     BG_IN, DIR_IN, cache=cb, bf16=bf16)
     bg_rgb_s = bg_rgb_s.reshape(N, S_bg, 3)
     bg_sigma = bg_sigma.reshape(N, S_bg)
     with np.errstate(over='ignore'):
@@ -416,13 +479,13 @@ def composite_backward(cache, g_rgb, g_depth, g_fg_weights=None):
     return fg_d_rgb, fg_d_sigma, bg_d_rgb, bg_d_sigma
 
 
-def nerf_backward(cache, g_rgb, g_depth, g_fg_weights=None):
+def nerf_backward(cache, g_rgb, g_depth, g_fg_weights=None, bf16=False):
     """Gradient of the loss w.r.t. every parameter, given dL/d rgb [N,3], dL/d depth [N] and
-    (KL only) dL/d fg_weights [N,S]."""
+    (KL only) dL/d fg_weights [N,S].  bf16: see mlp_backward."""
     fg_d_rgb, fg_d_sigma, bg_d_rgb, bg_d_sigma = composite_backward(cache, g_rgb, g_depth,
                                                                     g_fg_weights)
-    gf = mlp_backward(cache['pf'], cache['fg'], fg_d_rgb.reshape(-1, 3), fg_d_sigma.reshape(-1))
-    gb = mlp_backward(cache['pb'], cache['bg'], bg_d_rgb.reshape(-1, 3), bg_d_sigma.reshape(-1))
+    gf = mlp_backward(cache['pf'], cache['fg'], fg_d_rgb.reshape(-1, 3), fg_d_sigma.reshape(-1), bf16=bf16)
+    gb = mlp_backward(cache['pb'], cache['bg'], bg_d_rgb.reshape(-1, 3), bg_d_sigma.reshape(-1), bf16=bf16)
     out = OrderedDict()
     for k, v in gf.items():
         out['fg_net.' + k] = v

@@ -129,8 +129,24 @@ int nerfpp_sample_coarse(void* stream, int n_rays, int n_samples, const float* r
   REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= NERFPP_MAX_SAMPLES, "2 <= n_samples <= 256");
   REQUIRE(ray_o && ray_d && min_depth && fg_far && fg_z && bg_z, "non-null pointers");
   launch_sample_coarse((hipStream_t)stream, n_rays, n_samples, ray_o, ray_d, min_depth, t_rand_fg, t_rand_bg,
-                       fg_far, fg_z, bg_z, bad_count);
+                       fg_far, fg_z, bg_z, bad_count, make_rng_key(0, 0, false));
   return check_launch("sample_coarse");
+}
+
+int nerfpp_sample_coarse_rng(void* stream, int n_rays, int n_samples, const float* ray_o, const float* ray_d,
+                             const float* min_depth, uint64_t seed, uint64_t step, float* fg_far, float* fg_z,
+                             float* bg_z, int* bad_count) {
+  REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= NERFPP_MAX_SAMPLES, "2 <= n_samples <= 256");
+  REQUIRE(ray_o && ray_d && min_depth && fg_far && fg_z && bg_z, "non-null pointers");
+  launch_sample_coarse((hipStream_t)stream, n_rays, n_samples, ray_o, ray_d, min_depth, nullptr, nullptr, fg_far,
+                       fg_z, bg_z, bad_count, make_rng_key(seed, step, true));
+  return check_launch("sample_coarse_rng");
+}
+
+int nerfpp_rng_uniform(void* stream, uint64_t seed, uint64_t step, int stream_id, int64_t n, float* out) {
+  REQUIRE(n > 0 && out && stream_id >= 0 && stream_id <= 3, "stream_id in 0..3, non-null output");
+  launch_rng_uniform((hipStream_t)stream, make_rng_key(seed, step, true), (uint32_t)stream_id, n, out);
+  return check_launch("rng_uniform");
 }
 
 int nerfpp_perturb_samples(void* stream, int n_rays, int n_samples, const float* z_vals, const float* t_rand,
@@ -167,8 +183,21 @@ int nerfpp_sample_fine_pair(void* stream, int n_rays, int s_old, int n_new, cons
   const float* w[2] = {fg_weights, bg_weights};
   const float* u[2] = {fg_u, bg_u};
   float* m[2] = {fg_z_merged, bg_z_merged};
-  launch_sample_fine_pair((hipStream_t)stream, n_rays, s_old - 2, n_new, z, w, u, m);
+  launch_sample_fine_pair((hipStream_t)stream, n_rays, s_old - 2, n_new, z, w, u, m, make_rng_key(0, 0, false));
   return check_launch("sample_fine_pair");
+}
+
+int nerfpp_sample_fine_pair_rng(void* stream, int n_rays, int s_old, int n_new, const float* fg_z_old,
+                                const float* fg_weights, float* fg_z_merged, const float* bg_z_old,
+                                const float* bg_weights, float* bg_z_merged, uint64_t seed, uint64_t step) {
+  REQUIRE(n_rays > 0 && s_old >= 3 && n_new >= 1 && s_old + n_new <= 512, "3 <= s_old, s_old + n_new <= 512");
+  REQUIRE(fg_z_old && fg_weights && fg_z_merged && bg_z_old && bg_weights && bg_z_merged, "non-null pointers");
+  const float* z[2] = {fg_z_old, bg_z_old};
+  const float* w[2] = {fg_weights, bg_weights};
+  const float* u[2] = {nullptr, nullptr};
+  float* m[2] = {fg_z_merged, bg_z_merged};
+  launch_sample_fine_pair((hipStream_t)stream, n_rays, s_old - 2, n_new, z, w, u, m, make_rng_key(seed, step, true));
+  return check_launch("sample_fine_pair_rng");
 }
 
 int nerfpp_gather_rays(void* stream, int n_rays, int width, const float* cam, const int64_t* pix,
@@ -262,7 +291,7 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     if (train) { m.ws = make_netws(ws, L, net); m.masks = (uint4*)(ws + L.masks[net]); }
     if (net == 0 && a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
     launch_mlp_fwd(st, net, P, train, m);
-    if (net == 0 && a->ev_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_mlp_end, st);
+    if (net == N_NET - 1 && a->ev_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_mlp_end, st);
   }
   launch_composite_fwd(st, a->n_rays, a->n_samples, (const float*)(ws + L.out_raw[0]),
                        (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
@@ -315,7 +344,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
     m.masks = (const uint4*)(ws + L.masks[net]);
     if (net == 0 && a->ev_bwd_begin) (void)hipEventRecord((hipEvent_t)a->ev_bwd_begin, st);
     launch_mlp_bwd(st, net, P, m);
-    if (net == 0 && a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);
+    if (net == N_NET - 1 && a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);
     dw.ws[net] = m.ws;
     dw.slabs[net] = (float*)(ws + L.slabs[net]);
   }

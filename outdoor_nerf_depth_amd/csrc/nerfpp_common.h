@@ -328,4 +328,32 @@ inline DwPlan dw_plan(int64_t rows) {
   return pl;
 }
 
+// ---- counter-based RNG for the sampling uniforms ---------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; the generator family torch's CUDA/HIP backend uses), keyed by the
+// caller's 64-bit seed; counter = (element index lo, hi, stream id, step).  Stream ids follow the order
+// the reference consumes torch's RNG per step: 0 = rand_like(fg_z), 1 = rand_like(bg_z)
+// (perturb_samples, ddp_train_nerf.py:444,449), 2 = fg sample_pdf u, 3 = bg sample_pdf u (:455,463).
+// uniform = (word0 >> 8) * 2^-24 in [0, 1) like torch.rand's float32 mapping.  The numpy oracle carries
+// the same function (oracle/nerfpp_oracle.py: philox_uniform), checked bit-for-bit in the GPU tests.
+struct RngKey { uint32_t k0, k1, step_lo, enabled; };
+__host__ __device__ inline RngKey make_rng_key(uint64_t seed, uint64_t step, bool enabled) {
+  RngKey k;
+  k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.step_lo = (uint32_t)step; k.enabled = enabled ? 1u : 0u;
+  return k;
+}
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+__host__ __device__ inline float philox_uniform(const RngKey& key, uint32_t stream_id, uint64_t idx) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream_id, c3 = key.step_lo;
+  uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * 5.9604644775390625e-8f;
+}
+
 }  // namespace nerfpp

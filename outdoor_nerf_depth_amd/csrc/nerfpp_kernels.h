@@ -48,12 +48,15 @@ struct DwArgs {
 // nerfpp_render.hip
 void launch_intersect_sphere(hipStream_t st, int n, const float* o, const float* d, float* far, int* bad);
 void launch_sample_coarse(hipStream_t st, int n, int S, const float* o, const float* d, const float* min_depth,
-                          const float* t_fg, const float* t_bg, float* far, float* fg_z, float* bg_z, int* bad);
+                          const float* t_fg, const float* t_bg, float* far, float* fg_z, float* bg_z, int* bad,
+                          const nerfpp::RngKey& rng);
+void launch_rng_uniform(hipStream_t st, const nerfpp::RngKey& rng, uint32_t stream_id, int64_t n, float* out);
 void launch_perturb(hipStream_t st, int n, int S, const float* z, const float* t, float* out);
 void launch_sample_pdf(hipStream_t st, bool fused, int n, int M, int S_new, const float* bins_or_zold,
                        const float* weights, const float* u, float* samples, int64_t* above, float* merged);
 void launch_sample_fine_pair(hipStream_t st, int n, int M, int S_new, const float* const* z_old,
-                             const float* const* weights, const float* const* u, float* const* merged);
+                             const float* const* weights, const float* const* u, float* const* merged,
+                             const nerfpp::RngKey& rng);
 void launch_composite_fwd(hipStream_t st, int n, int S, const float* raw_fg, const float* raw_bg,
                           const float* depth_real_bg, const float* ray_d, const float* fg_far,
                           const float* fg_z, const float* bg_z, float* rgb, float* depth, float* fg_weights,

@@ -57,7 +57,7 @@ __global__ void sample_coarse_kernel(int n, int S, const float* __restrict__ ray
                                      const float* __restrict__ min_depth,
                                      const float* __restrict__ t_fg, const float* __restrict__ t_bg,
                                      float* __restrict__ fg_far, float* __restrict__ fg_z,
-                                     float* __restrict__ bg_z, int* bad) {
+                                     float* __restrict__ bg_z, int* bad, RngKey rng) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * S) return;
   const int ray = idx / S, i = idx - ray * S;
@@ -67,19 +67,24 @@ __global__ void sample_coarse_kernel(int n, int S, const float* __restrict__ ray
   const float step = (far - near) / (float)(S - 1);
   const float z0 = near + (float)i * step;
   float out = z0;
-  if (t_fg) {
+  if (t_fg || rng.enabled) {
     const float zm = near + (float)(i - 1) * step, zp = near + (float)(i + 1) * step;
-    out = perturb(zm, z0, zp, i == 0, i == S - 1, t_fg[idx]);
+    out = perturb(zm, z0, zp, i == 0, i == S - 1, rng.enabled ? philox_uniform(rng, 0, (uint64_t)idx) : t_fg[idx]);
   }
   fg_z[idx] = out;
   const float b0 = torch_linspace01(i, S);
   out = b0;
-  if (t_bg) {
+  if (t_bg || rng.enabled) {
     const float bm = i > 0 ? torch_linspace01(i - 1, S) : 0.f;
     const float bp = i < S - 1 ? torch_linspace01(i + 1, S) : 0.f;
-    out = perturb(bm, b0, bp, i == 0, i == S - 1, t_bg[idx]);
+    out = perturb(bm, b0, bp, i == 0, i == S - 1, rng.enabled ? philox_uniform(rng, 1, (uint64_t)idx) : t_bg[idx]);
   }
   bg_z[idx] = out;
+}
+
+__global__ void rng_uniform_kernel(RngKey rng, uint32_t stream_id, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = philox_uniform(rng, stream_id, (uint64_t)i);
 }
 
 __global__ void perturb_kernel(int n, int S, const float* __restrict__ z, const float* __restrict__ t,
@@ -107,7 +112,7 @@ struct SamplePdfProblem {
   const float* bins_or_zold; const float* weights; const float* u;
   float* samples; int64_t* above; float* merged;
 };
-struct SamplePdfArgs { SamplePdfProblem p[2]; };
+struct SamplePdfArgs { SamplePdfProblem p[2]; RngKey rng; };   // rng.enabled: u = philox stream 2 + blockIdx.y
 template <bool FUSED>
 __global__ __launch_bounds__(256) void sample_pdf_kernel(int n, int M, int S_new, SamplePdfArgs args) {
   const SamplePdfProblem& pr = args.p[blockIdx.y];
@@ -159,7 +164,8 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(int n, int M, int S_new
   __syncthreads();
   if (active) {
     for (int j = lane; j < S_new; j += 64) {
-      const float u = u_in ? u_in[(size_t)ray * S_new + j] : torch_linspace01(j, S_new);
+      const float u = args.rng.enabled ? philox_uniform(args.rng, 2u + blockIdx.y, (uint64_t)ray * S_new + j)
+                      : u_in ? u_in[(size_t)ray * S_new + j] : torch_linspace01(j, S_new);
       int above = 0;
       for (int k = 0; k < M; ++k) above += (u >= cdf[k]) ? 1 : 0;
       const int below = above - 1 > 0 ? above - 1 : 0;
@@ -515,10 +521,14 @@ void launch_intersect_sphere(hipStream_t st, int n, const float* o, const float*
   hipLaunchKernelGGL(intersect_sphere_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, o, d, far, bad);
 }
 void launch_sample_coarse(hipStream_t st, int n, int S, const float* o, const float* d, const float* min_depth,
-                          const float* t_fg, const float* t_bg, float* far, float* fg_z, float* bg_z, int* bad) {
+                          const float* t_fg, const float* t_bg, float* far, float* fg_z, float* bg_z, int* bad,
+                          const nerfpp::RngKey& rng) {
   const int tot = n * S;
   hipLaunchKernelGGL(sample_coarse_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, n, S, o, d, min_depth,
-                     t_fg, t_bg, far, fg_z, bg_z, bad);
+                     t_fg, t_bg, far, fg_z, bg_z, bad, rng);
+}
+void launch_rng_uniform(hipStream_t st, const nerfpp::RngKey& rng, uint32_t stream_id, int64_t n, float* out) {
+  hipLaunchKernelGGL(rng_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rng, stream_id, n, out);
 }
 void launch_perturb(hipStream_t st, int n, int S, const float* z, const float* t, float* out) {
   const int tot = n * S;
@@ -533,9 +543,11 @@ void launch_sample_pdf(hipStream_t st, bool fused, int n, int M, int S_new, cons
   else hipLaunchKernelGGL(sample_pdf_kernel<false>, grid, block, 0, st, n, M, S_new, a);
 }
 void launch_sample_fine_pair(hipStream_t st, int n, int M, int S_new, const float* const* z_old,
-                             const float* const* weights, const float* const* u, float* const* merged) {
+                             const float* const* weights, const float* const* u, float* const* merged,
+                             const nerfpp::RngKey& rng) {
   dim3 grid((n + 3) / 4, 2), block(256);
   SamplePdfArgs a{};
+  a.rng = rng;
   for (int k = 0; k < 2; ++k) a.p[k] = SamplePdfProblem{z_old[k], weights[k], u[k], nullptr, nullptr, merged[k]};
   hipLaunchKernelGGL(sample_pdf_kernel<true>, grid, block, 0, st, n, M, S_new, a);
 }

@@ -53,7 +53,7 @@ def ddp_test_nerf(rank, args):
                                        try_load_min_depth=args.load_min_depth, depth_sup_type=args.depth_sup_type)
         psnrs, rmses, abs_rels = [], [], []
         for idx, sampler in enumerate(samplers):
-            ret = render_single_image(rank, world, trainer, sampler, args.chunk_size)
+            ret = render_single_image(rank, world, trainer, sampler, args.chunk_size, keep_dists=False)   # fg_dists is never read below
             if rank != 0:
                 continue
             fname = '{:06d}.png'.format(idx)

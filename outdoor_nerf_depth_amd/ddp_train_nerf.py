@@ -38,11 +38,22 @@ def setup_logger():
 
 
 class ConfigFileParser(argparse.ArgumentParser):
-    """argparse + the `key = value` config file of configargparse (--config, command line wins)."""
+    """argparse + the config file syntax of configargparse's default parser (--config; the command line
+    wins): one `key = value`, `key: value` or `key value` per line, `#` / `;` comments, a bare `key` or
+    `key = true` for store_true flags.  Unknown keys are an error, like upstream."""
+
+    @staticmethod
+    def _split(line):
+        for sep in ('=', ':'):
+            if sep in line:
+                k, v = line.split(sep, 1)
+                if ' ' not in k.strip():
+                    return k.strip(), v.strip()
+        parts = line.split(None, 1)
+        return parts[0], (parts[1].strip() if len(parts) > 1 else None)
 
     def parse_args(self, args=None, namespace=None):
         args = list(sys.argv[1:] if args is None else args)
-        pre, _ = argparse.ArgumentParser(add_help=False).parse_known_args([])
         cfg = None
         for i, a in enumerate(args):
             if a == '--config' and i + 1 < len(args):
@@ -51,19 +62,32 @@ class ConfigFileParser(argparse.ArgumentParser):
                 cfg = a.split('=', 1)[1]
         file_args = []
         if cfg and cfg != 'None':
-            known = {a.dest: a for a in self._actions}
-            for line in open(cfg):
-                line = line.split('#', 1)[0].strip()
-                if not line or '=' not in line:
+            known = {}
+            for a in self._actions:
+                for opt in a.option_strings:
+                    known[opt.lstrip('-')] = a
+            for ln, raw in enumerate(open(cfg), 1):
+                line = raw.strip()
+                if not line or line[0] in '#;' or line.startswith('---'):
                     continue
-                k, v = [x.strip() for x in line.split('=', 1)]
-                if k == 'config' or k not in known or v == 'None':
+                line = line.split(' #', 1)[0].strip()
+                k, v = self._split(line)
+                k = k.lstrip('-')
+                if k == 'config':
                     continue
+                if k not in known:
+                    self.error('%s:%d: unrecognized config key %r' % (cfg, ln, k))
+                if v is not None and len(v) >= 2 and v[0] == v[-1] and v[0] in '"\'':
+                    v = v[1:-1]
                 act = known[k]
                 if isinstance(act, argparse._StoreTrueAction):
-                    if v.lower() in ('true', '1', 'yes'):
+                    if v is None or v.lower() in ('true', '1', 'yes', 'on'):
                         file_args.append('--' + k)
-                else:
+                    elif v.lower() not in ('false', '0', 'no', 'off'):
+                        self.error('%s:%d: flag %r takes true/false, got %r' % (cfg, ln, k, v))
+                elif v is None:
+                    self.error('%s:%d: key %r needs a value' % (cfg, ln, k))
+                elif v != 'None':
                     file_args += ['--' + k, v]
         return super().parse_args(file_args + args, namespace)
 
@@ -141,9 +165,11 @@ def validate_args(args):
 
 
 # ------------------------------------------------------------------------------------------------
-def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size):
+def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size, keep_dists=True):
     """ddp_train_nerf.py:133-249: deterministic sampling, no perturbation, chunked, sharded over ranks
-    (ragged last shard instead of raising when H*W % world_size != 0)."""
+    (ragged last shard instead of raising when H*W % world_size != 0).  Returns, per level, every key of
+    `ret` except the two weight tensors, in the reference's order (:210-218) -- including `fg_dists`
+    [H, W, S] (0.36 GB per 375x1242 frame at S = 192; keep_dists=False drops it for timing runs)."""
     import torch
     from . import ops
     from .dist_utils import shard_sizes, gather_ragged
@@ -156,7 +182,9 @@ def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size):
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:lo + sizes[rank]])).to(dev)
     ray_o, ray_d, min_depth = T(b['ray_o']), T(b['ray_d']), T(b['min_depth'])
     S0, S1 = trainer.cascade_samples
-    keys = ('rgb', 'fg_rgb', 'bg_rgb', 'fg_depth', 'bg_depth', 'bg_lambda', 'depth')
+    keys = ('rgb', 'fg_dists', 'fg_rgb', 'fg_depth', 'bg_rgb', 'bg_depth', 'bg_lambda', 'depth')
+    if not keep_dists:
+        keys = tuple(k for k in keys if k != 'fg_dists')
     out = [OrderedDict((k, []) for k in keys) for _ in range(2)]
     for s in range(0, sizes[rank], chunk_size):
         o, d, md = ray_o[s:s + chunk_size], ray_d[s:s + chunk_size], min_depth[s:s + chunk_size]
@@ -316,7 +344,7 @@ def ddp_train_nerf(rank, args):
                             depth_loss_type=args.depth_loss_type, lambda_depth=args.lambda_depth,
                             depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world,
                             optim_autoexpo=args.optim_autoexpo, img_names=img_names,
-                            lambda_autoexpo=args.lambda_autoexpo)
+                            lambda_autoexpo=args.lambda_autoexpo, seed=(rank + 1) * 777)   # :406-408
     ckpt, start = find_latest_checkpoint(args)
     if ckpt is not None:
         logger.info('Reloading from: {}'.format(ckpt))
@@ -345,6 +373,8 @@ def ddp_train_nerf(rank, args):
                 ray_batch['img_name'] = img_names[i]
         scalars = trainer.train_step(ray_batch)
         log_now = rank == 0 and (global_step % args.i_print == 0 or global_step < 10)
+        if global_step % args.i_print == 0 or global_step < 10:
+            trainer.check_cameras()               # every rank: the reference raises per step (:62-63)
         if log_now:
             scalars_to_log = OrderedDict([('resolution', ray_samplers[0].resolution_level)])
             for m, sc in enumerate(scalars):
@@ -373,7 +403,7 @@ def ddp_train_nerf(rank, args):
                 os.makedirs(out_dir, exist_ok=True)
             psnrs, rmses, abs_rels = [], [], []
             for idx, sampler in enumerate(val_ray_samplers):
-                ret = render_single_image(rank, world, trainer, sampler, args.chunk_size)
+                ret = render_single_image(rank, world, trainer, sampler, args.chunk_size, keep_dists=False)   # fg_dists is never read below
                 if rank != 0:
                     continue
                 from PIL import Image
@@ -404,6 +434,8 @@ def ddp_train_nerf(rank, args):
         if rank == 0 and (global_step % args.i_weights == 0 and global_step > 0):   # :642-652
             save_checkpoint(os.path.join(exp_dir, 'model_{:06d}.pth'.format(global_step)), trainer, global_step)
 
+    trainer.flush()                               # the last step's level-1 update is applied lazily under DP
+    trainer.check_cameras()
     if world > 1:
         dist.destroy_process_group()
 

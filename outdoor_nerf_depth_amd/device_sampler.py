@@ -6,7 +6,12 @@ permutation of 465 750 pixels), numpy fancy indexing of five arrays and five H2D
 bottleneck, so here the frames (rgb, depth prior, cameras) live in HBM and a batch is
 `torch.randperm` on the device + one `nerfpp_gather_rays` kernel that regenerates the rays from
 K^-1 / c2w (same formula as get_rays_single_image) and gathers rgb / depth_sup.
-Same dict keys as the reference's sampler output.
+
+Keys: the ones the training step reads -- ray_o, ray_d, rgb, min_depth, depth_sup (+ frame).  The
+reference's sampler dict also carries depth_gt, mask and depth (nerf_sample_ray_split.py:199-221), which
+the training loop never reads; `random_sample(..., full_keys=True)` adds depth_gt and mask from their own
+device-resident maps (torch indexing, not the kernel).  `depth` (a dummy ones-vector upstream) only exists
+with --host_sampling.
 """
 import ctypes as C
 
@@ -37,6 +42,19 @@ class DeviceRaySamplers(object):
         if s0.depth_sup is not None:
             self.depth_sup = torch.stack([torch.from_numpy(np.ascontiguousarray(s.depth_sup, np.float32))
                                           for s in ray_samplers]).to(self.device)      # [F, H*W]
+        # ground-truth depth and mask maps for full_keys (only uploaded when they are separate data)
+        self.depth_gt = None
+        if s0.depth_gt is not None:
+            if all(s.depth_gt is s.depth_sup or (s.depth_sup is not None and np.array_equal(s.depth_gt, s.depth_sup))
+                   for s in ray_samplers):
+                self.depth_gt = self.depth_sup                                          # depth_sup_type == 'gt'
+            else:
+                self.depth_gt = torch.stack([torch.from_numpy(np.ascontiguousarray(s.depth_gt, np.float32))
+                                             for s in ray_samplers]).to(self.device)
+        self.mask = None
+        if getattr(s0, 'mask', None) is not None:
+            self.mask = torch.stack([torch.from_numpy(np.ascontiguousarray(s.mask, np.float32))
+                                     for s in ray_samplers]).to(self.device)
         self.depth_scale = s0.get_depth_scale()
         # optional per-pixel near bound (min_depth/ pngs): gathered with torch indexing after the kernel
         self.min_depth = None
@@ -44,7 +62,7 @@ class DeviceRaySamplers(object):
             self.min_depth = torch.stack([torch.from_numpy(np.ascontiguousarray(s.min_depth, np.float32))
                                           for s in ray_samplers]).to(self.device)      # [F, H*W]
 
-    def gather(self, frame, pix):
+    def gather(self, frame, pix, full_keys=False):
         """Ray batch of `frame` at the flat pixel indices `pix` (int64 device tensor)."""
         n = pix.numel()
         dev = self.device
@@ -63,15 +81,17 @@ class DeviceRaySamplers(object):
                                            p(out['min_depth'])), 'nerfpp_gather_rays')
         if self.min_depth is not None:
             out['min_depth'] = self.min_depth[frame][pix]
-        if 'depth_sup' in out:
-            out['depth_gt'] = out['depth_sup']
+        if full_keys:
+            if self.depth_gt is not None:
+                out['depth_gt'] = out['depth_sup'] if self.depth_gt is self.depth_sup else self.depth_gt[frame][pix]
+            out['mask'] = None if self.mask is None else self.mask[frame][pix]
         return out
 
-    def random_sample(self, N_rand, frame=None):
+    def random_sample(self, N_rand, frame=None, full_keys=False):
         """One random frame (host RNG, like ddp_train_nerf.py:423), N_rand distinct pixels (device RNG)."""
         if frame is None:
             frame = int(np.random.randint(low=0, high=self.n_frames))
         pix = torch.randperm(self.H * self.W, device=self.device)[:N_rand]
-        out = self.gather(frame, pix)
+        out = self.gather(frame, pix, full_keys)
         out['frame'] = frame
         return out

@@ -44,18 +44,45 @@ def intersect_sphere(ray_o, ray_d):
     L.check(L.lib().nerfpp_intersect_sphere(_stream(), n, _p(ray_o), _p(ray_d), _p(far), _p(bad)),
             'nerfpp_intersect_sphere')
     if int(bad.item()) != 0:
-        raise Exception('Not all your cameras are bounded by the unit sphere; please make sure the '
-                        'cameras are normalized properly!')
+        raise Exception(CAMERA_ERROR)
     return far
 
 
+CAMERA_ERROR = ('Not all your cameras are bounded by the unit sphere; please make sure the '
+                'cameras are normalized properly!')                      # ddp_train_nerf.py:62-63
+
+
+def rng_uniform(seed, step, stream_id, shape, device):
+    """The uniforms the in-kernel generator yields for (seed, step, stream_id): stream 0 / 1 = the
+    stratified jitter of the fg / bg depths, 2 / 3 = the fg / bg sample_pdf draws."""
+    out = torch.empty(shape, device=device)
+    L.check(L.lib().nerfpp_rng_uniform(_stream(), int(seed), int(step), int(stream_id), out.numel(), _p(out)),
+            'nerfpp_rng_uniform')
+    return out
+
+
 def sample_coarse(ray_o, ray_d, min_depth, n_samples, t_rand_fg=None, t_rand_bg=None, perturb=True,
-                  check=True):
+                  check=True, rng=None, bad=None):
     """Level-0 depths of ddp_train_nerf.py:438-449 (perturb=True, training) / :166-175 (render).
+    rng = (seed, step): draw the jitter inside the kernel (Philox) instead of from t_rand_* / torch.rand.
+    bad: optional persistent int32[1] device counter of rays outside the unit sphere (not zeroed here; the
+    caller reads it where it synchronises anyway and raises the reference's exception).
     Returns fg_far [n], fg_z [n,S], bg_z [n,S]."""
     ray_o, ray_d, min_depth = _f32(ray_o), _f32(ray_d), _f32(min_depth)
     n = ray_o.shape[0]
     dev = ray_o.device
+    if rng is not None and perturb:
+        far = torch.empty(n, device=dev)
+        fg_z = torch.empty(n, n_samples, device=dev)
+        bg_z = torch.empty(n, n_samples, device=dev)
+        if bad is None:
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(L.lib().nerfpp_sample_coarse_rng(_stream(), n, n_samples, _p(ray_o), _p(ray_d), _p(min_depth),
+                                                 int(rng[0]), int(rng[1]), _p(far), _p(fg_z), _p(bg_z), _p(bad)),
+                'nerfpp_sample_coarse_rng')
+        if check and int(bad.item()) != 0:
+            raise Exception(CAMERA_ERROR)
+        return far, fg_z, bg_z
     if perturb:
         # RNG call order of the reference: fg rand_like, then bg rand_like
         if t_rand_fg is None:
@@ -68,13 +95,13 @@ def sample_coarse(ray_o, ray_d, min_depth, n_samples, t_rand_fg=None, t_rand_bg=
     far = torch.empty(n, device=dev)
     fg_z = torch.empty(n, n_samples, device=dev)
     bg_z = torch.empty(n, n_samples, device=dev)
-    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    if bad is None:
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
     L.check(L.lib().nerfpp_sample_coarse(_stream(), n, n_samples, _p(ray_o), _p(ray_d), _p(min_depth),
                                          _p(t_rand_fg), _p(t_rand_bg), _p(far), _p(fg_z), _p(bg_z), _p(bad)),
             'nerfpp_sample_coarse')
     if check and int(bad.item()) != 0:
-        raise Exception('Not all your cameras are bounded by the unit sphere; please make sure the '
-                        'cameras are normalized properly!')
+        raise Exception(CAMERA_ERROR)
     return far, fg_z, bg_z
 
 
@@ -126,13 +153,21 @@ def sample_fine(z_old, weights, N_samples, det=False, u=None, return_all=False):
     return (merged, samples, above) if return_all else merged
 
 
-def sample_fine_pair(fg_z, fg_weights, bg_z, bg_weights, N_samples, det=False, u_fg=None, u_bg=None):
+def sample_fine_pair(fg_z, fg_weights, bg_z, bg_weights, N_samples, det=False, u_fg=None, u_bg=None, rng=None):
     """Both volumes of a level in one launch (same arithmetic as two sample_fine calls; the uniforms are
-    drawn fg first, then bg, like the reference's two sample_pdf calls)."""
+    drawn fg first, then bg, like the reference's two sample_pdf calls).  rng = (seed, step): draw them
+    inside the kernel (Philox streams 2 and 3)."""
     fg_z, fg_weights, bg_z, bg_weights = _f32(fg_z), _f32(fg_weights), _f32(bg_z), _f32(bg_weights)
     n, S_old = fg_z.shape
     if fg_weights.shape != (n, S_old) or bg_z.shape != (n, S_old) or bg_weights.shape != (n, S_old):
         raise L.NerfppError('z / weights must all be [n, S_old]')
+    if rng is not None and not det:
+        fg_m = torch.empty(n, S_old + N_samples, device=fg_z.device)
+        bg_m = torch.empty(n, S_old + N_samples, device=fg_z.device)
+        L.check(L.lib().nerfpp_sample_fine_pair_rng(_stream(), n, S_old, N_samples, _p(fg_z), _p(fg_weights), _p(fg_m),
+                                                    _p(bg_z), _p(bg_weights), _p(bg_m), int(rng[0]), int(rng[1])),
+                'nerfpp_sample_fine_pair_rng')
+        return fg_m, bg_m
     if det:
         u_fg = u_bg = None
     else:

@@ -22,7 +22,10 @@ class NerfppTrainer(object):
     def __init__(self, device, precision=L.PREC_SPLIT_BF16, cascade_samples=(64, 128), lrate=5e-4,
                  use_depth=True, depth_loss_type='mse', lambda_depth=0.1, depth_sigma=0.01, depth_scale=1.0,
                  world_size=1, level_params=None, overlap_allreduce=True, optim_autoexpo=False, img_names=None,
-                 lambda_autoexpo=1.0):
+                 lambda_autoexpo=1.0, seed=777, torch_rng=False):
+        """seed: key of the in-kernel sampling RNG (the CLI passes (rank+1)*777 like ddp_train_nerf.py:406-408);
+        torch_rng=True draws the four uniform tensors with torch.rand in the reference's call order instead
+        (4 extra launches per step)."""
         self.device = torch.device(device)
         self.precision = precision
         self.cascade_samples = tuple(cascade_samples)
@@ -41,6 +44,12 @@ class NerfppTrainer(object):
         self.exp_avg_sq = [torch.zeros_like(e.params) for e in self.engines]
         self.grads = [torch.empty_like(e.params) for e in self.engines]
         self.step_count = 0
+        self.seed, self.torch_rng = int(seed), bool(torch_rng)
+        self.rng_step = 0                 # counter of the in-kernel RNG (not reset by checkpoint reloads of step_count)
+        # rays whose closest point to the origin lies outside the unit sphere, summed over all steps since
+        # the last check_cameras() (the reference raises on the spot, ddp_train_nerf.py:62-63; here the
+        # counter is read wherever the caller synchronises anyway)
+        self.bad_cameras = torch.zeros(1, dtype=torch.int32, device=self.device)
         # per-image auto-exposure parameters, one set per level's net (ddp_model.py:161-192)
         self.autoexpo = None
         if optim_autoexpo:
@@ -64,7 +73,12 @@ class NerfppTrainer(object):
         if self.world_size <= 1:
             return
         import torch.distributed as dist
-        if self._ae_grad[m] is not None:                  # [n_img, 3]: grads | used flag; a few hundred bytes
+        if self.autoexpo is not None:
+            # [n_img, 3]: grads | used flag; a few hundred bytes.  EVERY rank issues this collective every
+            # step: a rank whose image has no auto-exposure entry (ddp_model.py:186 falls back to the plain
+            # rgb loss) contributes zeros, otherwise the ranks' collective sequences would diverge
+            if self._ae_grad[m] is None:
+                self._ae_grad[m] = torch.zeros(len(self.autoexpo[m].names), 3, device=self.device)
             dist.all_reduce(self._ae_grad[m])
         if self.comm_stream is None:
             dist.all_reduce(self.grads[m])
@@ -91,6 +105,14 @@ class NerfppTrainer(object):
             self._apply(*self._late)
             self._late = None
 
+    def check_cameras(self):
+        """Raise the reference's exception (ddp_train_nerf.py:62-63) if any ray of any step since the last
+        call left the unit sphere.  Synchronises (one 4-byte D2H): call it where the loop syncs anyway --
+        the log line, checkpoints, evaluation, the end of training."""
+        if int(self.bad_cameras.item()) != 0:
+            self.bad_cameras.zero_()
+            raise Exception(ops.CAMERA_ERROR)
+
     def _apply(self, m, step=None):
         self._allreduce_end(m)
         eng = self.engines[m]
@@ -113,9 +135,16 @@ class NerfppTrainer(object):
         S0, S1 = self.cascade_samples[0], self.cascade_samples[1] if len(self.cascade_samples) > 1 else 0
         dev = self.device
         u = uniforms or {}
-        t_fg = u['t_fg'] if 't_fg' in u else torch.rand(n, S0, device=dev)
-        t_bg = u['t_bg'] if 't_bg' in u else torch.rand(n, S0, device=dev)
-        far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, batch['min_depth'], S0, t_fg, t_bg, check=False)
+        self.rng_step += 1
+        rng = None if (uniforms is not None or self.torch_rng) else (self.seed, self.rng_step)
+        if rng is not None:
+            far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, batch['min_depth'], S0, check=False, rng=rng,
+                                                bad=self.bad_cameras)
+        else:
+            t_fg = u['t_fg'] if 't_fg' in u else torch.rand(n, S0, device=dev)
+            t_bg = u['t_bg'] if 't_bg' in u else torch.rand(n, S0, device=dev)
+            far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, batch['min_depth'], S0, t_fg, t_bg, check=False,
+                                                bad=self.bad_cameras)
         depth_sup = batch.get('depth_sup') if self.loss_type != 'rgbonly' else None
         scalars = []
         ret = None
@@ -130,7 +159,9 @@ class NerfppTrainer(object):
             if self._late is not None and self._late[0] == m:     # this level's update from the previous step
                 self._apply(*self._late)
                 self._late = None
-            if m > 0:
+            if m > 0 and rng is not None:
+                fg_z, bg_z = ops.sample_fine_pair(fg_z, ret['fg_weights'], bg_z, ret['bg_weights'], S1, rng=rng)
+            elif m > 0:
                 u_fg = u['u_fg'] if 'u_fg' in u else torch.rand(n, S1, device=dev)
                 u_bg = u['u_bg'] if 'u_bg' in u else torch.rand(n, S1, device=dev)
                 fg_z, bg_z = ops.sample_fine_pair(fg_z, ret['fg_weights'], bg_z, ret['bg_weights'], S1,

@@ -131,3 +131,122 @@ def test_two_ranks_autoexposure(tmp_path):
     steps = np.load(tmp_path / 'ae_steps_rank0.npy')
     np.testing.assert_array_equal(steps, np.ones_like(steps))              # images 0..3, both levels: one step each
     assert (np.abs(a0 - np.array([0.5, 0.0], np.float32)).max(-1) > 1e-5).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: the HIP gradients against the REFERENCE's 2-rank average (tests/golden/ddp2.npz), over gloo on one GPU
+# and over RCCL on two; bench.py --gpus N launching its own ranks
+# ---------------------------------------------------------------------------------------------------------------
+GOLDEN_DDP2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ddp2.npz')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker_ddp2(rank, world, port, out_path, backend, share_gpu):
+    """One DDP rank: its own batch of ddp2.npz through the HIP level-0 forward / loss / backward with the
+    gradients pre-scaled by 1/world (trainer.py), then ONE all-reduce(SUM) -- DDP's average (ddp_train_nerf.py:323)."""
+    import torch.distributed as dist
+    from oracle import nerfpp_oracle as O
+    from outdoor_nerf_depth_amd import ops
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dev = torch.device('cuda', 0 if share_gpu else rank)
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    g = np.load(GOLDEN_DDP2)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    level = O.init_params_like_reference(1)[0]
+    flat = np.concatenate([level[k].reshape(-1) for k in O.param_order()]).astype(np.float32)
+    eng = ops.LevelEngine(T(flat), precision=2)
+    pre = 'r%d.' % rank
+    far, fg_z, bg_z = ops.sample_coarse(T(g[pre + 'ray_o']), T(g[pre + 'ray_d']), T(g[pre + 'min_depth']), 64,
+                                        t_rand_fg=T(g[pre + 't_fg']), t_rand_bg=T(g[pre + 't_bg']))
+    ret = eng.forward(T(g[pre + 'ray_o']), T(g[pre + 'ray_d']), far, fg_z, bg_z, training=True)
+    sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, T(g[pre + 'rgb']), T(g[pre + 'depth_sup']), 'mse', 0.1)
+    grads = eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / world)
+    dist.all_reduce(grads)
+    torch.cuda.synchronize()
+    np.save(out_path % rank, grads.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_against_ddp2(avg):
+    from oracle import nerfpp_oracle as O
+    g = np.load(GOLDEN_DDP2)
+    shapes, off = {}, 0
+    for net, in_ch in (('fg_net', 63), ('bg_net', 84)):
+        for k, s in O.mlp_param_shapes(in_ch, 27).items():
+            shapes['%s.%s' % (net, k)] = s
+    for k in O.param_order():
+        n = int(np.prod(shapes[k]))
+        mine = avg[off:off + n][g['avg.%s.idx' % k]]
+        assert np.abs(mine - g['avg.%s.g' % k]).max() <= 5e-2 * g['avg.%s.rms' % k] + 1e-12, k
+        off += n
+
+
+def test_hip_two_rank_average_matches_reference_ddp2_gloo(tmp_path):
+    """a16 on ONE GPU: two processes share cuda:0, all-reduce over gloo; the averaged HIP gradients against the
+    reference's own 2-rank emulation (float64 run, tests/golden/ddp2.npz) -- not against HIP itself."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'avg_rank%d.npy')
+    mp.spawn(_worker_ddp2, args=(2, _free_port(), out, 'gloo', True), nprocs=2, join=True)
+    a0, a1 = np.load(out % 0), np.load(out % 1)
+    np.testing.assert_array_equal(a0, a1)
+    _check_against_ddp2(a0)
+
+
+def test_hip_two_rank_average_matches_reference_ddp2_rccl(tmp_path):
+    """a16 over RCCL: one process per GPU, backend nccl (= RCCL over xGMI).  Skipped on 1-GPU boxes."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'avg_rank%d.npy')
+    mp.spawn(_worker_ddp2, args=(2, _free_port(), out, 'nccl', False), nprocs=2, join=True)
+    a0, a1 = np.load(out % 0), np.load(out % 1)
+    np.testing.assert_array_equal(a0, a1)
+    _check_against_ddp2(a0)
+
+
+def _run_bench(extra, env_extra, timeout=900):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--n_rand', '128',
+                           '--no_cpu_baseline', '--large_batch', '0'] + extra, capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` must itself start 2 ranks and print n_gpus: 2.  On a box with
+    2+ GPUs this runs RCCL; on a 1-GPU box the two ranks share cuda:0 over gloo (test hook) -- and WITHOUT the hook
+    the run must fail loudly rather than report N=1."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import json
+    if torch.cuda.device_count() >= 2:
+        out = _run_bench(['--gpus', '2'], {})
+        assert out.returncode == 0, out.stderr[-2000:]
+    else:
+        loud = _run_bench(['--gpus', '2'], {})
+        assert loud.returncode != 0 and 'only 1 GPU' in (loud.stderr + loud.stdout)
+        out = _run_bench(['--gpus', '2'], {'NERFPP_SHARE_GPU': '1', 'NERFPP_DIST_BACKEND': 'gloo'})
+        assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['config']['n_rand_per_gpu'] == 128
+    assert abs(r['value'] - 2 * 128 / (r['ms_per_step'] * 1e-3)) <= 1e-6 * r['value']
+    # a launcher environment that disagrees with --gpus is an error, not a silent N
+    import subprocess
+    import sys
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+    assert bad.returncode != 0 and 'WORLD_SIZE=1' in (bad.stderr + bad.stdout)

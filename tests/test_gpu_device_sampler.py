@@ -13,6 +13,8 @@ def test_device_batches_match_host_sampler(golden):
     from outdoor_nerf_depth_amd.data_loader_split import synthetic_ray_samplers
     from outdoor_nerf_depth_amd.device_sampler import DeviceRaySamplers
     samplers = synthetic_ray_samplers('train', skip=3, depth_sup_type='mono_crop', n_frames=20, H=30, W=44)
+    for s_ in samplers:                          # make the ground truth differ from the prior (full_keys check below)
+        s_.depth_gt = (s_.depth_sup * np.float32(1.25)).astype(np.float32)
     dev = torch.device('cuda:0')
     ds = DeviceRaySamplers(samplers, dev)
     assert ds.n_frames == len(samplers) and (ds.H, ds.W) == (30, 44)
@@ -37,8 +39,14 @@ def test_device_batches_match_host_sampler(golden):
     # random_sample: distinct pixels, right shapes and keys
     np.random.seed(3)
     b = ds.random_sample(128)
-    assert set(b.keys()) >= {'ray_o', 'ray_d', 'rgb', 'min_depth', 'depth_sup', 'depth_gt', 'frame'}
+    assert set(b.keys()) >= {'ray_o', 'ray_d', 'rgb', 'min_depth', 'depth_sup', 'frame'} and 'depth_gt' not in b
     assert b['ray_d'].shape == (128, 3) and 0 <= b['frame'] < ds.n_frames
+    # full_keys: depth_gt is the frame's GROUND-TRUTH map (not the mono_crop prior), mask as the host sampler has it
+    pix = torch.from_numpy(rs.choice(30 * 44, size=64, replace=False)).to(dev)
+    full = ds.gather(1, pix, full_keys=True)
+    host = samplers[1]
+    np.testing.assert_array_equal(full['depth_gt'].cpu().numpy(), host.depth_gt[pix.cpu().numpy()])
+    assert not np.array_equal(host.depth_gt, host.depth_sup) and full['mask'] is None
 
 
 def test_train_cli_with_device_sampling(tmp_path):

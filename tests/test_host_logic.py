@@ -2,12 +2,15 @@
 N > 1 path (world_size 2, gloo)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 from oracle import nerfpp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from outdoor_nerf_depth_amd import model as M
 from outdoor_nerf_depth_amd import dist_utils as D
 from outdoor_nerf_depth_amd import ddp_train_nerf as T
@@ -245,3 +248,46 @@ def test_autoexposure_matches_reference_steps(golden):
     ae2.load_state_dict_entries(dict(ae.state_dict_entries()))
     ae2.load_adam_entries(st)
     assert torch.equal(ae2.params, ae.params) and torch.equal(ae2.exp_avg_sq, ae.exp_avg_sq)
+
+
+def test_config_file_syntax_and_unknown_keys(tmp_path):
+    """configargparse semantics: `key = value`, `key: value`, `key value`, bare flags; the command line
+    wins; a typo in a key is an error instead of a silent default."""
+    from outdoor_nerf_depth_amd.ddp_train_nerf import config_parser
+    cfg = tmp_path / 'c.txt'
+    cfg.write_text('### INPUT\ndatadir = /data/x\nscene: seq00\nexpname run1\nN_iters = 17\nuse_depth = True\n'
+                   'no_reload = False\nckpt_path = None\noptim_autoexpo\n# comment\nlambda_depth: 0.1\n')
+    a = config_parser().parse_args(['--config', str(cfg), '--N_iters', '5'])
+    assert (a.datadir, a.scene, a.expname, a.N_iters) == ('/data/x', 'seq00', 'run1', 5)
+    assert a.use_depth and not a.no_reload and a.ckpt_path is None and a.optim_autoexpo and a.lambda_depth == 0.1
+    bad = tmp_path / 'bad.txt'
+    bad.write_text('lamda_depth = 3\n')
+    with pytest.raises(SystemExit):
+        config_parser().parse_args(['--config', str(bad)])
+
+
+def test_bench_refuses_world_size_mismatch():
+    """bench.py --gpus N under a launcher environment with a different WORLD_SIZE must fail loudly (CPU-only check:
+    the refusal happens before any GPU work)."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'))
+    assert out.returncode != 0 and '--gpus 4 but WORLD_SIZE=2' in (out.stderr + out.stdout)
+    # and without a launcher, on this GPU-less container, --gpus 2 refuses instead of running one rank
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK')})
+    if out.returncode == 0:
+        pytest.skip('this box has 2+ GPUs')
+    assert 'GPU(s) visible' in (out.stderr + out.stdout)
+
+
+def test_philox_known_answer_and_stream_layout():
+    """oracle philox_uniform: Random123's Philox4x32-10 known-answer vector (counter 0, key 0 -> first word
+    0x6627e8d5) and the (index, stream, step) counter layout of csrc/nerfpp_common.h."""
+    u = O.philox_uniform(0, 0, 0, 4)
+    assert u[0] == np.float32(0x6627e8) * np.float32(2.0 ** -24)
+    a, b = O.philox_uniform(777, 5, 2, 64), O.philox_uniform(777, 5, 3, 64)
+    assert not np.array_equal(a, b) and not np.array_equal(a, O.philox_uniform(777, 6, 2, 64))
+    np.testing.assert_array_equal(O.philox_uniform(777, 5, 2, 64)[:10], O.philox_uniform(777, 5, 2, 10))
+    uni = O.step_uniforms(777, 1, 8, 64, 128)
+    assert uni['t_fg'].shape == (8, 64) and uni['u_bg'].shape == (8, 128) and uni['u_fg'].dtype == np.float32

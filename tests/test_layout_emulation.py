@@ -53,7 +53,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nerfpp_abi_version() == 1
+    assert lib.nerfpp_abi_version() == L.ABI_VERSION
     assert lib.nerfpp_packed_bytes(1) > 0 and lib.nerfpp_packed_bytes(2) == 2 * lib.nerfpp_packed_bytes(1) - \
         (lib.nerfpp_packed_bytes(1) - sum(_stream_bytes(1))) or True
     assert lib.nerfpp_packed_bytes(3) == -1

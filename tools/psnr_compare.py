@@ -33,7 +33,7 @@ def run(prec, args, train, test, dev, seed=777):
     for it in range(args.iters):
         tr.train_step(ds.random_sample(args.n_rand))
         if (it + 1) in args.eval_at:
-            curve[it + 1] = float(np.mean([float(mse2psnr(np.mean((s.get_img() - render_single_image(0, 1, tr, s, 8192)[-1]['rgb'].numpy()) ** 2))) for s in test]))
+            curve[it + 1] = float(np.mean([float(mse2psnr(np.mean((s.get_img() - render_single_image(0, 1, tr, s, 8192, keep_dists=False)[-1]['rgb'].numpy()) ** 2))) for s in test]))
     torch.cuda.synchronize()
     dt = time.time() - t0
     psnrs, rmses = [], []

@@ -25,20 +25,21 @@ def main():
     p.add_argument('--chunk', type=int, default=8192)
     p.add_argument('--frames', type=int, default=3)
     p.add_argument('--precision', default='bf16')
+    p.add_argument('--keep_dists', action='store_true', help="also return fg_dists [H,W,S] like the reference's dict (0.36 GB D2H per frame)")
     a = p.parse_args()
     dev = torch.device('cuda:0')
     samplers = synthetic_ray_samplers('test', 1, 'gt', 20, 375, 1242)[:1]
     tr = NerfppTrainer(dev, precision=L.PREC_BF16 if a.precision == 'bf16' else L.PREC_SPLIT_BF16, use_depth=False)
-    render_single_image(0, 1, tr, samplers[0], a.chunk)                   # warm-up
+    render_single_image(0, 1, tr, samplers[0], a.chunk, keep_dists=a.keep_dists)                   # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.frames):
-        render_single_image(0, 1, tr, samplers[0], a.chunk)
+        render_single_image(0, 1, tr, samplers[0], a.chunk, keep_dists=a.keep_dists)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.frames
     n = 375 * 1242
     print(json.dumps({'metric': 'render s/frame 375x1242, 64+128 samples/ray', 's_per_frame': dt, 'rays_per_s': n / dt,
-                      'algorithmic_tflops': n * 0.613e9 / dt / 1e12, 'chunk': a.chunk, 'precision': a.precision}))
+                      'algorithmic_tflops': n * 0.613e9 / dt / 1e12, 'chunk': a.chunk, 'precision': a.precision, 'keep_dists': a.keep_dists}))
 
 
 if __name__ == '__main__':
