@@ -70,7 +70,7 @@ def parse():
     p.add_argument('--depth_loss_type', default='mse', choices=['mse', 'l1', 'kl'])
     p.add_argument('--lambda_depth', type=float, default=0.1)
     p.add_argument('--cpu_rays', type=int, default=1024, help='N_rand of the CPU baseline (SURVEY 8d: 1024)')
-    p.add_argument('--cpu_budget_s', type=float, default=120.0,
+    p.add_argument('--cpu_budget_s', type=float, default=100.0,
                    help='stop adding timed CPU steps once this much wall time is spent (>= 2 timed steps always run)')
     return p.parse_args()
 

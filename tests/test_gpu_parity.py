@@ -147,7 +147,9 @@ def test_sample_fine_ragged_shapes_bit_exact(ops, n_rays, S_old, n_new):
 
 
 # ----------------------------------------------------------------------------------------- forward
-RET_TOL = {2: dict(rtol=1e-4, atol=2e-6), 1: dict(rtol=3e-2, atol=3e-3)}
+# single-pass bf16: elementwise sanity bound; the measured errors (profiles/r02_bf16_error_report.json: rgb 2e-4, depth 7e-5,
+# fg_weights 4.7e-3 of the tensor's max) are held to 2x by tests/test_gpu_round2.py::test_bf16_errors_within_twice_...
+RET_TOL = {2: dict(rtol=1e-4, atol=2e-6), 1: dict(rtol=2e-2, atol=1.5e-3)}
 
 
 @pytest.mark.parametrize('prec', [2, 1])
@@ -222,7 +224,9 @@ def test_losses_match_reference(ops, golden):
 # reference itself is ~1e-1*RMS noisy on these cancelling sums (tests/test_oracle_golden.py::
 # test_level_gradients), so the comparison is against the float64 run of the reference.  Single-pass
 # bf16 (8 mantissa bits) is expected to be ~10x noisier than split-bf16.
-GRAD_TOL = {2: (5e-2, 2e-2), 1: (1.5, 0.25)}
+# bf16: 2x the worst values measured on MI355X over the four loss modes (profiles/r02_bf16_error_report.json:
+# max|diff|/RMS 0.62, relative L2 0.10)
+GRAD_TOL = {2: (5e-2, 2e-2), 1: (1.25, 0.2)}
 
 
 @pytest.mark.parametrize('prec', [2, 1])

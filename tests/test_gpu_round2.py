@@ -119,7 +119,12 @@ def test_full_size_forward_and_losses_match_oracle(ops, levels, level):
         np.testing.assert_allclose(N(g_rgb), o_rgb, rtol=2e-4, atol=1e-9)
         np.testing.assert_allclose(N(g_depth), o_depth, rtol=2e-4, atol=1e-9)
         if mode == 'kl':
-            np.testing.assert_allclose(N(g_w), o_w, rtol=5e-4, atol=1e-9)
+            # g_w = -lambda e dists / ((w + 1e-5) S) amplifies the 1e-4-level forward differences in w by w / (w + 1e-5)
+            # where w ~ 0: the kernel's arithmetic is checked on ITS OWN forward outputs (tight), the cross-path value loosely
+            own = {k: N(ret[k]) for k in ('rgb', 'depth', 'fg_weights', 'fg_dists')}
+            k_w = O.loss_and_grads(own, N(fg_z), N(far), b['rgb'], b['depth_sup'], True, mode, 0.1, 0.01)[5]
+            np.testing.assert_allclose(N(g_w), k_w, rtol=2e-5, atol=1e-9)
+            np.testing.assert_allclose(N(g_w), o_w, rtol=2e-2, atol=1e-7)
     # single-pass bf16 at the same size, against the oracle run with bf16-rounded GEMM operands
     ref16 = O.nerf_forward(levels[level], b['ray_o'], b['ray_d'], N(far), N(fg_z), N(bg_z), bf16=True)
     e16 = ops.LevelEngine(T(flat(levels[level])), precision=1)
