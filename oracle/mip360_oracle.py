@@ -64,7 +64,8 @@ def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr
 # ======================================================================================== internal/geopoly.py
 def generate_basis(base_shape='icosahedron', angular_tesselation=2, eps=1e-4):
     """geopoly.py:74-124 (with :33-71): unit vectors of a tesselated icosahedron, antipodal duplicates removed,
-    column order reversed.  Returns [3, n] (n = 21 for the NerfMLP default: icosahedron, 2 subdivisions)."""
+    coordinate order reversed.  Returns [n, 3] like upstream (n = 21 for the MLP default: icosahedron, 2
+    subdivisions); the MLPs use its transpose (models.py:387-389), see pos_basis_t()."""
     if base_shape != 'icosahedron':
         raise ValueError('only the icosahedron basis (the MLP default, models.py:381) is restated')
     a = (np.sqrt(5) + 1) / 2
@@ -85,7 +86,12 @@ def generate_basis(base_shape='icosahedron', angular_tesselation=2, eps=1e-4):
     pts = pts[np.unique(first), :]
     match = sq(pts, -pts) < eps
     pts = pts[np.any(np.triu(match), 1), :]
-    return pts[:, ::-1].T.copy()                                                   # [3, n]: x/y/z swapped like upstream
+    return pts[:, ::-1].copy()
+
+
+def pos_basis_t(base_shape='icosahedron', subdivisions=2):
+    """models.py:387-389: the [3, n] matrix the IPE lifts means / covariances onto."""
+    return generate_basis(base_shape, subdivisions).T.astype(np.float32)
 
 
 # ======================================================================================== internal/coord.py
@@ -143,9 +149,11 @@ def construct_ray_warps(fn, t_near, t_far):
     else:
         fwd, inv = {'reciprocal': (np.reciprocal, np.reciprocal), 'log': (np.log, np.exp),
                     'sqrt': (np.sqrt, np.square), 'exp': (np.exp, np.log), 'square': (np.square, np.sqrt)}[fn]
+    def _f(v):
+        v = np.asarray(v)
+        return v if v.dtype.kind == 'f' else v.astype(np.float64)
     with np.errstate(divide='ignore'):
-        s_near, s_far = fwd(np.asarray(t_near, np.float64) * 1.0), fwd(np.asarray(t_far, np.float64) * 1.0)
-    s_near, s_far = s_near.astype(np.result_type(t_near, np.float32)), s_far.astype(np.result_type(t_far, np.float32))
+        s_near, s_far = fwd(_f(t_near)), fwd(_f(t_far))
     t_to_s = lambda t: (fwd(t) - s_near) / (s_far - s_near)
     s_to_t = lambda s: inv(s * s_far + (1 - s) * s_near)
     return t_to_s, s_to_t
@@ -194,7 +202,9 @@ def searchsorted(a, v):
 def query(tq, t, y, outside_value=0):
     """stepfun.py:56-61."""
     lo, hi = searchsorted(t, tq)
-    return np.where(lo == hi, outside_value, np.take_along_axis(y, lo, -1))
+    # (idx_lo can be the last edge index = one past the last bin when tq is beyond the domain; jnp's gather does
+    # not raise there and the value is discarded by the where)
+    return np.where(lo == hi, outside_value, np.take_along_axis(y, np.minimum(lo, y.shape[-1] - 1), -1))
 
 
 def inner_outer(t0, t1, y1):
@@ -529,7 +539,7 @@ def model_forward(prop_params, nerf_params, rays, train_frac=1.0, jitter01=None,
     rays: dict origins, directions, viewdirs [N,3], radii, near, far [N,1].  jitter01: None (deterministic) or a
     list of num_levels arrays [N,1] in [0,1) replacing the per-level jax.random.uniform of stepfun.sample.
     Returns (renderings, ray_history) like upstream."""
-    basis = generate_basis() if basis is None else basis
+    basis = pos_basis_t() if basis is None else basis
     _, s_to_t = construct_ray_warps(raydist_fn, rays['near'], rays['far'])
     s_near, s_far = 0., 1.
     sdist = np.concatenate([np.full_like(rays['near'], s_near), np.full_like(rays['far'], s_far)], -1)
