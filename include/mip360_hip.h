@@ -1,0 +1,106 @@
+/* mip360_hip.h -- C ABI of libmip360_hip.so: the MI355X (gfx950) kernels of the MipNeRF-360 depth-supervised path
+ * of cwchenwang/outdoor-nerf-depth (BASELINE config 5; nerf-methods/mipnerf360, JAX upstream).
+ *
+ * Upstream has no FFI: the path is jitted JAX inside internal/models.py (Model.__call__ :76-303, MLP.__call__
+ * :436-606), internal/{stepfun,coord,render}.py and internal/train_utils.py (:72-169).  Each entry point names the
+ * upstream lines it replaces.  Conventions as in nerfpp_hip.h: plain C, raw DEVICE pointers (float32 unless stated),
+ * a `void* stream` (hipStream_t), return MIP360_OK or an error code with mip360_last_error(); the library is
+ * stateless and the caller owns every buffer.  Network / sampler shape = configs/360.gin (the configuration
+ * scripts/train_kitti.sh uses): 2 proposal levels x 64 samples (PropMLP 4 x 256) + 1 NeRF level x 32 samples
+ * (NerfMLP 8 x 1024, bottleneck 256, view branch 128), warp = contract, raydist = reciprocal, opaque background,
+ * icosahedron-2 basis (21 directions), IPE degrees [0, 12).
+ */
+#ifndef MIP360_HIP_H
+#define MIP360_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIP360_ABI_VERSION 1
+#define MIP360_OK 0
+#define MIP360_ERR_ARG 1
+#define MIP360_ERR_HIP 2
+
+#define MIP360_N_BASIS 21          /* geopoly.generate_basis('icosahedron', 2) */
+#define MIP360_IPE_DIM 504         /* 21 * 2 * 12 */
+#define MIP360_IPE_LD 512          /* row stride of the encoded-sample tensor (zero padded) */
+#define MIP360_MAX_BINS 128        /* bins of a step function handed to mip360_resample */
+#define MIP360_MAX_SAMPLES 64      /* samples per ray per level */
+
+const char* mip360_last_error(void);
+int mip360_abi_version(void);
+
+/* One sampling level of Model.__call__ (models.py:158-208):
+ *   max_dilate_weights(sdist, weights, dilation, domain, renormalize=True)[1:-1]      stepfun.py:100-130
+ *   logits = where(s[1:] > s[:-1], anneal * log(w + resample_padding), -inf)          models.py:179-183
+ *   sdist' = sample_intervals(rng, sdist, logits, num_samples, single_jitter=True, domain)   stepfun.py:166-270
+ *   tdist' = s_to_t(sdist')  with raydist_fn = reciprocal                             coord.py:63-100
+ * sdist_in [n, m_in+1], weights_in [n, m_in]; dilation <= 0 skips the dilation (level 0, where m_in = 1).
+ * jitter01 [n] in [0,1) replaces jax.random.uniform (one value per ray: single_jitter); NULL = deterministic.
+ * Outputs sdist_out, tdist_out [n, num_samples+1]. */
+int mip360_resample(void* stream, int n_rays, int m_in, const float* sdist_in, const float* weights_in,
+                    float dilation, float anneal, float resample_padding, int num_samples,
+                    const float* jitter01, float s_near, float s_far, const float* t_near,
+                    const float* t_far, float* sdist_out, float* tdist_out);
+
+/* Featurise the conical frustums of one level (models.py:213-226 + MLP.predict_density :449-456):
+ *   cast_rays(tdist, o, d, radii, 'cone', diag=False)        render.py:45-82,108-133
+ *   track_linearize(contract, means, covs)                    coord.py:21-27,39-60
+ *   lift_and_diagonalize(., ., basis)                         coord.py:131-135
+ *   integrated_pos_enc(., ., 0, 12)                           coord.py:103-128
+ * tdist [n, S+1]; origins, directions [n,3]; radii [n]; basis_t [3, 21] row-major.
+ * enc [n*S, ld]: float32 (out_bf16 = 0) or bfloat16 (out_bf16 = 1), columns 504..ld-1 zero-filled. */
+int mip360_cast_encode(void* stream, int n_rays, int n_samples, const float* tdist,
+                       const float* origins, const float* directions, const float* radii,
+                       const float* basis_t, void* enc, int out_bf16, int ld);
+
+/* compute_alpha_weights (render.py:136-158) + volumetric_rendering (render.py:161-216: rgb, acc, distance_mean,
+ * depth; the percentile outputs are not produced).  density [n,S], rgb_samples [n,S,3] or NULL (proposal levels),
+ * tdist [n,S+1], directions [n,3].  Outputs may be NULL except weights. */
+int mip360_render_level(void* stream, int n_rays, int n_samples, const float* density,
+                        const float* rgb_samples, const float* tdist, const float* directions,
+                        int opaque_background, float bg_rgb, float* weights, float* rgb, float* acc,
+                        float* distance_mean, float* depth);
+
+/* backward of the above (upstream: jax autograd): given dL/d weights [n,S] (interlevel / distortion / kl terms,
+ * may be NULL), dL/d rgb [n,3] (may be NULL) and dL/d distance_mean [n] (may be NULL), writes dL/d density [n,S]
+ * and dL/d rgb_samples [n,S,3] (NULL for proposal levels). */
+int mip360_render_level_backward(void* stream, int n_rays, int n_samples, const float* density,
+                                 const float* rgb_samples, const float* tdist, const float* directions,
+                                 int opaque_background, float bg_rgb, const float* g_weights,
+                                 const float* g_rgb, const float* g_distance_mean, float* g_density,
+                                 float* g_rgb_samples);
+
+/* Loss terms of one training step with their gradients (train_utils.py:72-169, loss_fn :258-300):
+ *   data term of the NeRF level: charb (sqrt(resid^2 + charb_padding^2)) or mse, mean over [n,3]   :82-107
+ *   depth term on `distance_mean`: 'mse' ((m dm - m sup)^2).mean() or 'l1', m = sup > 0, averaged over ALL rays;
+ *     weighted lambda_depth and -- as upstream adds stats['loss_disp_mse'] to the total a second time (:268-269) --
+ *     depth_weight = 2 reproduces the reference's effective weight, 1 the documented one               :108-146
+ *   interlevel loss: mean lossfun_outer(c, w, c_prop, w_prop) per proposal level (gradient to w_prop only)  :149-160
+ *   distortion loss: distortion_mult * mean lossfun_distortion(c, w)                                   :163-169
+ * sdist_nerf [n,Sn+1], w_nerf [n,Sn]; per proposal level k < n_prop: sdist_prop[k] [n,Sp+1], w_prop[k] [n,Sp].
+ * scalars[5] = {total, data, depth (unweighted), interlevel, distortion}.  Gradients: g_rgb [n,3],
+ * g_distance_mean [n], g_w_nerf [n,Sn], g_w_prop[k] [n,Sp].  depth_loss_type: 0 none, 1 mse, 2 l1. */
+int mip360_losses(void* stream, int n_rays, int s_nerf, int s_prop, int n_prop, const float* rgb,
+                  const float* rgb_gt, const float* distance_mean, const float* depth_sup,
+                  const float* sdist_nerf, const float* w_nerf, const float* const* sdist_prop,
+                  const float* const* w_prop, int charb, float charb_padding, float data_loss_mult,
+                  int depth_loss_type, float lambda_depth, float depth_weight, float interlevel_mult,
+                  float distortion_mult, float* scalars, float* g_rgb, float* g_distance_mean,
+                  float* g_w_nerf, float* const* g_w_prop, float* workspace /* >= 4 * n_rays floats */);
+
+/* One dense layer on the matrix cores: C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]), bf16 operands (row-major, K
+ * contiguous, leading dimensions lda / ldw in elements, multiples of 8), float32 accumulation
+ * (v_mfma_f32_32x32x16_bf16).  Replaces flax nn.Dense + nn.relu in MLP.__call__ (models.py:436-606).
+ * K must be a multiple of 32 (pad with zeros); M, N arbitrary.  act: 0 none, 1 relu.  Either output may be NULL:
+ * c_bf16 [M, ldc] bfloat16, c_f32 [M, ldc32] float32. */
+int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
+                       const float* bias, int act, void* c_bf16, int ldc, float* c_f32, int ldc32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIP360_HIP_H */
