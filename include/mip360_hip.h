@@ -76,29 +76,44 @@ int mip360_render_level_backward(void* stream, int n_rays, int n_samples, const 
 
 /* Loss terms of one training step with their gradients (train_utils.py:72-169, loss_fn :258-300):
  *   data term of the NeRF level: charb (sqrt(resid^2 + charb_padding^2)) or mse, mean over [n,3]   :82-107
- *   depth term on `distance_mean`: 'mse' ((m dm - m sup)^2).mean() or 'l1', m = sup > 0, averaged over ALL rays;
- *     weighted lambda_depth and -- as upstream adds stats['loss_disp_mse'] to the total a second time (:268-269) --
- *     depth_weight = 2 reproduces the reference's effective weight, 1 the documented one               :108-146
+ *   depth term on `distance_mean`: 'mse' ((m dm - m sup)^2).mean() or 'l1', m = sup > 0, averaged over ALL rays :108-119.
+ *     Upstream counts it twice: inside the data loss, data_loss_mult * lambda_depth * depth[nerf level] (:136-139, the
+ *     coarse levels carry data_coarse_loss_mult = 0), and again as stats['loss_disp_mse'] = lambda_depth * sum over
+ *     ALL levels (:143, added to the total at :268-269).  depth_weight multiplies lambda_depth for the NeRF level
+ *     (reference: 2 = 1 + 1), prop_depth_weight for the proposal levels' distance_mean (reference: 1; dm_prop NULL
+ *     or weight 0 drops them).
  *   interlevel loss: mean lossfun_outer(c, w, c_prop, w_prop) per proposal level (gradient to w_prop only)  :149-160
  *   distortion loss: distortion_mult * mean lossfun_distortion(c, w)                                   :163-169
  * sdist_nerf [n,Sn+1], w_nerf [n,Sn]; per proposal level k < n_prop: sdist_prop[k] [n,Sp+1], w_prop[k] [n,Sp].
- * scalars[5] = {total, data, depth (unweighted), interlevel, distortion}.  Gradients: g_rgb [n,3],
- * g_distance_mean [n], g_w_nerf [n,Sn], g_w_prop[k] [n,Sp].  depth_loss_type: 0 none, 1 mse, 2 l1. */
+ * scalars[6] = {total, data, depth of the NeRF level (unweighted), interlevel, distortion, sum of the proposal
+ * levels' depth terms (unweighted)}.  Gradients: g_rgb [n,3], g_distance_mean [n], g_w_nerf [n,Sn],
+ * g_w_prop[k] [n,Sp], g_dm_prop[k] [n].  depth_loss_type: 0 none, 1 mse, 2 l1.  workspace >= (4 + n_prop) * n floats. */
 int mip360_losses(void* stream, int n_rays, int s_nerf, int s_prop, int n_prop, const float* rgb,
                   const float* rgb_gt, const float* distance_mean, const float* depth_sup,
                   const float* sdist_nerf, const float* w_nerf, const float* const* sdist_prop,
                   const float* const* w_prop, int charb, float charb_padding, float data_loss_mult,
                   int depth_loss_type, float lambda_depth, float depth_weight, float interlevel_mult,
                   float distortion_mult, float* scalars, float* g_rgb, float* g_distance_mean,
-                  float* g_w_nerf, float* const* g_w_prop, float* workspace /* >= 4 * n_rays floats */);
+                  float* g_w_nerf, float* const* g_w_prop, float* workspace, float prop_depth_weight,
+                  const float* const* dm_prop, float* const* g_dm_prop);
 
 /* One dense layer on the matrix cores: C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]), bf16 operands (row-major, K
  * contiguous, leading dimensions lda / ldw in elements, multiples of 8), float32 accumulation
  * (v_mfma_f32_32x32x16_bf16).  Replaces flax nn.Dense + nn.relu in MLP.__call__ (models.py:436-606).
- * K must be a multiple of 32 (pad with zeros); M, N arbitrary.  act: 0 none, 1 relu.  Either output may be NULL:
- * c_bf16 [M, ldc] bfloat16, c_f32 [M, ldc32] float32. */
+ * K must be a multiple of 32 (pad with zeros); M, N arbitrary.  act: 0 none, 1 relu, 2 softplus(v + act_param) (the
+ * density head: density_activation(raw + density_bias), models.py:497), 3 sigmoid(v) * (1 + 2 act_param) - act_param
+ * (the colour head with rgb_padding, models.py:573-594).  Either output may be NULL: c_bf16 [M, ldc] bfloat16,
+ * c_f32 [M, ldc32] float32. */
 int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
-                       const float* bias, int act, void* c_bf16, int ldc, float* c_f32, int ldc32);
+                       const float* bias, int act, float act_param, void* c_bf16, int ldc, float* c_f32,
+                       int ldc32);
+
+/* View-direction encoding of the NerfMLP's second stage (models.py:395-399,548-553): pos_enc(viewdirs, 0, 4,
+ * append_identity=True) = 27 values per ray, broadcast over the ray's samples into columns [col0, col0 + 27) of a
+ * bfloat16 [n*S, ld] tensor (the bottleneck GEMM writes columns [0, 256) of the same rows); columns up to
+ * col0 + width are zero-filled (K padding of the next layer). */
+int mip360_dir_encode(void* stream, int n_rays, int n_samples, const float* viewdirs, void* out_bf16, int ld,
+                      int col0, int width);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,14 @@ SOURCES = {
     'nerfpp_api.hip': [],
 }
 HEADERS = ['nerfpp_common.h', 'nerfpp_kernels.h', os.path.join('..', '..', 'include', 'nerfpp_hip.h')]
+# SURVEY 8 f-4 (MipNeRF-360 path): its own shared object and C ABI (include/mip360_hip.h)
+OUT_MIP360 = os.path.join(PKG, 'libmip360_hip.so')
+SOURCES_MIP360 = {
+    'mip360_kernels.hip': ['-ffp-contract=off'],    # arithmetic order of the oracle
+    'mip360_gemm.hip': [],
+    'mip360_api.hip': [],
+}
+HEADERS_MIP360 = [os.path.join('..', '..', 'include', 'mip360_hip.h')]
 
 
 def _stale(target, deps):
@@ -32,9 +40,9 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, flags):
+def _compile(src, flags, headers=None):
     obj = os.path.join(OBJ, src.replace('.hip', '.o'))
-    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + [__file__]
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in (headers or HEADERS)] + [__file__]
     if _stale(obj, deps):
         cmd = [HIPCC] + COMMON + flags + ['-c', os.path.join(HERE, src), '-o', obj]
         subprocess.check_call(cmd)
@@ -48,8 +56,11 @@ def build(force=False):
             os.remove(os.path.join(OBJ, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(lambda kv: _compile(*kv), SOURCES.items()))
+        objs2 = list(ex.map(lambda kv: _compile(kv[0], kv[1], HEADERS_MIP360), SOURCES_MIP360.items()))
     if force or _stale(OUT, objs):
         subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    if force or _stale(OUT_MIP360, objs2):
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT_MIP360] + objs2)
     return OUT
 
 

@@ -1,0 +1,131 @@
+// extern "C" entry points of libmip360_hip.so (declared in include/mip360_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/mip360_hip.h"
+
+void mip360_launch_resample(hipStream_t st, int n, int m_in, const float* sd, const float* w, float dil, float anneal,
+                            float pad, int ns, const float* jit, float s_near, float s_far, const float* tn,
+                            const float* tf, float* sd_out, float* td_out);
+void mip360_launch_cast_encode(hipStream_t st, int n, int S, const float* td, const float* o, const float* d,
+                               const float* radii, const float* basis_t, void* enc, int bf16, int ld);
+void mip360_launch_render(hipStream_t st, int n, int S, const float* density, const float* rgbs, const float* td,
+                          const float* dirs, int opaque, float bg, float* w, float* rgb, float* acc, float* dm, float* depth);
+void mip360_launch_render_bwd(hipStream_t st, int n, int S, const float* density, const float* rgbs, const float* td,
+                              const float* dirs, int opaque, float bg, const float* g_w, const float* g_rgb,
+                              const float* g_dm, float* g_density, float* g_rgbs);
+void mip360_launch_losses(hipStream_t st, int n, int s_nerf, int s_prop, int n_prop, const float* rgb, const float* rgb_gt,
+                          const float* dm, const float* sup, const float* sd_nerf, const float* w_nerf,
+                          const float* const* sd_prop, const float* const* w_prop, int charb, float charb_pad,
+                          float data_mult, int depth_type, float lambda_depth, float depth_weight, float inter_mult,
+                          float dist_mult, float* scalars, float* g_rgb, float* g_dm, float* g_w_nerf,
+                          float* const* g_w_prop, float* ws, float prop_depth_weight, const float* const* dm_prop,
+                          float* const* g_dm_prop);
+void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
+                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32);
+void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width);
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MIP360_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return MIP360_OK;
+}
+#define REQUIRE(cond, what) \
+  do { if (!(cond)) return fail(MIP360_ERR_ARG, "%s: requirement failed: %s", __func__, what); } while (0)
+}  // namespace
+
+extern "C" {
+
+const char* mip360_last_error(void) { return g_err; }
+int mip360_abi_version(void) { return MIP360_ABI_VERSION; }
+
+int mip360_resample(void* stream, int n_rays, int m_in, const float* sdist_in, const float* weights_in, float dilation,
+                    float anneal, float resample_padding, int num_samples, const float* jitter01, float s_near,
+                    float s_far, const float* t_near, const float* t_far, float* sdist_out, float* tdist_out) {
+  REQUIRE(n_rays > 0 && m_in >= 1 && m_in <= MIP360_MAX_BINS, "1 <= m_in <= 128");
+  REQUIRE(num_samples >= 2 && num_samples <= MIP360_MAX_SAMPLES, "2 <= num_samples <= 64");
+  REQUIRE(sdist_in && weights_in && t_near && t_far && sdist_out && tdist_out, "non-null pointers");
+  mip360_launch_resample((hipStream_t)stream, n_rays, m_in, sdist_in, weights_in, dilation, anneal, resample_padding,
+                         num_samples, jitter01, s_near, s_far, t_near, t_far, sdist_out, tdist_out);
+  return check_launch("resample");
+}
+
+int mip360_cast_encode(void* stream, int n_rays, int n_samples, const float* tdist, const float* origins,
+                       const float* directions, const float* radii, const float* basis_t, void* enc, int out_bf16, int ld) {
+  REQUIRE(n_rays > 0 && n_samples >= 1 && ld >= MIP360_IPE_DIM, "sizes, ld >= 504");
+  REQUIRE(tdist && origins && directions && radii && basis_t && enc, "non-null pointers");
+  mip360_launch_cast_encode((hipStream_t)stream, n_rays, n_samples, tdist, origins, directions, radii, basis_t, enc,
+                            out_bf16, ld);
+  return check_launch("cast_encode");
+}
+
+int mip360_render_level(void* stream, int n_rays, int n_samples, const float* density, const float* rgb_samples,
+                        const float* tdist, const float* directions, int opaque_background, float bg_rgb, float* weights,
+                        float* rgb, float* acc, float* distance_mean, float* depth) {
+  REQUIRE(n_rays > 0 && n_samples >= 1 && n_samples <= MIP360_MAX_SAMPLES, "1 <= n_samples <= 64");
+  REQUIRE(density && tdist && directions && weights, "non-null pointers");
+  mip360_launch_render((hipStream_t)stream, n_rays, n_samples, density, rgb_samples, tdist, directions, opaque_background,
+                       bg_rgb, weights, rgb, acc, distance_mean, depth);
+  return check_launch("render_level");
+}
+
+int mip360_render_level_backward(void* stream, int n_rays, int n_samples, const float* density, const float* rgb_samples,
+                                 const float* tdist, const float* directions, int opaque_background, float bg_rgb,
+                                 const float* g_weights, const float* g_rgb, const float* g_distance_mean,
+                                 float* g_density, float* g_rgb_samples) {
+  REQUIRE(n_rays > 0 && n_samples >= 1 && n_samples <= MIP360_MAX_SAMPLES, "1 <= n_samples <= 64");
+  REQUIRE(density && tdist && directions && g_density, "non-null pointers");
+  mip360_launch_render_bwd((hipStream_t)stream, n_rays, n_samples, density, rgb_samples, tdist, directions,
+                           opaque_background, bg_rgb, g_weights, g_rgb, g_distance_mean, g_density, g_rgb_samples);
+  return check_launch("render_level_backward");
+}
+
+int mip360_losses(void* stream, int n_rays, int s_nerf, int s_prop, int n_prop, const float* rgb, const float* rgb_gt,
+                  const float* distance_mean, const float* depth_sup, const float* sdist_nerf, const float* w_nerf,
+                  const float* const* sdist_prop, const float* const* w_prop, int charb, float charb_padding,
+                  float data_loss_mult, int depth_loss_type, float lambda_depth, float depth_weight, float interlevel_mult,
+                  float distortion_mult, float* scalars, float* g_rgb, float* g_distance_mean, float* g_w_nerf,
+                  float* const* g_w_prop, float* workspace, float prop_depth_weight, const float* const* dm_prop,
+                  float* const* g_dm_prop) {
+  REQUIRE(n_rays > 0 && s_nerf >= 1 && s_nerf <= MIP360_MAX_SAMPLES && s_prop >= 1 && s_prop <= MIP360_MAX_SAMPLES, "sizes");
+  REQUIRE(n_prop >= 0 && n_prop <= 4, "0 <= n_prop <= 4");
+  REQUIRE(rgb && rgb_gt && sdist_nerf && w_nerf && scalars && g_rgb && g_distance_mean && g_w_nerf && workspace, "pointers");
+  REQUIRE(depth_loss_type >= 0 && depth_loss_type <= 2, "depth_loss_type in 0..2");
+  if (depth_loss_type) REQUIRE(distance_mean && depth_sup, "depth term needs distance_mean and depth_sup");
+  for (int k = 0; k < n_prop; ++k) REQUIRE(sdist_prop && w_prop && g_w_prop && sdist_prop[k] && w_prop[k] && g_w_prop[k], "proposal arrays");
+  if (dm_prop) for (int k = 0; k < n_prop; ++k) REQUIRE(!dm_prop[k] || (g_dm_prop && g_dm_prop[k]), "g_dm_prop for every dm_prop");
+  mip360_launch_losses((hipStream_t)stream, n_rays, s_nerf, s_prop, n_prop, rgb, rgb_gt, distance_mean, depth_sup, sdist_nerf,
+                       w_nerf, sdist_prop, w_prop, charb, charb_padding, data_loss_mult, depth_loss_type, lambda_depth,
+                       depth_weight, interlevel_mult, distortion_mult, scalars, g_rgb, g_distance_mean, g_w_nerf, g_w_prop,
+                       workspace, prop_depth_weight, dm_prop, g_dm_prop);
+  return check_launch("losses");
+}
+
+int mip360_dir_encode(void* stream, int n_rays, int n_samples, const float* viewdirs, void* out_bf16, int ld, int col0,
+                      int width) {
+  REQUIRE(n_rays > 0 && n_samples >= 1 && viewdirs && out_bf16, "non-null pointers");
+  REQUIRE(width >= 27 && col0 >= 0 && col0 + width <= ld, "27 <= width, col0 + width <= ld");
+  mip360_launch_dir_encode((hipStream_t)stream, n_rays, n_samples, viewdirs, out_bf16, ld, col0, width);
+  return check_launch("dir_encode");
+}
+
+int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw, const float* bias,
+                       int act, float act_param, void* c_bf16, int ldc, float* c_f32, int ldc32) {
+  REQUIRE(m > 0 && n > 0 && k > 0 && k % 32 == 0, "k must be a positive multiple of 32");
+  REQUIRE(a && w && (c_bf16 || c_f32), "non-null operands, at least one output");
+  REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k, "leading dimensions: multiples of 8, >= k");
+  REQUIRE(act >= 0 && act <= 3, "act in 0..3");
+  mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, bias, act, act_param, c_bf16, ldc, c_f32, ldc32);
+  return check_launch("linear_bf16");
+}
+
+}  // extern "C"

@@ -1,0 +1,636 @@
+// MipNeRF-360 ray-side kernels for gfx950: proposal resampling, conical-frustum featurisation
+// (cast -> contract -> lift -> IPE), alpha compositing forward / backward, and the loss terms with their
+// gradients.  All float32, HBM / latency bound, one wave per ray (the NeRF++ compositing design re-used).
+// Compiled with -ffp-contract=off so the arithmetic order is the oracle's (oracle/mip360_oracle.py).
+//
+// Upstream lines (nerf-methods/mipnerf360/internal/): stepfun.py:30-283, coord.py:21-135, render.py:21-216,
+// models.py:158-226, train_utils.py:72-169.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/mip360_hip.h"
+
+namespace mip360 {
+
+constexpr float EPS = 1.1920928955078125e-07f;        // jnp.finfo(float32).eps
+constexpr float EPS2 = EPS * EPS;
+constexpr int MAXE = 3 * MIP360_MAX_BINS + 1;          // edges after dilation
+constexpr int RPB = 4;                                  // rays per 256-thread block (one wave each)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ float wave_incl_sum(float x, int lane) {
+  float v = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_excl_suffix_sum(float x, int lane) {
+  float v = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_down(v, d, 64);
+    if (lane + d < 64) v += t;
+  }
+  const float e = __shfl_down(v, 1, 64);
+  return lane == 63 ? 0.f : e;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// One sampling level: dilate -> anneal -> softmax -> cdf -> sample_intervals -> s_to_t.   models.py:158-208
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resample_kernel(
+    int n, int m_in, const float* __restrict__ sdist_in, const float* __restrict__ w_in, float dilation, float anneal,
+    float padding, int ns, const float* __restrict__ jitter01, float s_near, float s_far,
+    const float* __restrict__ t_near, const float* __restrict__ t_far, float* __restrict__ sdist_out,
+    float* __restrict__ tdist_out) {
+  __shared__ float s_t[RPB][MAXE + 3];        // edges of the (dilated) step function
+  __shared__ float s_w[RPB][MAXE + 3];        // bin values: pdf, then weights, then softmax weights
+  __shared__ float s_a[RPB][MAXE + 3];        // scratch: unsorted edges / cdf
+  __shared__ float s_c[RPB][MIP360_MAX_SAMPLES + 2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wave;
+  if (ray >= n) return;                         // whole wave exits together; no block-level barrier below
+  float* t = s_t[wave];
+  float* w = s_w[wave];
+  float* a = s_a[wave];
+  float* c = s_c[wave];
+  const float* ti = sdist_in + (size_t)ray * (m_in + 1);
+  const float* wi = w_in + (size_t)ray * m_in;
+  int nb;                                       // bins of the step function that is sampled
+  if (dilation > 0.f) {
+    // max_dilate_weights (stepfun.py:100-130): p = w / max(eps^2, dt); t0 = t[:-1] - d, t1 = t[1:] + d
+    const int ne = 3 * m_in + 1;
+    for (int i = lane; i <= m_in; i += 64) a[i] = ti[i];
+    for (int i = lane; i < m_in; i += 64) {
+      a[m_in + 1 + i] = ti[i] - dilation;
+      a[2 * m_in + 1 + i] = ti[i + 1] + dilation;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < ne; e += 64) {       // rank sort (values only)
+      const float v = a[e];
+      int rank = 0;
+      for (int k = 0; k < ne; ++k) {
+        const float o = a[k];
+        rank += (o < v || (o == v && k < e)) ? 1 : 0;
+      }
+      t[rank] = fminf(fmaxf(v, s_near), s_far);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float part = 0.f;
+    for (int k = lane; k < ne - 1; k += 64) {   // max-pool of the pdf over the dilated supports
+      const float tk = t[k];
+      float p = 0.f;
+      for (int i = 0; i < m_in; ++i) {
+        const float lo = ti[i] - dilation, hi = ti[i + 1] + dilation;
+        const float pi = wi[i] / fmaxf(EPS2, ti[i + 1] - ti[i]);
+        p = (lo <= tk && hi > tk) ? fmaxf(p, pi) : p;
+      }
+      const float wd = p * (t[k + 1] - tk);
+      w[k] = wd;
+      part += wd;
+    }
+    const float tot = fmaxf(EPS2, wave_sum(part));
+    __builtin_amdgcn_wave_barrier();
+    // renormalise and trim [1:-1] (models.py:172-173): edges 1..ne-2, bins 1..ne-3
+    nb = ne - 3;
+    for (int k = lane; k < nb; k += 64) a[k] = w[k + 1] / tot;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < nb; k += 64) w[k] = a[k];
+    for (int k = lane; k <= nb; k += 64) a[k] = t[k + 1];
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k <= nb; k += 64) t[k] = a[k];
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    nb = m_in;
+    for (int i = lane; i <= m_in; i += 64) t[i] = ti[i];
+    for (int i = lane; i < m_in; i += 64) w[i] = wi[i];
+    __builtin_amdgcn_wave_barrier();
+  }
+  // logits (models.py:179-183) and softmax (stepfun.py:158)
+  float mx = -INFINITY;
+  for (int k = lane; k < nb; k += 64) {
+    const float l = t[k + 1] > t[k] ? anneal * logf(w[k] + padding) : -INFINITY;
+    a[k] = l;
+    mx = fmaxf(mx, l);
+  }
+  mx = wave_max(mx);
+  float part = 0.f;
+  for (int k = lane; k < nb; k += 64) {
+    const float e = expf(a[k] - mx);
+    a[k] = e;
+    part += e;
+  }
+  const float tot = wave_sum(part);
+  __builtin_amdgcn_wave_barrier();
+  // integrate_weights (stepfun.py:133-152): cw0 = [0, min(1, cumsum(w[:-1])), 1]; sequential float32 like numpy
+  if (lane == 0) {
+    float run = 0.f;
+    w[0] = 0.f;
+    for (int k = 0; k < nb - 1; ++k) {
+      run += a[k] / tot;
+      w[k + 1] = fminf(1.f, run);
+    }
+    w[nb] = 1.f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // uniform positions (stepfun.py:195-213) in double like np.linspace, then invert_cdf by sorted_interp
+  const double eps = (double)EPS;
+  for (int k = lane; k < ns; k += 64) {
+    double u;
+    if (jitter01) {
+      const double u_max = eps + (1.0 - eps) / ns;
+      const double max_jitter = (1.0 - u_max) / (ns - 1) - eps;
+      const double step = (1.0 - u_max) / (ns - 1);
+      u = (double)k * step + (double)jitter01[ray] * max_jitter;
+    } else {
+      const double pad = 1.0 / (2 * ns);
+      const double step = ((1.0 - pad - eps) - pad) / (ns - 1);
+      u = pad + (double)k * step;
+    }
+    const float uf = (float)u;
+    // last edge with cw0 <= u and first edge with cw0 > u (cw0 and t are non-decreasing)
+    int lo = 0, hi = nb;
+    bool any_lt = false;
+    for (int i = 0; i <= nb; ++i) {
+      const bool ge = uf >= w[i];
+      lo = ge ? i : lo;
+      if (!ge && !any_lt) { hi = i; any_lt = true; }
+    }
+    const float xp0 = w[lo], xp1 = w[hi], fp0 = t[lo], fp1 = t[hi];
+    float off = (uf - xp0) / (xp1 - xp0);
+    off = isnan(off) ? 0.f : off;
+    off = fminf(fmaxf(off, 0.f), 1.f);
+    c[k] = fp0 + off * (fp1 - fp0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // sample_intervals (stepfun.py:253-270) + s_to_t for the reciprocal warp (coord.py:93-99)
+  const float sn = 1.f / t_near[ray], sf = 1.f / t_far[ray];
+  for (int k = lane; k <= ns; k += 64) {
+    float s;
+    if (k == 0) s = fmaxf(s_near, 2.f * c[0] - (c[1] + c[0]) / 2.f);
+    else if (k == ns) s = fminf(s_far, 2.f * c[ns - 1] - (c[ns - 1] + c[ns - 2]) / 2.f);
+    else s = (c[k] + c[k - 1]) / 2.f;
+    sdist_out[(size_t)ray * (ns + 1) + k] = s;
+    tdist_out[(size_t)ray * (ns + 1) + k] = 1.f / (s * sf + (1.f - s) * sn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cast_rays (cone, full covariance) -> contract (mean + Jacobian) -> lift onto the basis -> IPE.
+// One thread per (sample row, basis direction): 21 threads per row, 3 rows per wave.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float safe_sin(float x) {      // math.py:26-38 with np.mod semantics
+  const float t = 314.15927f;                                // float32(100 pi)
+  if (fabsf(x) >= t) {
+    x = x - floorf(x / t) * t;
+  }
+  return sinf(x);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void cast_encode_kernel(
+    int n, int S, const float* __restrict__ tdist, const float* __restrict__ origins,
+    const float* __restrict__ directions, const float* __restrict__ radii, const float* __restrict__ basis_t,
+    void* __restrict__ enc, int ld) {
+  const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / MIP360_N_BASIS, j = lane - sub * MIP360_N_BASIS;
+  const int64_t row = (int64_t)wave_g * 3 + sub;
+  const int64_t rows = (int64_t)n * S;
+  if (sub >= 3 || row >= rows) return;
+  const int ray = (int)(row / S), smp = (int)(row - (int64_t)ray * S);
+  const float t0 = tdist[(size_t)ray * (S + 1) + smp], t1 = tdist[(size_t)ray * (S + 1) + smp + 1];
+  const float d[3] = {directions[ray * 3], directions[ray * 3 + 1], directions[ray * 3 + 2]};
+  const float o[3] = {origins[ray * 3], origins[ray * 3 + 1], origins[ray * 3 + 2]};
+  const float br = radii[ray];
+  // conical_frustum_to_gaussian, stable form (render.py:64-73)
+  const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
+  const float denom = fmaxf(EPS, 3.f * mu * mu + hw * hw);
+  const float t_mean = mu + (2.f * mu * hw * hw) / denom;
+  const float hw4 = hw * hw * hw * hw;
+  const float t_var = (hw * hw) / 3.f - (4.f / 15.f) * hw4 * (12.f * mu * mu - hw * hw) / (denom * denom);
+  float r_var = (mu * mu) / 4.f + (5.f / 12.f) * hw * hw - (4.f / 15.f) * hw4 / denom;
+  r_var *= br * br;
+  // lift_gaussian, diag = False (render.py:21-42)
+  const float dms = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  float mean[3], cov[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mean[a] = d[a] * t_mean + o[a];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float d_outer = d[a] * d[b];
+      const float null_outer = (a == b ? 1.f : 0.f) - d[a] * (d[b] / dms);
+      cov[a][b] = t_var * d_outer + r_var * null_outer;
+    }
+  }
+  // contract + its Jacobian (coord.py:21-27, track_linearize :39-60)
+  const float m2 = fmaxf(EPS, mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+  float cm[3], J[3][3];
+  if (m2 <= 1.f) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      cm[a] = mean[a];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) J[a][b] = a == b ? 1.f : 0.f;
+    }
+  } else {
+    const float r = sqrtf(m2);
+    const float s = (2.f * r - 1.f) / m2;
+    const float ds = (1.f - r) / (m2 * m2);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      cm[a] = s * mean[a];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) J[a][b] = (a == b ? s : 0.f) + 2.f * ds * mean[a] * mean[b];
+    }
+  }
+  // lift_and_diagonalize (coord.py:131-135): mean . b_j and b_j^T (J cov J^T) b_j = (J^T b_j)^T cov (J^T b_j)
+  const float bj[3] = {basis_t[j], basis_t[MIP360_N_BASIS + j], basis_t[2 * MIP360_N_BASIS + j]};
+  const float lm = cm[0] * bj[0] + cm[1] * bj[1] + cm[2] * bj[2];
+  float v[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) v[b] = J[0][b] * bj[0] + J[1][b] * bj[1] + J[2][b] * bj[2];
+  float lv = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) lv += v[a] * (cov[a][0] * v[0] + cov[a][1] * v[1] + cov[a][2] * v[2]);
+  // integrated_pos_enc, degrees [0, 12) (coord.py:108-128): column k*21 + j = sin, 252 + k*21 + j = cos
+  constexpr int ND = 12, HALF = ND * MIP360_N_BASIS;
+#pragma unroll
+  for (int k = 0; k < ND; ++k) {
+    const float sc = (float)(1 << k);
+    const float sm = lm * sc, sv = lv * sc * sc;
+    const float damp = expf(-0.5f * sv);
+    const float es = damp * safe_sin(sm);
+    const float ec = damp * safe_sin(sm + 1.5707963267948966f);
+    if (BF16) {
+      __bf16* e = (__bf16*)enc + (size_t)row * ld;
+      e[k * MIP360_N_BASIS + j] = (__bf16)es;
+      e[HALF + k * MIP360_N_BASIS + j] = (__bf16)ec;
+    } else {
+      float* e = (float*)enc + (size_t)row * ld;
+      e[k * MIP360_N_BASIS + j] = es;
+      e[HALF + k * MIP360_N_BASIS + j] = ec;
+    }
+  }
+  for (int col = 2 * HALF + j; col < ld; col += MIP360_N_BASIS) {        // zero padding 504..ld-1
+    if (BF16) ((__bf16*)enc)[(size_t)row * ld + col] = (__bf16)0.f;
+    else ((float*)enc)[(size_t)row * ld + col] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// compute_alpha_weights + volumetric_rendering, S <= 64: lane = sample.                       render.py:136-216
+// ------------------------------------------------------------------------------------------------------------
+struct LevelRay {
+  float delta, dd, alpha, trans, w, tmid, acc, logexp, dm, t_first, t_last;
+  bool dm_clipped;
+};
+__device__ __forceinline__ LevelRay level_forward(int S, int lane, float density, const float* __restrict__ td,
+                                                  float dnorm, bool opaque) {
+  LevelRay r;
+  const bool ok = lane < S;
+  const float ta = ok ? td[lane] : 0.f, tb = ok ? td[lane + 1] : 0.f;
+  r.delta = (tb - ta) * dnorm;
+  r.dd = ok ? density * r.delta : 0.f;
+  if (opaque && lane == S - 1) r.dd = INFINITY;
+  r.alpha = ok ? 1.f - expf(-r.dd) : 0.f;
+  const float incl = wave_incl_sum((ok && !(opaque && lane == S - 1)) ? r.dd : 0.f, lane);
+  const float excl = incl - ((ok && !(opaque && lane == S - 1)) ? r.dd : 0.f);
+  r.trans = expf(-excl);
+  r.w = ok ? r.alpha * r.trans : 0.f;
+  r.tmid = 0.5f * (ta + tb);
+  r.acc = wave_sum(r.w);
+  const float lg = ok ? r.w * logf(r.tmid) : 0.f;
+  r.logexp = wave_sum(lg) / fmaxf(EPS, r.acc);
+  r.t_first = __shfl(ta, 0, 64);
+  r.t_last = __shfl(tb, S - 1, 64);
+  float e = expf(r.logexp);
+  e = isnan(e) ? INFINITY : e;
+  r.dm = fminf(fmaxf(e, r.t_first), r.t_last);
+  r.dm_clipped = !(e >= r.t_first && e <= r.t_last);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void render_level_kernel(
+    int n, int S, const float* __restrict__ density, const float* __restrict__ rgbs, const float* __restrict__ tdist,
+    const float* __restrict__ dirs, int opaque, float bg, float* __restrict__ weights, float* __restrict__ rgb,
+    float* __restrict__ acc, float* __restrict__ dmean, float* __restrict__ depth) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wave;
+  if (ray >= n) return;
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float dens = lane < S ? density[(size_t)ray * S + lane] : 0.f;
+  const LevelRay r = level_forward(S, lane, dens, tdist + (size_t)ray * (S + 1), dnorm, opaque != 0);
+  if (lane < S) weights[(size_t)ray * S + lane] = r.w;
+  const float bg_w = fmaxf(0.f, 1.f - r.acc);
+  if (rgbs && rgb) {
+    float c[3] = {0.f, 0.f, 0.f};
+    if (lane < S) {
+      const float* p = rgbs + ((size_t)ray * S + lane) * 3;
+      c[0] = r.w * p[0]; c[1] = r.w * p[1]; c[2] = r.w * p[2];
+    }
+    const float c0 = wave_sum(c[0]), c1 = wave_sum(c[1]), c2 = wave_sum(c[2]);
+    if (lane == 0) { rgb[ray * 3] = c0 + bg_w * bg; rgb[ray * 3 + 1] = c1 + bg_w * bg; rgb[ray * 3 + 2] = c2 + bg_w * bg; }
+  }
+  float dsum = wave_sum(lane < S ? r.w * r.tmid : 0.f);
+  dsum = isnan(dsum) ? INFINITY : dsum;
+  if (lane == 0) {
+    if (acc) acc[ray] = r.acc;
+    if (dmean) dmean[ray] = r.dm;
+    if (depth) depth[ray] = fminf(fmaxf(dsum, r.t_first), r.t_last);
+  }
+}
+
+__global__ __launch_bounds__(256) void render_level_bwd_kernel(
+    int n, int S, const float* __restrict__ density, const float* __restrict__ rgbs, const float* __restrict__ tdist,
+    const float* __restrict__ dirs, int opaque, float bg, const float* __restrict__ g_w_in,
+    const float* __restrict__ g_rgb, const float* __restrict__ g_dm, float* __restrict__ g_density,
+    float* __restrict__ g_rgbs) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wave;
+  if (ray >= n) return;
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const bool ok = lane < S;
+  const float dens = ok ? density[(size_t)ray * S + lane] : 0.f;
+  const LevelRay r = level_forward(S, lane, dens, tdist + (size_t)ray * (S + 1), dnorm, opaque != 0);
+  float gw = (ok && g_w_in) ? g_w_in[(size_t)ray * S + lane] : 0.f;
+  if (g_rgb && rgbs && ok) {
+    const float* p = rgbs + ((size_t)ray * S + lane) * 3;
+    const float g0 = g_rgb[ray * 3], g1 = g_rgb[ray * 3 + 1], g2 = g_rgb[ray * 3 + 2];
+    // rgb = sum_i w_i c_i + max(0, 1 - acc) bg
+    const float dbg = (1.f - r.acc > 0.f) ? -bg : 0.f;
+    gw += g0 * (p[0] + dbg) + g1 * (p[1] + dbg) + g2 * (p[2] + dbg);
+    if (g_rgbs) {
+      float* q = g_rgbs + ((size_t)ray * S + lane) * 3;
+      q[0] = r.w * g0; q[1] = r.w * g1; q[2] = r.w * g2;
+    }
+  } else if (g_rgbs && ok) {
+    float* q = g_rgbs + ((size_t)ray * S + lane) * 3;
+    q[0] = 0.f; q[1] = 0.f; q[2] = 0.f;
+  }
+  if (g_dm && ok && !r.dm_clipped && r.acc > EPS) {
+    // dm = exp(sum_i w_i log tmid_i / acc):  d dm / d w_i = dm (log tmid_i - E) / acc
+    gw += g_dm[ray] * r.dm * (logf(r.tmid) - r.logexp) / r.acc;
+  }
+  // d L / d x_i = g_i (1 - alpha_i) T_i - sum_{k>i} g_k w_k ; x = density * delta
+  const float gww = ok ? gw * r.w : 0.f;
+  const float suffix = wave_excl_suffix_sum(gww, lane);
+  float gx = gw * (1.f - r.alpha) * r.trans - suffix;
+  if (opaque && lane == S - 1) gx = 0.f;
+  if (ok) g_density[(size_t)ray * S + lane] = gx * r.delta;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// losses: per-ray partial sums + gradients (one wave per ray), then a fixed-order reduction by one workgroup.
+// workspace [4][n]: data, depth, interlevel, distortion partial sums per ray.
+// ------------------------------------------------------------------------------------------------------------
+struct LossArgs {
+  int n, s_nerf, s_prop, n_prop;
+  const float* rgb; const float* rgb_gt; const float* dm; const float* sup;
+  const float* sd_nerf; const float* w_nerf;
+  const float* sd_prop[4]; const float* w_prop[4];
+  int charb; float charb_pad, data_mult; int depth_type; float lambda_depth, depth_weight, inter_mult, dist_mult;
+  float prop_depth_weight; const float* dm_prop[4]; float* g_dm_prop[4];
+  float* g_rgb; float* g_dm; float* g_w_nerf; float* g_w_prop[4]; float* ws;
+};
+
+__global__ __launch_bounds__(256) void losses_ray_kernel(LossArgs a) {
+  __shared__ float s_c[RPB][MIP360_MAX_SAMPLES + 2];     // nerf edges
+  __shared__ float s_w[RPB][MIP360_MAX_SAMPLES + 2];     // nerf weights
+  __shared__ float s_tp[RPB][MIP360_MAX_SAMPLES + 2];    // proposal edges
+  __shared__ float s_cy[RPB][MIP360_MAX_SAMPLES + 2];    // cumulative proposal weights
+  __shared__ float s_go[RPB][MIP360_MAX_SAMPLES + 2];    // d loss / d w_outer per nerf interval
+  __shared__ int s_lo[RPB][MIP360_MAX_SAMPLES + 2], s_hi[RPB][MIP360_MAX_SAMPLES + 2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wave;
+  if (ray >= a.n) return;
+  const int n = a.n, Sn = a.s_nerf, Sp = a.s_prop;
+  float* c = s_c[wave]; float* w = s_w[wave]; float* tp = s_tp[wave]; float* cy = s_cy[wave]; float* go = s_go[wave];
+  int* lo = s_lo[wave]; int* hi = s_hi[wave];
+  // ---- data term (train_utils.py:82-107) and depth term (:108-119) ----
+  float data = 0.f;
+  if (lane < 3) {
+    const float resid = a.rgb[ray * 3 + lane] - a.rgb_gt[ray * 3 + lane];
+    const float denom = 3.f * (float)n;
+    if (a.charb) {
+      const float v = sqrtf(resid * resid + a.charb_pad * a.charb_pad);
+      data = v;
+      a.g_rgb[ray * 3 + lane] = a.data_mult * resid / v / denom;
+    } else {
+      data = resid * resid;
+      a.g_rgb[ray * 3 + lane] = a.data_mult * 2.f * resid / denom;
+    }
+  }
+  data = wave_sum(data);
+  float dep = 0.f;
+  if (lane == 0) {
+    float g = 0.f;
+    if (a.depth_type) {
+      const float sup = a.sup[ray];
+      const float m = sup > 0.f ? 1.f : 0.f;
+      const float diff = m * a.dm[ray] - m * sup;
+      const float k = a.data_mult * a.lambda_depth * a.depth_weight / (float)n;
+      if (a.depth_type == 1) { dep = diff * diff; g = k * 2.f * diff * m; }
+      else { dep = fabsf(diff); g = k * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * m; }
+    }
+    a.g_dm[ray] = g;
+    // the proposal levels' distance_mean enters only through stats['loss_disp_mse'] (train_utils.py:143, :268-269)
+    for (int k = 0; k < a.n_prop; ++k) {
+      if (!a.dm_prop[k]) continue;
+      float dk = 0.f, gk = 0.f;
+      if (a.depth_type) {
+        const float sup = a.sup[ray];
+        const float m = sup > 0.f ? 1.f : 0.f;
+        const float diff = m * a.dm_prop[k][ray] - m * sup;
+        const float kk = a.lambda_depth * a.prop_depth_weight / (float)n;
+        if (a.depth_type == 1) { dk = diff * diff; gk = kk * 2.f * diff * m; }
+        else { dk = fabsf(diff); gk = kk * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * m; }
+      }
+      a.g_dm_prop[k][ray] = gk;
+      a.ws[(4 + k) * n + ray] = dk;
+    }
+  }
+  // ---- distortion (stepfun.py:273-283) ----
+  for (int i = lane; i <= Sn; i += 64) c[i] = a.sd_nerf[(size_t)ray * (Sn + 1) + i];
+  for (int i = lane; i < Sn; i += 64) w[i] = a.w_nerf[(size_t)ray * Sn + i];
+  __builtin_amdgcn_wave_barrier();
+  float dist = 0.f;
+  if (lane < Sn) {
+    const float ut = (c[lane + 1] + c[lane]) / 2.f, wi = w[lane], dt = c[lane + 1] - c[lane];
+    float inner = 0.f;
+    for (int j = 0; j < Sn; ++j) inner += w[j] * fabsf(ut - (c[j + 1] + c[j]) / 2.f);
+    dist = wi * inner + wi * wi * dt / 3.f;
+    a.g_w_nerf[(size_t)ray * Sn + lane] = a.dist_mult * (2.f * inner + 2.f * wi * dt / 3.f) / (float)n;
+  }
+  dist = wave_sum(dist);
+  // ---- interlevel (stepfun.py:64-87, train_utils.py:149-160): gradient to the proposal weights only ----
+  float inter = 0.f;
+  for (int k = 0; k < a.n_prop; ++k) {
+    for (int i = lane; i <= Sp; i += 64) tp[i] = a.sd_prop[k][(size_t)ray * (Sp + 1) + i];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      float run = 0.f;
+      cy[0] = 0.f;
+      for (int i = 0; i < Sp; ++i) { run += a.w_prop[k][(size_t)ray * Sp + i]; cy[i + 1] = run; }
+    }
+    // searchsorted(t_env = tp, v = c): lo = last edge <= v (else 0), hi = first edge > v (else last)
+    for (int i = lane; i <= Sn; i += 64) {
+      const float v = c[i];
+      int l = 0, h = Sp;
+      bool found = false;
+      for (int e = 0; e <= Sp; ++e) {
+        const bool ge = v >= tp[e];
+        l = ge ? e : l;
+        if (!ge && !found) { h = e; found = true; }
+      }
+      lo[i] = l; hi[i] = h;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float term = 0.f;
+    if (lane < Sn) {
+      const float w_outer = cy[hi[lane + 1]] - cy[lo[lane]];
+      const float ex = fmaxf(0.f, w[lane] - w_outer);
+      term = ex * ex / (w[lane] + EPS);
+      go[lane] = -2.f * ex / (w[lane] + EPS);
+    }
+    inter += wave_sum(term);
+    __builtin_amdgcn_wave_barrier();
+    const float scale = a.inter_mult / ((float)n * (float)Sn);
+    for (int j = lane; j < Sp; j += 64) {
+      float g = 0.f;
+      for (int i = 0; i < Sn; ++i) g += (j >= lo[i] && j < hi[i + 1]) ? go[i] : 0.f;
+      a.g_w_prop[k][(size_t)ray * Sp + j] = scale * g;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    a.ws[ray] = data; a.ws[n + ray] = dep; a.ws[2 * n + ray] = inter; a.ws[3 * n + ray] = dist;
+  }
+}
+
+__global__ __launch_bounds__(1024) void losses_reduce_kernel(int n, int s_nerf, const float* __restrict__ ws, float data_mult,
+                                                             int depth_type, float lambda_depth, float depth_weight,
+                                                             float inter_mult, float dist_mult, int n_prop_dm,
+                                                             float prop_depth_weight, float* __restrict__ scalars) {
+  __shared__ double sh[5][1024];
+  double p[5] = {0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] += (double)ws[q * n + r];
+    for (int k = 0; k < n_prop_dm; ++k) p[4] += (double)ws[(4 + k) * n + r];
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] = p[q];
+  __syncthreads();
+  for (int d = blockDim.x >> 1; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float data = (float)(sh[0][0] / (3.0 * n));
+    const float dep = depth_type ? (float)(sh[1][0] / n) : 0.f;
+    const float inter = inter_mult * (float)(sh[2][0] / ((double)n * s_nerf));
+    const float dist = dist_mult * (float)(sh[3][0] / n);
+    const float dep_prop = depth_type ? (float)(sh[4][0] / n) : 0.f;
+    scalars[0] = data_mult * (data + lambda_depth * depth_weight * dep) + lambda_depth * prop_depth_weight * dep_prop + inter + dist;
+    scalars[1] = data; scalars[2] = dep; scalars[3] = inter; scalars[4] = dist; scalars[5] = dep_prop;
+  }
+}
+
+// pos_enc(viewdirs, 0, 4, append_identity=True) (coord.py:138-147, models.py:395-399) broadcast over the samples of a
+// ray into columns [col0, col0 + 27) of a bf16 [n*S, ld] tensor; columns up to col0 + width are zero-filled.
+__global__ void dir_encode_kernel(int n, int S, const float* __restrict__ viewdirs, __bf16* __restrict__ out, int ld,
+                                  int col0, int width) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = idx / width;
+  const int c = (int)(idx - row * width);
+  if (row >= (int64_t)n * S) return;
+  const int ray = (int)(row / S);
+  float v = 0.f;
+  if (c < 3) v = viewdirs[ray * 3 + c];
+  else if (c < 27) {
+    // four_feat = sin(concat([scaled_x, scaled_x + pi/2])): scaled_x index = k*3 + d
+    const int q = c - 3, half = q / 12, r = q - half * 12, k = r / 3, d = r - k * 3;
+    const float sx = viewdirs[ray * 3 + d] * (float)(1 << k);
+    v = sinf(half ? sx + 1.5707963267948966f : sx);
+  }
+  out[(size_t)row * ld + col0 + c] = (__bf16)v;
+}
+
+}  // namespace mip360
+
+using namespace mip360;
+
+void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width) {
+  const int64_t tot = (int64_t)n * S * width;
+  hipLaunchKernelGGL(dir_encode_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, n, S, viewdirs, (__bf16*)out, ld,
+                     col0, width);
+}
+
+void mip360_launch_resample(hipStream_t st, int n, int m_in, const float* sd, const float* w, float dil, float anneal,
+                            float pad, int ns, const float* jit, float s_near, float s_far, const float* tn,
+                            const float* tf, float* sd_out, float* td_out) {
+  hipLaunchKernelGGL(resample_kernel, dim3((n + RPB - 1) / RPB), dim3(256), 0, st, n, m_in, sd, w, dil, anneal, pad, ns, jit,
+                     s_near, s_far, tn, tf, sd_out, td_out);
+}
+void mip360_launch_cast_encode(hipStream_t st, int n, int S, const float* td, const float* o, const float* d,
+                               const float* radii, const float* basis_t, void* enc, int bf16, int ld) {
+  const int64_t rows = (int64_t)n * S;
+  const int64_t waves = (rows + 2) / 3;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
+  if (bf16) hipLaunchKernelGGL(cast_encode_kernel<true>, dim3(grid), dim3(256), 0, st, n, S, td, o, d, radii, basis_t, enc, ld);
+  else hipLaunchKernelGGL(cast_encode_kernel<false>, dim3(grid), dim3(256), 0, st, n, S, td, o, d, radii, basis_t, enc, ld);
+}
+void mip360_launch_render(hipStream_t st, int n, int S, const float* density, const float* rgbs, const float* td,
+                          const float* dirs, int opaque, float bg, float* w, float* rgb, float* acc, float* dm, float* depth) {
+  hipLaunchKernelGGL(render_level_kernel, dim3((n + RPB - 1) / RPB), dim3(256), 0, st, n, S, density, rgbs, td, dirs, opaque,
+                     bg, w, rgb, acc, dm, depth);
+}
+void mip360_launch_render_bwd(hipStream_t st, int n, int S, const float* density, const float* rgbs, const float* td,
+                              const float* dirs, int opaque, float bg, const float* g_w, const float* g_rgb,
+                              const float* g_dm, float* g_density, float* g_rgbs) {
+  hipLaunchKernelGGL(render_level_bwd_kernel, dim3((n + RPB - 1) / RPB), dim3(256), 0, st, n, S, density, rgbs, td, dirs,
+                     opaque, bg, g_w, g_rgb, g_dm, g_density, g_rgbs);
+}
+void mip360_launch_losses(hipStream_t st, int n, int s_nerf, int s_prop, int n_prop, const float* rgb, const float* rgb_gt,
+                          const float* dm, const float* sup, const float* sd_nerf, const float* w_nerf,
+                          const float* const* sd_prop, const float* const* w_prop, int charb, float charb_pad,
+                          float data_mult, int depth_type, float lambda_depth, float depth_weight, float inter_mult,
+                          float dist_mult, float* scalars, float* g_rgb, float* g_dm, float* g_w_nerf,
+                          float* const* g_w_prop, float* ws, float prop_depth_weight, const float* const* dm_prop,
+                          float* const* g_dm_prop) {
+  LossArgs a{};
+  a.prop_depth_weight = prop_depth_weight;
+  int n_dm = 0;
+  for (int k = 0; k < n_prop; ++k) {
+    a.dm_prop[k] = dm_prop ? dm_prop[k] : nullptr;
+    a.g_dm_prop[k] = g_dm_prop ? g_dm_prop[k] : nullptr;
+    if (a.dm_prop[k]) n_dm = k + 1;
+  }
+  a.n = n; a.s_nerf = s_nerf; a.s_prop = s_prop; a.n_prop = n_prop;
+  a.rgb = rgb; a.rgb_gt = rgb_gt; a.dm = dm; a.sup = sup; a.sd_nerf = sd_nerf; a.w_nerf = w_nerf;
+  for (int k = 0; k < n_prop; ++k) { a.sd_prop[k] = sd_prop[k]; a.w_prop[k] = w_prop[k]; a.g_w_prop[k] = g_w_prop[k]; }
+  a.charb = charb; a.charb_pad = charb_pad; a.data_mult = data_mult; a.depth_type = depth_type;
+  a.lambda_depth = lambda_depth; a.depth_weight = depth_weight; a.inter_mult = inter_mult; a.dist_mult = dist_mult;
+  a.g_rgb = g_rgb; a.g_dm = g_dm; a.g_w_nerf = g_w_nerf; a.ws = ws;
+  hipLaunchKernelGGL(losses_ray_kernel, dim3((n + RPB - 1) / RPB), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(losses_reduce_kernel, dim3(1), dim3(1024), 0, st, n, s_nerf, ws, data_mult, depth_type, lambda_depth,
+                     depth_weight, inter_mult, dist_mult, n_dm, prop_depth_weight, scalars);
+}

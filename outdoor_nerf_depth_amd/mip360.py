@@ -1,0 +1,307 @@
+"""Host-side mirror of the MipNeRF-360 path (BASELINE config 5) on libmip360_hip.so.
+
+Upstream (nerf-methods/mipnerf360, JAX) has no FFI; this module mirrors its call face -- `Model.__call__`
+(internal/models.py:76-303) as `Mip360Model.forward`, `MLP.__call__` (:436-606) as `mlp_forward`, the loss terms of
+`train_utils.py:72-169` as `losses` -- with the arithmetic in HIP kernels behind the C ABI of include/mip360_hip.h.
+PyTorch is device memory and streams only.  There is no CPU fallback: `lib()` raises if the library is missing.
+
+Status (round 2): forward pass of the three sampling levels (resampling, cone casting + contraction + IPE, the
+PropMLP / NerfMLP dense layers on the matrix cores, compositing), the loss terms with their gradients, and the
+compositing backward are implemented and parity-tested against oracle/mip360_oracle.py; the MLP backward GEMMs
+(dX, dW), Adam with the upstream learning-rate schedule / gradient clipping and the pmean data-parallel step are not.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('MIP360_HIP_LIB') or os.path.join(_HERE, 'libmip360_hip.so')
+ABI_VERSION = 1
+N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
+_fp = C.c_void_p
+_fpp = C.POINTER(C.c_void_p)
+
+SYMBOLS = {
+    'mip360_last_error': (C.c_char_p, []),
+    'mip360_abi_version': (C.c_int, []),
+    'mip360_resample': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_int, _fp, C.c_float,
+                                  C.c_float, _fp, _fp, _fp, _fp]),
+    'mip360_cast_encode': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int]),
+    'mip360_render_level': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
+    'mip360_render_level_backward': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp,
+                                               _fp, _fp]),
+    'mip360_losses': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fpp, _fpp, C.c_int,
+                                C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp,
+                                _fpp, _fp, C.c_float, _fpp, _fpp]),
+    'mip360_linear_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, _fp,
+                                     C.c_int, _fp, C.c_int]),
+    'mip360_dir_encode': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int]),
+}
+_lib = None
+
+
+class Mip360Error(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mip360Error('libmip360_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+                              'g.build()"`. There is no CPU fallback for the MipNeRF-360 path.' % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        if h.mip360_abi_version() != ABI_VERSION:
+            raise Mip360Error('libmip360_hip.so ABI version mismatch')
+        _lib = h
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise Mip360Error('%s failed (code %d): %s' % (what, rc, lib().mip360_last_error().decode('utf-8', 'replace')))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    if not t.is_cuda:
+        raise Mip360Error('expected a CUDA/HIP tensor (no CPU fallback)')
+    return t.contiguous().float()
+
+
+def pos_basis_t():
+    """models.py:387-389: transpose of geopoly.generate_basis('icosahedron', 2) -- [3, 21] float32 (host numpy).
+    The 21 directions are the distinct-up-to-sign vertices of the twice-tesselated icosahedron."""
+    a = (np.sqrt(5) + 1) / 2
+    verts = np.array([(-1, 0, a), (1, 0, a), (-1, 0, -a), (1, 0, -a), (0, a, 1), (0, a, -1), (0, -a, 1), (0, -a, -1),
+                      (a, 1, 0), (-a, 1, 0), (a, -1, 0), (-a, -1, 0)]) / np.sqrt(a + 2)
+    faces = [(0, 4, 1), (0, 9, 4), (9, 5, 4), (4, 5, 8), (4, 8, 1), (8, 10, 1), (8, 3, 10), (5, 3, 8), (5, 2, 3), (2, 7, 3),
+             (7, 10, 3), (7, 6, 10), (7, 11, 6), (11, 0, 6), (0, 1, 6), (6, 1, 10), (9, 0, 11), (9, 11, 2), (9, 2, 5), (7, 2, 11)]
+    bary = np.array([(i, j, 2 - i - j) for i in range(3) for j in range(3 - i)], np.float64) / 2
+    pts = np.concatenate([bary @ verts[list(f)] for f in faces], 0)
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    keep = []
+    for i, p in enumerate(pts):                       # first occurrence of every vertex, in order of appearance
+        if not any(np.sum((p - pts[k]) ** 2) <= 1e-4 for k in keep):
+            keep.append(i)
+    pts = pts[keep]
+    out = []
+    for i, p in enumerate(pts):                       # drop the later member of every antipodal pair
+        if not any(np.sum((p + q) ** 2) < 1e-4 for q in pts[:i]):
+            out.append(p)
+    return np.ascontiguousarray(np.array(out)[:, ::-1].T, np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------- kernels
+def resample(sdist, weights, dilation, anneal, num_samples, t_near, t_far, jitter01=None, resample_padding=0.0,
+             domain=(0.0, 1.0)):
+    """models.py:158-208 for one level.  Returns (sdist', tdist') [n, num_samples + 1]."""
+    sdist, weights = _f32(sdist), _f32(weights)
+    n, m = weights.shape
+    so = torch.empty(n, num_samples + 1, device=sdist.device)
+    to = torch.empty_like(so)
+    jit = _f32(jitter01).reshape(-1) if jitter01 is not None else None
+    _check(lib().mip360_resample(_stream(), n, m, _p(sdist), _p(weights), float(dilation), float(anneal), float(resample_padding),
+                                 int(num_samples), _p(jit), float(domain[0]), float(domain[1]), _p(_f32(t_near).reshape(-1)),
+                                 _p(_f32(t_far).reshape(-1)), _p(so), _p(to)), 'mip360_resample')
+    return so, to
+
+
+def cast_encode(tdist, origins, directions, radii, basis_t, out=None, bf16=True, ld=IPE_LD):
+    """render.cast_rays + contract + lift + IPE -> [n*S, ld] (bf16 by default; `out` may be a column view base)."""
+    tdist = _f32(tdist)
+    n, S = tdist.shape[0], tdist.shape[1] - 1
+    if out is None:
+        out = torch.empty(n * S, ld, dtype=torch.bfloat16 if bf16 else torch.float32, device=tdist.device)
+    _check(lib().mip360_cast_encode(_stream(), n, S, _p(tdist), _p(_f32(origins)), _p(_f32(directions)),
+                                    _p(_f32(radii).reshape(-1)), _p(basis_t), _p(out), int(out.dtype == torch.bfloat16), ld),
+           'mip360_cast_encode')
+    return out
+
+
+def linear(a, w, bias, act=0, act_param=0.0, out_bf16=None, out_f32=None, m=None, n=None, k=None):
+    """act(A W^T + b): a [M, lda] bf16 (k leading columns used), w [N, ldw] bf16."""
+    m = a.shape[0] if m is None else m
+    n = w.shape[0] if n is None else n
+    k = w.shape[1] if k is None else k
+    _check(lib().mip360_linear_bf16(_stream(), m, n, k, _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), int(act),
+                                    float(act_param), _p(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0,
+                                    _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0), 'mip360_linear_bf16')
+
+
+def render_level(density, rgb_samples, tdist, directions, opaque_background=True, bg_rgb=1.0):
+    density, tdist = _f32(density), _f32(tdist)
+    n, S = density.shape
+    dev = density.device
+    w = torch.empty(n, S, device=dev)
+    rgb = torch.empty(n, 3, device=dev) if rgb_samples is not None else None
+    acc, dm, depth = torch.empty(n, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+    _check(lib().mip360_render_level(_stream(), n, S, _p(density), _p(rgb_samples), _p(tdist), _p(_f32(directions)),
+                                     int(opaque_background), float(bg_rgb), _p(w), _p(rgb), _p(acc), _p(dm), _p(depth)),
+           'mip360_render_level')
+    return dict(weights=w, rgb=rgb, acc=acc, distance_mean=dm, depth=depth)
+
+
+def render_level_backward(density, rgb_samples, tdist, directions, g_weights=None, g_rgb=None, g_distance_mean=None,
+                          opaque_background=True, bg_rgb=1.0):
+    density = _f32(density)
+    n, S = density.shape
+    g_density = torch.empty_like(density)
+    g_rgbs = torch.empty(n, S, 3, device=density.device) if rgb_samples is not None else None
+    _check(lib().mip360_render_level_backward(_stream(), n, S, _p(density), _p(rgb_samples), _p(_f32(tdist)),
+                                              _p(_f32(directions)), int(opaque_background), float(bg_rgb), _p(g_weights),
+                                              _p(g_rgb), _p(g_distance_mean), _p(g_density), _p(g_rgbs)),
+           'mip360_render_level_backward')
+    return g_density, g_rgbs
+
+
+def losses(rgb, rgb_gt, distance_mean, depth_sup, sdist_nerf, w_nerf, sdist_prop, w_prop, data_loss_type='charb',
+           charb_padding=0.001, data_loss_mult=1.0, depth_loss_type='mse', lambda_depth=0.1, depth_weight=2.0,
+           interlevel_loss_mult=1.0, distortion_loss_mult=0.01, dm_prop=None, prop_depth_weight=1.0):
+    """train_utils.py:72-169 + loss_fn :258-300.  depth_weight = 2 / prop_depth_weight = 1 are the reference's
+    effective weights: its total adds stats['loss_disp_mse'] = lambda * sum over ALL levels (:143, :268-269) on top of
+    the lambda * depth[nerf] already inside the data loss.  dm_prop: the proposal levels' distance_mean [n] each.
+    Returns (scalars[6], g_rgb, g_distance_mean, g_w_nerf, [g_w_prop], [g_dm_prop])."""
+    n, Sn = w_nerf.shape
+    Sp = w_prop[0].shape[1] if w_prop else 1
+    dev = w_nerf.device
+    scalars = torch.empty(6, device=dev)
+    g_rgb, g_dm, g_wn = torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, Sn, device=dev)
+    g_wp = [torch.empty(n, Sp, device=dev) for _ in w_prop]
+    ws = torch.empty((4 + len(w_prop)) * n, device=dev)
+    dm_prop = list(dm_prop) if dm_prop is not None else []
+    g_dmp = [torch.empty(n, device=dev) for _ in dm_prop]
+    arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+    dtype = {None: 0, 'none': 0, 'mse': 1, 'l1': 2}[depth_loss_type]
+    _check(lib().mip360_losses(_stream(), n, Sn, Sp, len(w_prop), _p(_f32(rgb)), _p(_f32(rgb_gt)),
+                               _p(distance_mean), _p(depth_sup), _p(_f32(sdist_nerf)), _p(_f32(w_nerf)), arr(sdist_prop),
+                               arr(w_prop), int(data_loss_type == 'charb'), float(charb_padding), float(data_loss_mult), dtype,
+                               float(lambda_depth), float(depth_weight), float(interlevel_loss_mult),
+                               float(distortion_loss_mult), _p(scalars), _p(g_rgb), _p(g_dm), _p(g_wn), arr(g_wp), _p(ws),
+                               float(prop_depth_weight), arr(dm_prop) if dm_prop else None, arr(g_dmp) if dm_prop else None),
+           'mip360_losses')
+    return scalars, g_rgb, g_dm, g_wn, g_wp, g_dmp
+
+
+# ----------------------------------------------------------------------------------------------------- MLPs
+PROP_CFG = dict(net_depth=4, net_width=256, disable_rgb=True)          # configs/360.gin:12-16
+NERF_CFG = dict(net_depth=8, net_width=1024, disable_rgb=False)        # configs/360.gin:17-20
+SKIP_LAYER, BOTTLENECK, VIEW_WIDTH, DIR_DIM, DIR_LD = 4, 256, 128, 27, 32
+DENSITY_BIAS, RGB_PADDING = -1.0, 0.001
+
+
+class PackedMLP(object):
+    """bf16 device copies of one MLP's flax parameters (list of (kernel [in, out], bias [out]) in construction order,
+    models.py:436-606), transposed to [out, in_padded] (K contiguous, K padded to a multiple of 32 with zero columns;
+    the skip layer's input is [x (width) | encoding (504 -> 512)], the view layer's [bottleneck (256) | dirs (27 -> 32)])."""
+
+    def __init__(self, params, cfg, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        W, depth = cfg['net_width'], cfg['net_depth']
+        self.w, self.b = [], []
+        for i, (k, b) in enumerate(params):
+            k = np.asarray(k, np.float32)
+            if i < depth and i > 0 and (i - 1) % SKIP_LAYER == 0 and (i - 1) > 0:      # input = cat([x, enc])
+                k = np.concatenate([k[:W], k[W:], np.zeros((IPE_LD - IPE_DIM, k.shape[1]), np.float32)], 0)
+            elif i == 0:
+                k = np.concatenate([k, np.zeros((IPE_LD - IPE_DIM, k.shape[1]), np.float32)], 0)
+            elif not cfg['disable_rgb'] and i == depth + 2:                             # view layer
+                k = np.concatenate([k, np.zeros((BOTTLENECK + DIR_LD - k.shape[0], k.shape[1]), np.float32)], 0)
+            assert k.shape[0] % 32 == 0, (i, k.shape)
+            self.w.append(torch.from_numpy(np.ascontiguousarray(k.T)).to(self.device).to(torch.bfloat16).contiguous())
+            self.b.append(torch.from_numpy(np.asarray(b, np.float32)).to(self.device))
+
+
+def mlp_forward(pk, enc_buf, rows, viewdirs=None, n_rays=None, n_samples=None):
+    """MLP.__call__ (models.py:436-606) for 360.gin.  enc_buf: bf16 [rows, W + 512] whose columns [W, W + 512) hold
+    the IPE features (cast_encode wrote them there) -- layer 0 reads them in place and the skip layer finds them next to
+    the hidden state without a concat.  Returns (density [rows] f32, rgb [rows, 3] f32 or None)."""
+    cfg = pk.cfg
+    W, depth = cfg['net_width'], cfg['net_depth']
+    dev = enc_buf.device
+    enc = enc_buf[:, W:]                                           # [rows, 512] view, stride W + 512
+    ping = [torch.empty(rows, W, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    x, x_k, nxt = enc, IPE_LD, 0
+    for i in range(depth):
+        skip_out = (i % SKIP_LAYER == 0 and i > 0)                 # this layer's output is concatenated with the encoding
+        out = enc_buf[:, :W] if skip_out else ping[nxt]
+        linear(x, pk.w[i], pk.b[i], act=1, out_bf16=out, m=rows, n=W, k=x_k)
+        if skip_out:
+            x, x_k = enc_buf, W + IPE_LD
+        else:
+            x, x_k, nxt = out, W, nxt ^ 1
+    density = torch.empty(rows, 1, device=dev)
+    linear(x, pk.w[depth], pk.b[depth], act=2, act_param=DENSITY_BIAS, out_f32=density, m=rows, n=1, k=x_k)
+    if cfg['disable_rgb']:
+        return density[:, 0], None
+    view_in = torch.empty(rows, BOTTLENECK + DIR_LD, dtype=torch.bfloat16, device=dev)
+    linear(x, pk.w[depth + 1], pk.b[depth + 1], act=0, out_bf16=view_in, m=rows, n=BOTTLENECK, k=x_k)
+    _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0), BOTTLENECK,
+                                   DIR_LD), 'mip360_dir_encode')
+    h = torch.empty(rows, VIEW_WIDTH, dtype=torch.bfloat16, device=dev)
+    linear(view_in, pk.w[depth + 2], pk.b[depth + 2], act=1, out_bf16=h, m=rows, n=VIEW_WIDTH, k=BOTTLENECK + DIR_LD)
+    rgb = torch.empty(rows, 3, device=dev)
+    linear(h, pk.w[depth + 3], pk.b[depth + 3], act=3, act_param=RGB_PADDING, out_f32=rgb, m=rows, n=3, k=VIEW_WIDTH)
+    return density[:, 0], rgb
+
+
+class Mip360Model(object):
+    """Model.__call__ (models.py:76-303) for configs/360.gin: two proposal levels (64 samples, PropMLP) and one NeRF
+    level (32 samples, NerfMLP), stop-gradient between levels, dilation + annealed resampling, opaque background."""
+
+    def __init__(self, prop_params, nerf_params, device, num_prop_samples=64, num_nerf_samples=32, num_levels=3,
+                 anneal_slope=10., dilation_multiplier=0.5, dilation_bias=0.0025, bg_rgb=1.0):
+        self.device = torch.device(device)
+        self.prop = PackedMLP(prop_params, PROP_CFG, device)
+        self.nerf = PackedMLP(nerf_params, NERF_CFG, device)
+        self.basis_t = torch.from_numpy(pos_basis_t()).to(self.device)
+        self.cfg = dict(num_prop_samples=num_prop_samples, num_nerf_samples=num_nerf_samples, num_levels=num_levels,
+                        anneal_slope=anneal_slope, dilation_multiplier=dilation_multiplier, dilation_bias=dilation_bias,
+                        bg_rgb=bg_rgb)
+
+    def forward(self, rays, train_frac=1.0, jitter01=None):
+        """rays: dict of device tensors origins, directions, viewdirs [n,3], radii, near, far [n,1].
+        jitter01: None (deterministic) or a list of per-level [n] tensors in [0,1).  Returns (renderings, ray_history)."""
+        c = self.cfg
+        n = rays['origins'].shape[0]
+        dev = self.device
+        sdist = torch.tensor([[0., 1.]], device=dev).repeat(n, 1)
+        weights = torch.ones(n, 1, device=dev)
+        prod = 1
+        renderings, history = [], []
+        for lvl in range(c['num_levels']):
+            is_prop = lvl < c['num_levels'] - 1
+            ns = c['num_prop_samples'] if is_prop else c['num_nerf_samples']
+            dilation = c['dilation_bias'] + c['dilation_multiplier'] * 1.0 / prod
+            prod *= ns
+            s = c['anneal_slope']
+            anneal = (s * train_frac) / ((s - 1) * train_frac + 1) if s > 0 else 1.
+            sdist, tdist = resample(sdist, weights, dilation if lvl > 0 else 0.0, anneal, ns, rays['near'], rays['far'],
+                                    None if jitter01 is None else jitter01[lvl])
+            pk = self.prop if is_prop else self.nerf
+            W = pk.cfg['net_width']
+            rows = n * ns
+            enc_buf = torch.empty(rows, W + IPE_LD, dtype=torch.bfloat16, device=dev)
+            cast_encode(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, out=enc_buf[:, W:],
+                        ld=W + IPE_LD)
+            density, rgb = mlp_forward(pk, enc_buf, rows, rays['viewdirs'], n, ns)
+            density = density.reshape(n, ns)
+            rgb_s = rgb.reshape(n, ns, 3) if rgb is not None else None
+            r = render_level(density, rgb_s, tdist, rays['directions'], True, c['bg_rgb'])
+            weights = r['weights']
+            renderings.append(r)
+            history.append(dict(sdist=sdist, tdist=tdist, weights=weights, density=density, rgb=rgb_s))
+        return renderings, history

@@ -1,0 +1,302 @@
+"""GPU parity tests of the MipNeRF-360 kernels (BASELINE config 5) through the C ABI of
+include/mip360_hip.h, against oracle/mip360_oracle.py (pinned by the upstream unit-test properties,
+tests/test_mip360_oracle.py) on the same seeded inputs.
+
+Tolerances: float32 ray-side kernels (resampling, compositing, losses) 1e-5 relative / 2e-6 absolute on [0,1]
+quantities; the IPE features scale their absolute tolerance with the frequency (a float32 argument of 2^k x carries
+2^k ulp(x) of phase error in the reference too); the bf16 dense layers are compared with a bf16-operand numpy
+restatement at 2e-3 and with the float32 oracle at bf16-grade bounds."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import mip360_oracle as O                                    # noqa: E402
+from oracle.nerfpp_oracle import round_bf16                               # noqa: E402
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.fixture(scope='module')
+def M():
+    dev()
+    from outdoor_nerf_depth_amd import mip360
+    return mip360
+
+
+def _rays(rs, n):
+    d = rs.randn(n, 3).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return dict(origins=(rs.randn(n, 3) * 0.3).astype(np.float32), directions=d, viewdirs=d.copy(),
+                radii=np.full((n, 1), 2e-3, np.float32), near=np.full((n, 1), 0.2, np.float32),
+                far=np.full((n, 1), 1e6, np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------- resampling
+@pytest.mark.parametrize('jitter', [False, True])
+def test_resample_levels_match_oracle(M, jitter):
+    """models.py:158-208: level 0 (one unit interval), then dilation 0.0025 + 0.5/1 and 0.0025 + 0.5/64 on 64-bin
+    histograms with zero-width bins and zero weights in them."""
+    rs = np.random.RandomState(0)
+    n = 37
+    near, far = np.full((n, 1), 0.2, np.float32), np.full((n, 1), 1e6, np.float32)
+    _, s_to_t = O.construct_ray_warps('reciprocal', near, far)
+    sd = np.tile(np.array([[0., 1.]], np.float32), (n, 1))
+    w = np.ones((n, 1), np.float32)
+    prod = 1
+    for lvl, ns in enumerate((64, 64, 32)):
+        dilation = np.float32(0.0025 + 0.5 / prod)
+        prod *= ns
+        anneal = np.float32(10 * 0.3 / (9 * 0.3 + 1))
+        jit = rs.rand(n, 1).astype(np.float32) if jitter else None
+        got_s, got_t = M.resample(T(sd), T(w), float(dilation) if lvl > 0 else 0.0, float(anneal), ns, T(near), T(far),
+                                  None if jit is None else T(jit))
+        sd_o, w_o = sd, w
+        if lvl > 0:
+            sd_o, w_o = O.max_dilate_weights(sd, w, dilation, domain=(0., 1.), renormalize=True)
+            sd_o, w_o = sd_o[..., 1:-1], w_o[..., 1:-1]
+        with np.errstate(divide='ignore'):
+            logits = np.where(sd_o[..., 1:] > sd_o[..., :-1], anneal * np.log(w_o), -np.inf).astype(np.float32)
+        want = O.sample_intervals(sd_o.astype(np.float32), logits, ns, jit, True, domain=(0., 1.)).astype(np.float32)
+        np.testing.assert_allclose(N(got_s), want, rtol=1e-5, atol=3e-6, err_msg='level %d sdist' % lvl)
+        np.testing.assert_allclose(1.0 / N(got_t), 1.0 / s_to_t(want), rtol=2e-5, atol=1e-9, err_msg='level %d 1/tdist' % lvl)
+        assert (np.diff(N(got_s)) >= 0).all()
+        # next level's input: the oracle's intervals with a spiky weight vector (exact zeros included)
+        sd = want
+        w = O.softmax(rs.randn(n, ns) * 3).astype(np.float32)
+        w[:, ::9] = 0
+        w /= w.sum(-1, keepdims=True)
+
+
+# ---------------------------------------------------------------------------------------------------- featurisation
+def test_cast_encode_matches_oracle(M):
+    rs = np.random.RandomState(1)
+    n, S = 29, 32
+    rays = _rays(rs, n)
+    s = np.sort(rs.rand(n, S + 1), -1).astype(np.float32)
+    _, s_to_t = O.construct_ray_warps('reciprocal', rays['near'], np.full((n, 1), 50., np.float32))
+    tdist = s_to_t(s).astype(np.float32)
+    basis = O.pos_basis_t()
+    enc = N(M.cast_encode(T(tdist), T(rays['origins']), T(rays['directions']), T(rays['radii']), T(basis), bf16=False))
+    assert enc.shape == (n * S, 512) and not enc[:, 504:].any()
+    f64 = lambda a: np.asarray(a, np.float64)
+    means, covs = O.cast_rays(f64(tdist), f64(rays['origins']), f64(rays['directions']), f64(rays['radii']), 'cone', diag=False)
+    m, cv = O.track_linearize_contract(means, covs)
+    lm, lv = O.lift_and_diagonalize(m, cv, f64(basis))
+    want = O.integrated_pos_enc(lm, lv, 0, 12).reshape(n * S, 504)
+    # absolute tolerance grows with the frequency: column k*21 + j (and 252 + ...) has scale 2^k
+    scale = np.tile(np.repeat(2.0 ** np.arange(12), 21), 2)
+    err = np.abs(enc[:, :504] - want)
+    assert (err <= 2e-6 + 3e-6 * scale[None, :] * np.maximum(1.0, np.abs(np.tile(np.repeat(lm.reshape(n * S, 1, 21), 12, 1).reshape(n * S, 252), 2)))).all(), err.max()
+    assert err[:, :21 * 4].max() < 2e-5                                # the low degrees are tight
+    # bf16 output = rounding of the same values, written through a strided view (the MLP's skip buffer)
+    buf = torch.zeros(n * S, 256 + 512, dtype=torch.bfloat16, device=dev())
+    M.cast_encode(T(tdist), T(rays['origins']), T(rays['directions']), T(rays['radii']), T(basis), out=buf[:, 256:], ld=768)
+    np.testing.assert_allclose(N(buf[:, 256:256 + 504]), enc[:, :504], rtol=2 ** -8, atol=1e-6)
+    assert not N(buf[:, :256]).any()
+
+
+# ---------------------------------------------------------------------------------------------------- dense layers
+@pytest.mark.parametrize('m,n,k', [(300, 70, 96), (128, 128, 32), (1000, 1, 1024), (257, 1024, 1536)])
+def test_linear_bf16_against_numpy(M, m, n, k):
+    rs = np.random.RandomState(m + n)
+    a = round_bf16(rs.randn(m, k).astype(np.float32))
+    w = round_bf16((rs.randn(n, k) / np.sqrt(k)).astype(np.float32))
+    b = rs.randn(n).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+    ta, tw = T(a).to(torch.bfloat16), T(w).to(torch.bfloat16)
+    for act, fn in ((0, lambda v: v), (1, lambda v: np.maximum(v, 0)), (2, lambda v: np.logaddexp(v - 1.0, 0)),
+                    (3, lambda v: 1 / (1 + np.exp(-v)) * 1.002 - 0.001)):
+        o32 = torch.empty(m, n, device=dev())
+        o16 = torch.empty(m, n + 8, dtype=torch.bfloat16, device=dev())
+        M.linear(ta, tw, T(b), act=act, act_param={2: -1.0, 3: 0.001}.get(act, 0.0), out_bf16=o16[:, :n] if n > 1 else None,
+                 out_f32=o32)
+        np.testing.assert_allclose(N(o32), fn(ref), rtol=2e-5, atol=2e-5)
+        if n > 1:
+            np.testing.assert_allclose(N(o16[:, :n]), fn(ref), rtol=2 ** -7, atol=1e-3)
+    # strided A (a column window of a wider buffer), as the skip / view layers use it
+    wide = torch.zeros(m, k + 64, dtype=torch.bfloat16, device=dev())
+    wide[:, 64:] = ta
+    o32 = torch.empty(m, n, device=dev())
+    M.linear(wide[:, 64:], tw, None, act=0, out_f32=o32)
+    np.testing.assert_allclose(N(o32), ref - b, rtol=2e-5, atol=2e-5)
+
+
+def _mlp_bf16_reference(params, cfg, enc504, viewdirs_rows):
+    """MLP.__call__ with every dense layer's operands rounded to bfloat16 (what the matrix cores see), float64 sums."""
+    c = dict(O.MLP_DEFAULTS, **cfg)
+    r = lambda a: round_bf16(np.asarray(a, np.float32)).astype(np.float64)
+    x = r(enc504)
+    inputs = x
+    k = 0
+    for i in range(c['net_depth']):
+        W, b = params[k]; k += 1
+        x = r(np.maximum(x @ r(W) + b, 0))
+        if i % c['skip_layer'] == 0 and i > 0:
+            x = np.concatenate([x, inputs], -1)
+    W, b = params[k]; k += 1
+    density = np.logaddexp((x @ r(W) + b)[..., 0] - 1.0, 0)
+    if c['disable_rgb']:
+        return density, None
+    W, b = params[k]; k += 1
+    bott = r(x @ r(W) + b)
+    x = np.concatenate([bott, r(O.pos_enc(viewdirs_rows, 0, 4, True))], -1)
+    W, b = params[k]; k += 1
+    x = r(np.maximum(x @ r(W) + b, 0))
+    W, b = params[k]; k += 1
+    rgb = 1 / (1 + np.exp(-(x @ r(W) + b))) * 1.002 - 0.001
+    return density, rgb
+
+
+@pytest.mark.parametrize('which', ['prop', 'nerf'])
+def test_mlp_forward_matches_bf16_reference_and_oracle(M, which):
+    rs = np.random.RandomState(3)
+    n, S = 11, 32
+    cfg = O.PROP_CFG if which == 'prop' else O.NERF_CFG
+    params = O.init_mlp_params(cfg, rs)
+    params = [(w, (rs.randn(*b.shape) * 0.1).astype(np.float32)) for w, b in params]     # non-zero biases
+    rays = _rays(rs, n)
+    s = np.sort(rs.rand(n, S + 1), -1).astype(np.float32)
+    _, s_to_t = O.construct_ray_warps('reciprocal', rays['near'], np.full((n, 1), 30., np.float32))
+    tdist = s_to_t(s).astype(np.float32)
+    basis = O.pos_basis_t()
+    pk = M.PackedMLP(params, M.PROP_CFG if which == 'prop' else M.NERF_CFG, dev())
+    W = cfg['net_width']
+    buf = torch.empty(n * S, W + 512, dtype=torch.bfloat16, device=dev())
+    M.cast_encode(T(tdist), T(rays['origins']), T(rays['directions']), T(rays['radii']), T(basis), out=buf[:, W:], ld=W + 512)
+    enc = N(buf[:, W:W + 504])
+    density, rgb = M.mlp_forward(pk, buf, n * S, T(rays['viewdirs']), n, S)
+    vd_rows = np.repeat(rays['viewdirs'], S, 0)
+    d_ref, rgb_ref = _mlp_bf16_reference(params, cfg, enc, vd_rows)
+    np.testing.assert_allclose(N(density), d_ref, rtol=4e-3, atol=1e-4)
+    means, covs = O.cast_rays(tdist, rays['origins'], rays['directions'], rays['radii'], 'cone', diag=False)
+    full = O.mlp_forward(params, cfg, means, covs, rays['viewdirs'], basis)
+    np.testing.assert_allclose(N(density).reshape(n, S), full['density'], rtol=5e-2, atol=5e-3)
+    if which == 'nerf':
+        np.testing.assert_allclose(N(rgb), rgb_ref, rtol=0, atol=3e-3)
+        np.testing.assert_allclose(N(rgb).reshape(n, S, 3), full['rgb'], rtol=0, atol=2e-2)
+    else:
+        assert rgb is None
+
+
+# ---------------------------------------------------------------------------------------------------- compositing
+@pytest.mark.parametrize('S,opaque', [(32, True), (64, True), (17, False)])
+def test_render_level_forward_and_backward(M, S, opaque):
+    rs = np.random.RandomState(S)
+    n = 23
+    density = np.exp(rs.randn(n, S)).astype(np.float32)
+    rgbs = rs.rand(n, S, 3).astype(np.float32)
+    tdist = (0.2 + np.cumsum(np.exp(rs.randn(n, S + 1) * 0.5) * 0.1, -1)).astype(np.float32)
+    dirs = rs.randn(n, 3).astype(np.float32)
+    r = M.render_level(T(density), T(rgbs), T(tdist), T(dirs), opaque, 1.0)
+    w_o = O.compute_alpha_weights(density, tdist, dirs, opaque)[0]
+    rend = O.volumetric_rendering(rgbs, w_o, tdist, 1.0, np.full((n, 1), 1e6, np.float32))
+    np.testing.assert_allclose(N(r['weights']), w_o, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(N(r['rgb']), rend['rgb'], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(N(r['acc']), rend['acc'], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(N(r['distance_mean']), rend['distance_mean'], rtol=3e-5)
+    np.testing.assert_allclose(N(r['depth']), rend['depth'], rtol=3e-5)
+    # backward against float64 finite differences of the oracle's forward
+    g_w, g_rgb, g_dm = rs.randn(n, S).astype(np.float32), rs.randn(n, 3).astype(np.float32), rs.randn(n).astype(np.float32)
+    gd, grgbs = M.render_level_backward(T(density), T(rgbs), T(tdist), T(dirs), T(g_w), T(g_rgb), T(g_dm), opaque, 1.0)
+
+    def scalar(dens, cols):
+        w = O.compute_alpha_weights(dens, tdist.astype(np.float64), dirs.astype(np.float64), opaque)[0]
+        rr = O.volumetric_rendering(cols, w, tdist.astype(np.float64), 1.0, np.full((n, 1), 1e6))
+        return (w * g_w).sum() + (rr['rgb'] * g_rgb).sum() + (rr['distance_mean'] * g_dm).sum()
+
+    d64, c64 = density.astype(np.float64), rgbs.astype(np.float64)
+    num = np.zeros_like(d64)
+    for i in range(0, n, 5):
+        for s_ in range(S):
+            dp, dm_ = d64.copy(), d64.copy()
+            h = 1e-6 * max(1.0, d64[i, s_])
+            dp[i, s_] += h
+            dm_[i, s_] -= h
+            num[i, s_] = (scalar(dp, c64) - scalar(dm_, c64)) / (2 * h)
+    sel = slice(0, n, 5)
+    np.testing.assert_allclose(N(gd)[sel], num[sel], rtol=2e-3, atol=2e-5 * np.abs(num[sel]).max())
+    np.testing.assert_allclose(N(grgbs), w_o[..., None] * g_rgb[:, None, :], rtol=2e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize('depth_kind', ['mse', 'l1'])
+def test_losses_and_gradients_match_oracle(M, depth_kind):
+    rs = np.random.RandomState(7)
+    n, Sn, Sp = 41, 32, 64
+    mk_s = lambda S: np.sort(rs.rand(n, S + 1), -1).astype(np.float32)
+    mk_w = lambda S: (O.softmax(rs.randn(n, S) * 2) * rs.uniform(0.5, 1.0, (n, 1))).astype(np.float32)
+    sd_n, w_n = mk_s(Sn), mk_w(Sn)
+    sd_p, w_p = [mk_s(Sp), mk_s(Sp)], [mk_w(Sp), mk_w(Sp)]
+    rgb, gt = rs.rand(n, 3).astype(np.float32), rs.rand(n, 3).astype(np.float32)
+    dm = rs.uniform(1, 6, n).astype(np.float32)
+    sup = np.where(rs.rand(n) < .6, rs.uniform(1, 6, n), 0).astype(np.float32)
+    dm_p = [rs.uniform(1, 6, n).astype(np.float32) for _ in range(2)]
+    sc, g_rgb, g_dm, g_wn, g_wp, g_dmp = M.losses(T(rgb), T(gt), T(dm), T(sup), T(sd_n), T(w_n), [T(x) for x in sd_p],
+                                                  [T(x) for x in w_p], depth_loss_type=depth_kind, lambda_depth=0.1,
+                                                  depth_weight=2.0, dm_prop=[T(x) for x in dm_p], prop_depth_weight=1.0)
+    rend = [dict(rgb=rgb, distance_mean=dm_p[0]), dict(rgb=rgb, distance_mean=dm_p[1]), dict(rgb=rgb, distance_mean=dm)]
+    hist = [dict(sdist=sd_p[0], weights=w_p[0]), dict(sdist=sd_p[1], weights=w_p[1]), dict(sdist=sd_n, weights=w_n, tdist=sd_n)]
+    data_loss, st = O.compute_data_loss(gt, sup, rend, hist, np.ones((n, 3), np.float32), depth_loss_type=depth_kind,
+                                        lambda_depth=0.1)
+    inter, dist = O.interlevel_loss(hist), O.distortion_loss(hist)
+    total = data_loss + 0.1 * st['depth_losses'].sum() + inter + dist      # + stats['loss_disp_mse'] (train_utils.py:143, :268-269)
+    s = N(sc)
+    np.testing.assert_allclose(s[1], np.sqrt((rgb - gt) ** 2 + 1e-6).mean(), rtol=1e-5)
+    np.testing.assert_allclose(s[2], st['depth_losses'][-1], rtol=1e-5)
+    np.testing.assert_allclose(s[3], inter, rtol=2e-5)
+    np.testing.assert_allclose(s[4], dist, rtol=2e-5)
+    np.testing.assert_allclose(s[0], total, rtol=2e-5)
+    # gradients: closed forms of the oracle (themselves checked by finite differences in tests/test_mip360_oracle.py)
+    resid = rgb - gt
+    np.testing.assert_allclose(N(g_rgb), resid / np.sqrt(resid ** 2 + 1e-6) / (3 * n), rtol=1e-5, atol=1e-9)
+    m = (sup > 0).astype(np.float32)
+    diff = m * dm - m * sup
+    want = 0.2 * (2 * diff if depth_kind == 'mse' else np.sign(diff)) * m / n
+    np.testing.assert_allclose(N(g_dm), want, rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(s[5], st['depth_losses'][:-1].sum(), rtol=1e-5)
+    for k in range(2):
+        dk = m * dm_p[k] - m * sup
+        np.testing.assert_allclose(N(g_dmp[k]), 0.1 * (2 * dk if depth_kind == 'mse' else np.sign(dk)) * m / n, rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(N(g_wn), 0.01 * O.lossfun_distortion_grad_w(sd_n, w_n) / n, rtol=2e-5, atol=1e-9)
+    for k in range(2):
+        np.testing.assert_allclose(N(g_wp[k]), O.lossfun_outer_grad_w_env(sd_n, w_n, sd_p[k], w_p[k]) / (n * Sn), rtol=2e-5,
+                                   atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------- whole model
+def test_model_forward_matches_oracle(M):
+    """Model.__call__ for configs/360.gin (64 / 64 / 32 samples) against the oracle with the same per-level jitter.
+    The dense layers run in bf16, and later levels re-sample from earlier weights, so the comparison is bf16-grade;
+    level 0's intervals do not depend on any MLP and are float32-tight."""
+    rs = np.random.RandomState(5)
+    n = 9
+    rays = _rays(rs, n)
+    prop, nerf = O.init_mlp_params(O.PROP_CFG, rs), O.init_mlp_params(O.NERF_CFG, rs)
+    jit = [rs.rand(n, 1).astype(np.float32) for _ in range(3)]
+    model = M.Mip360Model(prop, nerf, dev())
+    rend, hist = model.forward({k: T(v) for k, v in rays.items()}, train_frac=0.3, jitter01=[T(j) for j in jit])
+    rend_o, hist_o = O.model_forward(prop, nerf, rays, train_frac=0.3, jitter01=jit)
+    assert [h['weights'].shape[1] for h in hist] == [64, 64, 32]
+    np.testing.assert_allclose(N(hist[0]['sdist']), hist_o[0]['sdist'], rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(N(hist[0]['weights']), hist_o[0]['weights'], rtol=0, atol=2e-2)
+    for lvl in (1, 2):
+        assert np.abs(N(hist[lvl]['sdist']) - hist_o[lvl]['sdist']).max() < 2e-2
+        np.testing.assert_allclose(N(hist[lvl]['weights']).sum(-1), 1, atol=1e-4)
+    np.testing.assert_allclose(N(rend[-1]['rgb']), rend_o[-1]['rgb'], rtol=0, atol=3e-2)
+    for h in hist:
+        s = N(h['sdist'])
+        assert (np.diff(s) >= 0).all() and s.min() >= 0 and s.max() <= 1

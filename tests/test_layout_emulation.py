@@ -249,3 +249,20 @@ def test_weight_gradient_launch_plan():
             # [sigma | rgb0 M] (160 + 256 columns) is the widest narrow job, rgb1 (32 + 128) the narrowest
             assert nk.max() == k[9] == k[12 + 9] and nk.min() == min(k[10], k[11], k[22], k[23])
             assert nk.sum() == 256
+
+
+def test_mip360_library_loads_and_exports_every_declared_symbol():
+    """libmip360_hip.so exports exactly what include/mip360_hip.h declares (no compute without a GPU)."""
+    from outdoor_nerf_depth_amd import mip360 as M3
+    lib = M3.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'mip360_hip.h')).read()
+    declared = set(re.findall(r'\b(mip360_[a-z_0-9]+)\s*\(', hdr))
+    assert declared == set(M3.SYMBOLS), declared ^ set(M3.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mip360_abi_version() == M3.ABI_VERSION
+    # argument validation happens before any launch: a NULL pointer is an error code + message, not a crash
+    assert lib.mip360_resample(None, 4, 1, None, None, 0.0, 1.0, 0.0, 64, None, 0.0, 1.0, None, None, None, None) == 1
+    assert b'non-null' in lib.mip360_last_error()
+    b = M3.pos_basis_t()
+    assert b.shape == (3, 21)
