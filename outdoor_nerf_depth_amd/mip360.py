@@ -136,9 +136,9 @@ def linear(a, w, bias, act=0, act_param=0.0, out_bf16=None, out_f32=None, m=None
     m = a.shape[0] if m is None else m
     n = w.shape[0] if n is None else n
     k = w.shape[1] if k is None else k
-    _check(lib().mip360_linear_bf16(_stream(), m, n, k, _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), int(act),
-                                    float(act_param), _p(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0,
-                                    _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0), 'mip360_linear_bf16')
+    ld = lambda t: 0 if t is None else (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))   # size-1 dims have free strides
+    _check(lib().mip360_linear_bf16(_stream(), m, n, k, _p(a), ld(a), _p(w), ld(w), _p(bias), int(act), float(act_param),
+                                    _p(out_bf16), ld(out_bf16), _p(out_f32), ld(out_f32)), 'mip360_linear_bf16')
 
 
 def render_level(density, rgb_samples, tdist, directions, opaque_background=True, bg_rgb=1.0):
