@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/nerfpp_hip.h"
 #include "nerfpp_common.h"
@@ -108,6 +109,28 @@ NetWs make_netws(char* ws, const WsLayout& L, int net) {
 }
 
 bool prec_ok(int P) { return P == NERFPP_PREC_BF16 || P == NERFPP_PREC_SPLIT_BF16; }
+
+// The foreground and background nets of a level are independent until the compositing kernel, and each of their
+// kernels is one workgroup per CU: launched back to back on one stream, the second waits for the LAST workgroup of the
+// first (a full drain + ramp per pair, ~20 us at level 0 where a launch is a single round of 256 workgroups).  With
+// NERFPP_OVERLAP_NETS=1 the background kernel goes to a per-device side stream forked from / joined to the caller's
+// stream with events, so its workgroups fill CUs as the foreground's tail frees them.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+SideStream* side_stream() {
+  static const bool enabled = getenv("NERFPP_OVERLAP_NETS") ? atoi(getenv("NERFPP_OVERLAP_NETS")) != 0 : false;
+  if (!enabled) return nullptr;
+  static SideStream table[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream& t = table[dev];
+  if (!t.ok) {
+    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    t.ok = true;
+  }
+  return &t;
+}
 
 }  // namespace
 
@@ -276,6 +299,7 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
   const PackLayout PL = pack_layout(P);
   char* ws = (char*)a->workspace;
   const char* pk = (const char*)a->packed;
+  SideStream* side = side_stream();
   for (int net = 0; net < N_NET; ++net) {
     MlpFwdArgs m{};
     m.geom.ray_o = a->ray_o;
@@ -290,7 +314,9 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     m.depth_real = (float*)(ws + L.depth_real);
     if (train) { m.ws = make_netws(ws, L, net); m.masks = (uint4*)(ws + L.masks[net]); }
     if (net == 0 && a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
-    launch_mlp_fwd(st, net, P, train, m);
+    if (side && net == 0) { (void)hipEventRecord(side->fork, st); (void)hipStreamWaitEvent(side->s, side->fork, 0); }
+    launch_mlp_fwd(side && net == 1 ? side->s : st, net, P, train, m);
+    if (side && net == 1) { (void)hipEventRecord(side->join, side->s); (void)hipStreamWaitEvent(st, side->join, 0); }
     if (net == N_NET - 1 && a->ev_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_mlp_end, st);
   }
   launch_composite_fwd(st, a->n_rays, a->n_samples, (const float*)(ws + L.out_raw[0]),
@@ -334,6 +360,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
                        a->fg_z, a->bg_z, a->g_rgb, a->g_depth, a->g_fg_weights, (float*)(ws + L.d_out[0]),
                        (float*)(ws + L.d_out[1]));
   DwArgs dw{};
+  SideStream* side = side_stream();
   for (int net = 0; net < N_NET; ++net) {
     MlpBwdArgs m{};
     m.rows = L.rows;
@@ -343,7 +370,9 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
     m.ws = make_netws(ws, L, net);
     m.masks = (const uint4*)(ws + L.masks[net]);
     if (net == 0 && a->ev_bwd_begin) (void)hipEventRecord((hipEvent_t)a->ev_bwd_begin, st);
-    launch_mlp_bwd(st, net, P, m);
+    if (side && net == 0) { (void)hipEventRecord(side->fork, st); (void)hipStreamWaitEvent(side->s, side->fork, 0); }
+    launch_mlp_bwd(side && net == 1 ? side->s : st, net, P, m);
+    if (side && net == 1) { (void)hipEventRecord(side->join, side->s); (void)hipStreamWaitEvent(st, side->join, 0); }
     if (net == N_NET - 1 && a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);
     dw.ws[net] = m.ws;
     dw.slabs[net] = (float*)(ws + L.slabs[net]);
