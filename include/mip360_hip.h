@@ -102,11 +102,50 @@ int mip360_losses(void* stream, int n_rays, int s_nerf, int s_prop, int n_prop, 
  * (v_mfma_f32_32x32x16_bf16).  Replaces flax nn.Dense + nn.relu in MLP.__call__ (models.py:436-606).
  * K must be a multiple of 32 (pad with zeros); M, N arbitrary.  act: 0 none, 1 relu, 2 softplus(v + act_param) (the
  * density head: density_activation(raw + density_bias), models.py:497), 3 sigmoid(v) * (1 + 2 act_param) - act_param
- * (the colour head with rgb_padding, models.py:573-594).  Either output may be NULL: c_bf16 [M, ldc] bfloat16,
+ * (the colour head with rgb_padding, models.py:573-594), 4 v * (aux[m][n] > 0) (backward through a ReLU: aux = the
+ * layer's saved bf16 output [M, ldaux]; with a = dZ of the next layer and w = its kernel [in, out] this is the dX
+ * chain dZ_l = (dZ_{l+1} K_{l+1}^T) * relu'(H_l)).  Either output may be NULL: c_bf16 [M, ldc] bfloat16,
  * c_f32 [M, ldc32] float32. */
 int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
                        const float* bias, int act, float act_param, void* c_bf16, int ldc, float* c_f32,
-                       int ldc32);
+                       int ldc32, const void* aux, int ldaux);
+
+/* ---- training side (upstream: jax.value_and_grad + optax, train_utils.py:215-236, 303-370) ---------------------- */
+
+/* d kernel [n_in, n_out] (flax layout, float32, row stride ldg) = scale * H[m, n_in]^T dZ[m, n_out]: bf16 operands,
+ * MFMA with ds_read_b64_tr_b16 transposed fragments, split over `ksplit` row slices into `slabs`
+ * (>= ksplit * n_in * ldg floats) that are summed in a fixed order. */
+int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz,
+                            int lddz, int ksplit, float* slabs, float* grad_kernel, int ldg, float scale);
+
+/* d bias [n_out] = scale * column sums of dZ [m, n_out] (bf16); partial >= nslice * n_out floats. */
+int mip360_grad_bias_bf16(void* stream, int m, int n_out, const void* dz, int lddz, int nslice, float* partial,
+                          float* grad_bias, float scale);
+
+/* Backward through the heads (models.py:497, 573-594): d raw_density = g_density * (1 - exp(-density)) written to
+ * column raw_col of a bf16 [rows, ld_raw] tensor (columns raw_col+1 .. raw_zero_to-1 zero-filled: K padding);
+ * d rgb_pre = g_rgb (1 + 2p) s (1 - s), s = (rgb + p) / (1 + 2p), to columns 0..2 of a bf16 [rows, 32] tensor
+ * (3..31 zero-filled); d_pre_bf16 NULL for the proposal MLP. */
+int mip360_head_backward(void* stream, int64_t rows, const float* density, const float* g_density,
+                         const float* rgb, const float* g_rgb, float rgb_padding, void* d_raw_bf16, int ld_raw,
+                         int raw_col, int raw_zero_to, void* d_pre_bf16);
+
+/* clip_gradients (train_utils.py:215-236): per-tensor partial sums of squares (n_blocks floats each, deterministic),
+ * then mult = min(1, grad_max_norm / (eps + sqrt(sum of all partials))) over ONE MLP's tensors;
+ * mult_and_norm[2] = {mult, norm} stays on the device and feeds mip360_adam_step. */
+int mip360_sum_squares(void* stream, int64_t n, const float* g, float* partial, int n_blocks);
+int mip360_clip_multiplier(void* stream, int n_partial, const float* partial, float grad_max_norm,
+                           float* mult_and_norm);
+
+/* optax.adam step on one tensor (train_utils.py:303-331; defaults lr 2e-3 -> 2e-5 log-decay with 512 warm-up steps,
+ * b1 0.9, b2 0.999, eps 1e-6, configs.py:118-124); grad_mult: device scalar from mip360_clip_multiplier or NULL. */
+int mip360_adam_step(void* stream, int64_t n, float* params, const float* grads, float* mu, float* nu,
+                     const float* grad_mult, int step, double lr, double beta1, double beta2, double eps);
+
+/* float32 flax kernel [n_in, n_out] -> the two bf16 operand copies of the dense-layer kernel: fwd [n_out, ld_fwd]
+ * (transposed; the caller zero-fills the K padding once) and bwd [n_in, ld_bwd] (as stored). */
+int mip360_pack_weight(void* stream, int n_in, int n_out, const float* kernel, void* fwd_bf16, int ld_fwd,
+                       void* bwd_bf16, int ld_bwd);
 
 /* View-direction encoding of the NerfMLP's second stage (models.py:395-399,548-553): pos_enc(viewdirs, 0, 4,
  * append_identity=True) = 27 values per ray, broadcast over the ray's samples into columns [col0, col0 + 27) of a

@@ -499,36 +499,86 @@ def init_mlp_params(cfg, rng):
     return ps
 
 
-def mlp_forward(params, cfg, means, covs, viewdirs, basis):
+def mlp_forward(params, cfg, means, covs, viewdirs, basis, cache=None):
     """models.py:436-606 for the 360.gin configuration (warp_fn = contract, disable_density_normals).
-    means [..., n, 3], covs [..., n, 3, 3], viewdirs [..., 3].  Returns dict(density [..., n], rgb [..., n, 3])."""
+    means [..., n, 3], covs [..., n, 3, 3], viewdirs [..., 3].  Returns dict(density [..., n], rgb [..., n, 3]).
+    cache: optional dict that receives what mlp_backward needs."""
     c = dict(MLP_DEFAULTS, **cfg)
     m, cv = track_linearize_contract(means, covs)
     lm, lv = lift_and_diagonalize(m, cv, basis)
     x = integrated_pos_enc(lm, lv, c['min_deg_point'], c['max_deg_point'])
     inputs = x
     k = 0
+    acts_in, pre = [], []
     for i in range(c['net_depth']):
         W, b = params[k]; k += 1
-        x = np.maximum(x @ W + b, 0)
+        acts_in.append(x)
+        z = x @ W + b
+        pre.append(z)
+        x = np.maximum(z, 0)
         if i % c['skip_layer'] == 0 and i > 0:
             x = np.concatenate([x, inputs], -1)
     W, b = params[k]; k += 1
     raw_density = (x @ W + b)[..., 0]
     density = softplus(raw_density + c['density_bias'])
+    if cache is not None:
+        cache.update(acts_in=acts_in, pre=pre, trunk_out=x, raw_density=raw_density, cfg=c)
     if c['disable_rgb']:
         return dict(density=density, rgb=np.zeros_like(means))
     W, b = params[k]; k += 1
     bott = x @ W + b
     de = pos_enc(viewdirs, 0, c['deg_view'], append_identity=True)
     de = np.broadcast_to(de[..., None, :], bott.shape[:-1] + (de.shape[-1],))
-    x = np.concatenate([bott, de], -1)
+    view_in = np.concatenate([bott, de], -1)
     W, b = params[k]; k += 1
-    x = np.maximum(x @ W + b, 0)
+    hz = view_in @ W + b
+    h = np.maximum(hz, 0)
     W, b = params[k]; k += 1
-    rgb = 1 / (1 + np.exp(-(x @ W + b)))
-    rgb = rgb * (1 + 2 * c['rgb_padding']) - c['rgb_padding']
+    s = 1 / (1 + np.exp(-(h @ W + b)))
+    rgb = s * (1 + 2 * c['rgb_padding']) - c['rgb_padding']
+    if cache is not None:
+        cache.update(view_in=view_in, hz=hz, h=h, sig=s)
     return dict(density=density, rgb=rgb)
+
+
+def mlp_backward(params, cache, g_density, g_rgb=None):
+    """Closed-form backward of mlp_forward w.r.t. the parameters (upstream: jax.grad; positions get no gradient --
+    models.py:203-204 stop_level_grad and the inputs are not learned).  g_density [..., n], g_rgb [..., n, 3].
+    Returns a list of (d kernel, d bias) in the parameter order."""
+    c = cache['cfg']
+    D = c['net_depth']
+    flat = lambda a, w: np.reshape(a, (-1, w))
+    grads = [None] * len(params)
+    x = flat(cache['trunk_out'], cache['trunk_out'].shape[-1])
+    sig = 1 / (1 + np.exp(-(cache['raw_density'] + c['density_bias'])))          # softplus'
+    d_raw = np.reshape(g_density * sig, (-1, 1))
+    W_d, _ = params[D]
+    grads[D] = (x.T @ d_raw, d_raw.sum(0))
+    d_x = d_raw @ W_d.T
+    if not c['disable_rgb']:
+        s = flat(cache['sig'], 3)
+        d_pre = flat(g_rgb, 3) * (1 + 2 * c['rgb_padding']) * s * (1 - s)
+        h = flat(cache['h'], cache['h'].shape[-1])
+        W3, _ = params[D + 3]
+        grads[D + 3] = (h.T @ d_pre, d_pre.sum(0))
+        d_hz = (d_pre @ W3.T) * (flat(cache['hz'], h.shape[-1]) > 0)
+        vin = flat(cache['view_in'], cache['view_in'].shape[-1])
+        W2, _ = params[D + 2]
+        grads[D + 2] = (vin.T @ d_hz, d_hz.sum(0))
+        d_bott = (d_hz @ W2.T)[:, :c['bottleneck_width']]
+        W1, _ = params[D + 1]
+        grads[D + 1] = (x.T @ d_bott, d_bott.sum(0))
+        d_x = d_x + d_bott @ W1.T
+    for i in reversed(range(D)):
+        if i % c['skip_layer'] == 0 and i > 0:
+            d_x = d_x[:, :c['net_width']]                                        # the encoding part needs no gradient
+        z = flat(cache['pre'][i], c['net_width'])
+        d_z = d_x * (z > 0)
+        a_in = flat(cache['acts_in'][i], cache['acts_in'][i].shape[-1])
+        grads[i] = (a_in.T @ d_z, d_z.sum(0))
+        if i > 0:
+            d_x = d_z @ params[i][0].T
+    return grads
 
 
 def model_forward(prop_params, nerf_params, rays, train_frac=1.0, jitter01=None, basis=None, num_prop_samples=64,

@@ -1,5 +1,6 @@
 // extern "C" entry points of libmip360_hip.so (declared in include/mip360_hip.h).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/mip360_hip.h"
@@ -22,7 +23,19 @@ void mip360_launch_losses(hipStream_t st, int n, int s_nerf, int s_prop, int n_p
                           float* const* g_w_prop, float* ws, float prop_depth_weight, const float* const* dm_prop,
                           float* const* g_dm_prop);
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
-                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32);
+                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux);
+void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
+                               float* slabs, float* out, int ldc, float scale);
+void mip360_launch_col_sum(hipStream_t st, int M, int O, const void* dZ, int ld, int nslice, float* partial, float* out,
+                           float scale);
+void mip360_launch_head_backward(hipStream_t st, int64_t rows, const float* density, const float* g_density, const float* rgb,
+                                 const float* g_rgb, float pad, void* d_raw, int ld_raw, int raw_col, int raw_zero_to,
+                                 void* d_pre);
+void mip360_launch_sumsq(hipStream_t st, int64_t n, const float* g, float* partial, int nblocks);
+void mip360_launch_clip_mult(hipStream_t st, int n_partial, const float* partial, float max_norm, float* out);
+void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, float* m, float* v, const float* gmult, float lr,
+                        float b1, float b2, float eps, float bc1, float bc2);
+void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd);
 void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width);
 
 namespace {
@@ -119,13 +132,68 @@ int mip360_dir_encode(void* stream, int n_rays, int n_samples, const float* view
 }
 
 int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw, const float* bias,
-                       int act, float act_param, void* c_bf16, int ldc, float* c_f32, int ldc32) {
+                       int act, float act_param, void* c_bf16, int ldc, float* c_f32, int ldc32, const void* aux, int ldaux) {
   REQUIRE(m > 0 && n > 0 && k > 0 && k % 32 == 0, "k must be a positive multiple of 32");
   REQUIRE(a && w && (c_bf16 || c_f32), "non-null operands, at least one output");
   REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k, "leading dimensions: multiples of 8, >= k");
-  REQUIRE(act >= 0 && act <= 3, "act in 0..3");
-  mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, bias, act, act_param, c_bf16, ldc, c_f32, ldc32);
+  REQUIRE(act >= 0 && act <= 4, "act in 0..4");
+  REQUIRE(act != 4 || (aux && ldaux >= n), "act 4 needs the mask tensor");
+  mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, bias, act, act_param, c_bf16, ldc, c_f32, ldc32, aux, ldaux);
   return check_launch("linear_bf16");
+}
+
+int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz, int lddz,
+                            int ksplit, float* slabs, float* grad_kernel, int ldg, float scale) {
+  REQUIRE(m > 0 && n_in > 0 && n_out > 0 && n_in % 8 == 0 && ksplit >= 1 && ksplit <= 64, "sizes (n_in multiple of 8, 1 <= ksplit <= 64)");
+  REQUIRE(h && dz && slabs && grad_kernel && ldh >= n_in && lddz >= n_out && ldg >= n_out && ldh % 8 == 0 && lddz % 8 == 0, "pointers / leading dimensions");
+  mip360_launch_grad_weight((hipStream_t)stream, m, n_in, n_out, h, ldh, dz, lddz, ksplit, slabs, grad_kernel, ldg, scale);
+  return check_launch("grad_weight_bf16");
+}
+
+int mip360_grad_bias_bf16(void* stream, int m, int n_out, const void* dz, int lddz, int nslice, float* partial, float* grad_bias,
+                          float scale) {
+  REQUIRE(m > 0 && n_out > 0 && dz && partial && grad_bias && nslice >= 1 && nslice <= 1024 && lddz >= n_out, "arguments");
+  mip360_launch_col_sum((hipStream_t)stream, m, n_out, dz, lddz, nslice, partial, grad_bias, scale);
+  return check_launch("grad_bias_bf16");
+}
+
+int mip360_head_backward(void* stream, int64_t rows, const float* density, const float* g_density, const float* rgb,
+                         const float* g_rgb, float rgb_padding, void* d_raw_bf16, int ld_raw, int raw_col, int raw_zero_to,
+                         void* d_pre_bf16) {
+  REQUIRE(rows > 0 && density && g_density && d_raw_bf16 && raw_col >= 0 && raw_zero_to <= ld_raw && raw_col < ld_raw, "arguments");
+  REQUIRE(!d_pre_bf16 || (rgb && g_rgb), "colour head needs rgb and g_rgb");
+  mip360_launch_head_backward((hipStream_t)stream, rows, density, g_density, rgb, g_rgb, rgb_padding, d_raw_bf16, ld_raw, raw_col,
+                              raw_zero_to, d_pre_bf16);
+  return check_launch("head_backward");
+}
+
+int mip360_sum_squares(void* stream, int64_t n, const float* g, float* partial, int n_blocks) {
+  REQUIRE(n > 0 && g && partial && n_blocks >= 1 && n_blocks <= 1024, "arguments");
+  mip360_launch_sumsq((hipStream_t)stream, n, g, partial, n_blocks);
+  return check_launch("sum_squares");
+}
+
+int mip360_clip_multiplier(void* stream, int n_partial, const float* partial, float grad_max_norm, float* mult_and_norm) {
+  REQUIRE(n_partial >= 1 && partial && mult_and_norm, "arguments");
+  mip360_launch_clip_mult((hipStream_t)stream, n_partial, partial, grad_max_norm, mult_and_norm);
+  return check_launch("clip_multiplier");
+}
+
+int mip360_adam_step(void* stream, int64_t n, float* params, const float* grads, float* mu, float* nu, const float* grad_mult,
+                     int step, double lr, double beta1, double beta2, double eps) {
+  REQUIRE(n > 0 && params && grads && mu && nu && step >= 1, "arguments");
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  mip360_launch_adam((hipStream_t)stream, n, params, grads, mu, nu, grad_mult, (float)lr, (float)beta1, (float)beta2, (float)eps,
+                     (float)bc1, (float)bc2);
+  return check_launch("adam_step");
+}
+
+int mip360_pack_weight(void* stream, int n_in, int n_out, const float* kernel, void* fwd_bf16, int ld_fwd, void* bwd_bf16,
+                       int ld_bwd) {
+  REQUIRE(n_in > 0 && n_out > 0 && kernel && (fwd_bf16 || bwd_bf16), "arguments");
+  REQUIRE((!fwd_bf16 || ld_fwd >= n_in) && (!bwd_bf16 || ld_bwd >= n_out), "leading dimensions");
+  mip360_launch_pack_weight((hipStream_t)stream, n_in, n_out, kernel, fwd_bf16, ld_fwd, bwd_bf16, ld_bwd);
+  return check_launch("pack_weight");
 }
 
 }  // extern "C"

@@ -24,7 +24,8 @@ template <int ACT>
 __global__ __launch_bounds__(256) void linear_bf16_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda,
                                                           const __bf16* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc,
-                                                          float* __restrict__ C32, int ldc32, float act_param) {
+                                                          float* __restrict__ C32, int ldc32, float act_param,
+                                                          const __bf16* __restrict__ aux, int ldaux) {
   __shared__ __attribute__((aligned(16))) __bf16 sA[2][BM * LDS_ROW];
   __shared__ __attribute__((aligned(16))) __bf16 sB[2][BN * LDS_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(int M, int N, int K, c
         float v = acc[i][j][r] + b;
         if (ACT == 1) v = fmaxf(v, 0.f);
         if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }   // softplus(raw + density_bias)
+        if (ACT == 4) v = (float)aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;                             // ReLU mask of the layer's saved output
         if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;                // padded sigmoid
         if (C16) C16[(size_t)m * ldc + n] = (__bf16)v;
         if (C32) C32[(size_t)m * ldc32 + n] = v;
@@ -110,14 +112,15 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(int M, int N, int K, c
 }  // namespace mip360
 
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
-                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32) {
+                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux) {
   using namespace mip360;
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
 #define MIP360_LAUNCH(ACT) hipLaunchKernelGGL(linear_bf16_kernel<ACT>, dim3(tiles), dim3(256), 0, st, M, N, K, (const __bf16*)A, \
-                                              lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param)
+                                              lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux)
   if (act == 1) MIP360_LAUNCH(1);
   else if (act == 2) MIP360_LAUNCH(2);
   else if (act == 3) MIP360_LAUNCH(3);
+  else if (act == 4) MIP360_LAUNCH(4);
   else MIP360_LAUNCH(0);
 #undef MIP360_LAUNCH
 }

@@ -1,0 +1,254 @@
+// Training-side kernels of the MipNeRF-360 path: weight-gradient GEMM, bias gradients, head
+// backward, gradient-norm clipping and Adam.  Upstream relies on jax.grad + optax (internal/train_utils.py:215-236,
+// 303-370); the closed forms are restated in oracle/mip360_oracle.py (mlp_backward) and checked there by finite
+// differences.
+//
+//   grad_weight_bf16 : dK[I, O] = H[M, I]^T * dZ[M, O]  (flax kernel layout [in, out]), bf16 operands, f32 result.
+//     The contraction runs over the sample rows M (131 072 at 4096 rays x 32 samples) -- both operands are
+//     row-major with M as the slow axis, so MFMA fragments (8 consecutive k per lane) come from
+//     ds_read_b64_tr_b16 transposed reads of row-major [32 rows][128 cols] LDS tiles, as in the NeRF++ dw_kernel.
+//     Split-K: blockIdx = (tile_i, tile_o, slice); every slice writes its own f32 slab and a second kernel sums the
+//     slabs in a fixed order (deterministic, no atomics).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace mip360 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GT = 128;            // output tile (both ways)
+constexpr int GK = 32;             // rows per K step
+constexpr int GROWB = GT * 2 + 16; // LDS row stride in bytes (272: consecutive rows 4 banks apart)
+
+extern __shared__ __attribute__((aligned(16))) char gw_smem[];
+
+__device__ __forceinline__ bf16x8 tr_frag(uint32_t off) {
+  __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)gw_smem;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + GROWB));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void grad_weight_kernel(int M, int I, int O, const __bf16* __restrict__ H, int ldh,
+                                                          const __bf16* __restrict__ dZ, int lddz, int ksplit,
+                                                          float* __restrict__ slabs, int ldc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wo = wave & 1;
+  const int tiles_o = (O + GT - 1) / GT, tiles_i = (I + GT - 1) / GT;
+  int b = blockIdx.x;
+  const int slice = b / (tiles_i * tiles_o);
+  b -= slice * tiles_i * tiles_o;
+  const int ti = b / tiles_o, to = b - ti * tiles_o;
+  const int i0 = ti * GT, o0 = to * GT;
+  // rows of this slice, in multiples of GK
+  const int64_t steps_total = ((int64_t)M + GK - 1) / GK;
+  const int64_t per = (steps_total + ksplit - 1) / ksplit;
+  const int64_t s_begin = (int64_t)slice * per, s_end = s_begin + per < steps_total ? s_begin + per : steps_total;
+  char* sH = gw_smem;                                   // [2][GK][GROWB]
+  char* sZ = gw_smem + 2 * GK * GROWB;
+  // loads: a tile is 32 rows x 256 B = 512 16-byte chunks, 2 per thread: chunk c -> row c >> 4, byte (c & 15) * 16
+  uint4 rh[2], rz[2];
+  auto fetch = [&](int64_t step) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = tid + q * 256, row = c >> 4, cb = (c & 15) * 8;         // cb in elements
+      const int64_t m = step * GK + row;
+      const bool rok = m < M;
+      rh[q] = (rok && i0 + cb < I) ? *(const uint4*)(H + (size_t)m * ldh + i0 + cb) : make_uint4(0, 0, 0, 0);
+      rz[q] = (rok && o0 + cb < O) ? *(const uint4*)(dZ + (size_t)m * lddz + o0 + cb) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = tid + q * 256, row = c >> 4, cbyte = (c & 15) * 16;
+      *(uint4*)(sH + (buf * GK + row) * GROWB + cbyte) = rh[q];
+      *(uint4*)(sZ + (buf * GK + row) * GROWB + cbyte) = rz[q];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  // transposed-read lane map (see nerfpp_dw.hip): 16-lane group g = lane >> 4: k half g >> 1, column sub-block g & 1;
+  // lane a16 = lane & 15: row pair a16 >> 2, 4-column piece a16 & 3
+  const int g = lane >> 4, a16 = lane & 15;
+  const uint32_t lane_off = (uint32_t)((8 * (g >> 1) + 2 * (a16 >> 2)) * GROWB + (16 * (g & 1) + 4 * (a16 & 3)) * 2);
+  if (s_begin < s_end) {
+    fetch(s_begin);
+    stash(0);
+  }
+  __syncthreads();
+  for (int64_t st = s_begin; st < s_end; ++st) {
+    const int buf = (int)((st - s_begin) & 1);
+    if (st + 1 < s_end) fetch(st + 1);
+#pragma unroll
+    for (int kk = 0; kk < GK / 16; ++kk) {
+      bf16x8 fh[2], fz[2];
+      const uint32_t base = (uint32_t)((buf * GK + kk * 16) * GROWB) + lane_off;
+#pragma unroll
+      for (int x = 0; x < 2; ++x) fh[x] = tr_frag(base + (uint32_t)((wi * 64 + x * 32) * 2));
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fz[y] = tr_frag((uint32_t)(2 * GK * GROWB) + base + (uint32_t)((wo * 64 + y * 32) * 2));
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[x], fz[y], acc[x][y], 0, 0, 0);
+    }
+    if (st + 1 < s_end) stash(buf ^ 1);
+    __syncthreads();
+  }
+  float* slab = slabs + (size_t)slice * I * ldc;
+  const int hi = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    const int o = o0 + wo * 64 + y * 32 + j;
+    if (o >= O) continue;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (i < I) slab[(size_t)i * ldc + o] = acc[x][y][r];
+      }
+  }
+}
+
+// out[e] = scale * sum_s slabs[s][e], fixed order
+__global__ void slab_sum_kernel(int64_t n, int ksplit, const float* __restrict__ slabs, float scale, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < ksplit; ++s) acc += slabs[(size_t)s * n + e];
+  out[e] = acc * scale;
+}
+
+// bias gradients: partial[slice][o] = sum over the slice's rows of dZ[m][o]
+__global__ __launch_bounds__(256) void col_sum_kernel(int M, int O, const __bf16* __restrict__ dZ, int ld, int nslice,
+                                                      float* __restrict__ partial) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int slice = blockIdx.y;
+  const int64_t per = ((int64_t)M + nslice - 1) / nslice;
+  const int64_t m0 = (int64_t)slice * per, m1 = m0 + per < M ? m0 + per : M;
+  if (o >= O) return;
+  float acc = 0.f;
+  for (int64_t m = m0; m < m1; ++m) acc += (float)dZ[(size_t)m * ld + o];
+  partial[(size_t)slice * O + o] = acc;
+}
+
+// Heads (models.py:497, 573-594): density = softplus(raw - 1) -> d raw = g * (1 - exp(-density));
+// rgb = sigmoid(pre) (1 + 2p) - p -> d pre = g (1 + 2p) s (1 - s), s = (rgb + p) / (1 + 2p).
+// d_raw goes to column `raw_col` of a bf16 [rows, ld_raw] tensor (the columns next to it up to a multiple of 32 are
+// zero-filled by the caller once); d_pre to columns 0..2 of a bf16 [rows, 32] tensor (3..31 zero-filled here).
+__global__ void head_backward_kernel(int64_t rows, const float* __restrict__ density, const float* __restrict__ g_density,
+                                     const float* __restrict__ rgb, const float* __restrict__ g_rgb, float pad,
+                                     __bf16* __restrict__ d_raw, int ld_raw, int raw_col, int raw_zero_to,
+                                     __bf16* __restrict__ d_pre) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float v = g_density[r] * (1.f - expf(-density[r]));
+  d_raw[(size_t)r * ld_raw + raw_col] = (__bf16)v;
+  for (int c = raw_col + 1; c < raw_zero_to; ++c) d_raw[(size_t)r * ld_raw + c] = (__bf16)0.f;
+  if (d_pre) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float s = (rgb[r * 3 + c] + pad) / (1.f + 2.f * pad);
+      d_pre[(size_t)r * 32 + c] = (__bf16)(g_rgb[r * 3 + c] * (1.f + 2.f * pad) * s * (1.f - s));
+    }
+    for (int c = 3; c < 32; ++c) d_pre[(size_t)r * 32 + c] = (__bf16)0.f;
+  }
+}
+
+// deterministic sum of squares: partial[b] per block, then block 0 style reduce by a second launch
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ partial) {
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)g[i] * g[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = (float)sh[0];
+}
+// clip_gradients (train_utils.py:215-236): mult = min(1, max_norm / (eps + ||g||)) over all tensors of ONE MLP;
+// `partials` holds the per-tensor partial sums of that MLP back to back
+__global__ void clip_mult_kernel(int n_partial, const float* __restrict__ partial, float max_norm, float* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  double acc = 0;
+  for (int i = 0; i < n_partial; ++i) acc += (double)partial[i];
+  const float norm = (float)sqrt(acc);
+  out[0] = max_norm > 0.f ? fminf(1.f, max_norm / (1.1920928955078125e-07f + norm)) : 1.f;
+  out[1] = norm;
+}
+// optax.adam (scale_by_adam + scale(-lr)): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; update = -lr m_hat / (sqrt(v_hat) + eps)
+__global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, const float* __restrict__ gmult, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * (gmult ? gmult[0] : 1.f);
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+}
+// f32 [rows, cols] parameter (flax kernel [in, out]) -> bf16 copies: fwd [out, in_pad] (transposed, zero padded) and
+// bwd [in_pad?]: the kernel as stored, [in, out_pad], both K-contiguous for the NT dense-layer kernel
+__global__ void pack_weight_kernel(int n_in, int n_out, const float* __restrict__ k, __bf16* __restrict__ fwd, int ld_fwd,
+                                   __bf16* __restrict__ bwd, int ld_bwd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n_in * n_out) return;
+  const int i = (int)(e / n_out), o = (int)(e - (int64_t)i * n_out);
+  const __bf16 v = (__bf16)k[e];
+  if (fwd) fwd[(size_t)o * ld_fwd + i] = v;
+  if (bwd) bwd[(size_t)i * ld_bwd + o] = v;
+}
+
+}  // namespace mip360
+
+using namespace mip360;
+
+void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
+                               float* slabs, float* out, int ldc, float scale) {
+  const int tiles = ((I + GT - 1) / GT) * ((O + GT - 1) / GT);
+  const size_t lds = 4 * GK * GROWB;
+  hipLaunchKernelGGL(grad_weight_kernel, dim3(tiles * ksplit), dim3(256), lds, st, M, I, O, (const __bf16*)H, ldh,
+                     (const __bf16*)dZ, lddz, ksplit, slabs, ldc);
+  const int64_t n = (int64_t)I * ldc;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ksplit, slabs, scale, out);
+}
+void mip360_launch_col_sum(hipStream_t st, int M, int O, const void* dZ, int ld, int nslice, float* partial, float* out,
+                           float scale) {
+  hipLaunchKernelGGL(col_sum_kernel, dim3((O + 255) / 256, nslice), dim3(256), 0, st, M, O, (const __bf16*)dZ, ld, nslice, partial);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((O + 255) / 256), dim3(256), 0, st, (int64_t)O, nslice, partial, scale, out);
+}
+void mip360_launch_head_backward(hipStream_t st, int64_t rows, const float* density, const float* g_density, const float* rgb,
+                                 const float* g_rgb, float pad, void* d_raw, int ld_raw, int raw_col, int raw_zero_to,
+                                 void* d_pre) {
+  hipLaunchKernelGGL(head_backward_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, density, g_density, rgb,
+                     g_rgb, pad, (__bf16*)d_raw, ld_raw, raw_col, raw_zero_to, (__bf16*)d_pre);
+}
+void mip360_launch_sumsq(hipStream_t st, int64_t n, const float* g, float* partial, int nblocks) {
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, g, partial);
+}
+void mip360_launch_clip_mult(hipStream_t st, int n_partial, const float* partial, float max_norm, float* out) {
+  hipLaunchKernelGGL(clip_mult_kernel, dim3(1), dim3(64), 0, st, n_partial, partial, max_norm, out);
+}
+void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, float* m, float* v, const float* gmult, float lr,
+                        float b1, float b2, float eps, float bc1, float bc2) {
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, gmult, lr, b1, b2, eps, bc1, bc2);
+}
+void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd) {
+  const int64_t n = (int64_t)n_in * n_out;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_in, n_out, k, (__bf16*)fwd, ld_fwd,
+                     (__bf16*)bwd, ld_bwd);
+}

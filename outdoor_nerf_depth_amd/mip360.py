@@ -36,7 +36,16 @@ SYMBOLS = {
                                 C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp,
                                 _fpp, _fp, C.c_float, _fpp, _fpp]),
     'mip360_linear_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, _fp,
-                                     C.c_int, _fp, C.c_int]),
+                                     C.c_int, _fp, C.c_int, _fp, C.c_int]),
+    'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
+                                          C.c_float]),
+    'mip360_grad_bias_bf16': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_float]),
+    'mip360_head_backward': (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'mip360_sum_squares': (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int]),
+    'mip360_clip_multiplier': (C.c_int, [_fp, C.c_int, _fp, C.c_float, _fp]),
+    'mip360_adam_step': (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                   C.c_double]),
+    'mip360_pack_weight': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int]),
     'mip360_dir_encode': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int]),
 }
 _lib = None
@@ -131,14 +140,14 @@ def cast_encode(tdist, origins, directions, radii, basis_t, out=None, bf16=True,
     return out
 
 
-def linear(a, w, bias, act=0, act_param=0.0, out_bf16=None, out_f32=None, m=None, n=None, k=None):
-    """act(A W^T + b): a [M, lda] bf16 (k leading columns used), w [N, ldw] bf16."""
+def linear(a, w, bias, act=0, act_param=0.0, out_bf16=None, out_f32=None, m=None, n=None, k=None, aux=None):
+    """act(A W^T + b): a [M, lda] bf16 (k leading columns used), w [N, ldw] bf16.  act 4: multiply by (aux > 0)."""
     m = a.shape[0] if m is None else m
     n = w.shape[0] if n is None else n
     k = w.shape[1] if k is None else k
     ld = lambda t: 0 if t is None else (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))   # size-1 dims have free strides
     _check(lib().mip360_linear_bf16(_stream(), m, n, k, _p(a), ld(a), _p(w), ld(w), _p(bias), int(act), float(act_param),
-                                    _p(out_bf16), ld(out_bf16), _p(out_f32), ld(out_f32)), 'mip360_linear_bf16')
+                                    _p(out_bf16), ld(out_bf16), _p(out_f32), ld(out_f32), _p(aux), ld(aux)), 'mip360_linear_bf16')
 
 
 def render_level(density, rgb_samples, tdist, directions, opaque_background=True, bg_rgb=1.0):
@@ -305,3 +314,288 @@ class Mip360Model(object):
             renderings.append(r)
             history.append(dict(sdist=sdist, tdist=tdist, weights=weights, density=density, rgb=rgb_s))
         return renderings, history
+
+
+# ----------------------------------------------------------------------------------------------------- training
+def learning_rate(step, lr_init=2e-3, lr_final=2e-5, max_steps=250000, lr_delay_steps=512, lr_delay_mult=0.01):
+    """math.learning_rate_decay (internal/math.py:67-97) with the Config defaults (configs.py:91,118-121)."""
+    delay = 1.0
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+    t = np.clip(step / max_steps, 0, 1)
+    return float(delay * np.exp(t * (np.log(lr_final) - np.log(lr_init)) + np.log(lr_init)))
+
+
+class TrainableMLP(object):
+    """One MLP of the model for training: float32 master parameters (flax layout, one flat buffer with per-tensor
+    views), Adam moments, gradients, and the bf16 operand copies the dense-layer kernels read -- forward
+    [out, in_padded] and backward [in, out_padded] (the density and bottleneck heads share one stacked backward
+    operand so that dH_trunk = [d bottleneck | d raw_density] * [K_bottleneck | K_density]^T is a single GEMM)."""
+
+    def __init__(self, params, cfg, device):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.W, self.depth = cfg['net_width'], cfg['net_depth']
+        self.shapes = [tuple(np.asarray(k).shape) for k, _ in params]
+        sizes = []
+        for (i, o) in self.shapes:
+            sizes += [i * o, o]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n = int(self.offsets[-1])
+        self.flat = torch.empty(n, device=self.device)
+        for t, (k, b) in enumerate(params):
+            self.kernel(t).copy_(torch.from_numpy(np.asarray(k, np.float32)))
+            self.bias(t).copy_(torch.from_numpy(np.asarray(b, np.float32)))
+        self.grads = torch.zeros_like(self.flat)
+        self.mu, self.nu = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        D, W = self.depth, self.W
+        self.in_pad = []
+        for t, (i, o) in enumerate(self.shapes):
+            if t == 0:
+                self.in_pad.append(IPE_LD)
+            elif t < D and i == W + IPE_DIM:
+                self.in_pad.append(W + IPE_LD)
+            elif not cfg['disable_rgb'] and t == D + 2:
+                self.in_pad.append(BOTTLENECK + DIR_LD)
+            else:
+                self.in_pad.append(i)
+        bf = lambda *sh: torch.zeros(*sh, dtype=torch.bfloat16, device=self.device)
+        self.w = [bf(o, self.in_pad[t]) for t, (i, o) in enumerate(self.shapes)]           # forward operands
+        self.b = [self.bias(t) for t in range(len(self.shapes))]
+        self.wb = {}                                                                         # backward operands
+        for t in range(1, D):
+            self.wb[t] = bf(self.in_pad[t], W)
+        self.head_k = (BOTTLENECK + 32) if not cfg['disable_rgb'] else 32
+        self.wb['heads'] = bf(W, self.head_k)                    # [K_bottleneck | K_density | 0], or [K_density | 0]
+        if not cfg['disable_rgb']:
+            self.wb[D + 2] = bf(BOTTLENECK + DIR_LD, VIEW_WIDTH)
+            self.wb[D + 3] = bf(VIEW_WIDTH, 32)
+        self.repack()
+
+    def kernel(self, t, buf=None):
+        i, o = self.shapes[t]
+        a = int(self.offsets[2 * t])
+        return (self.flat if buf is None else buf)[a:a + i * o].view(i, o)
+
+    def bias(self, t, buf=None):
+        a = int(self.offsets[2 * t + 1])
+        return (self.flat if buf is None else buf)[a:a + self.shapes[t][1]]
+
+    def repack(self):
+        """float32 master -> bf16 operand copies (after every Adam step)."""
+        D = self.depth
+        L = lib()
+        for t, (i, o) in enumerate(self.shapes):
+            k = self.kernel(t)
+            bwd, ldb = None, 0
+            if 1 <= t < D:
+                bwd, ldb = self.wb[t], self.W
+            elif t == D:                                                      # density head -> column 256 (or 0)
+                col = BOTTLENECK if not self.cfg['disable_rgb'] else 0
+                bwd, ldb = self.wb['heads'][:, col:], self.head_k
+            elif t == D + 1:
+                bwd, ldb = self.wb['heads'], self.head_k
+            elif t in (D + 2, D + 3):
+                bwd, ldb = self.wb[t], self.wb[t].shape[1]
+            _check(L.mip360_pack_weight(_stream(), i, o, _p(k), _p(self.w[t]), self.in_pad[t], _p(bwd), ldb), 'mip360_pack_weight')
+
+    def state(self):
+        return [(self.kernel(t).clone(), self.bias(t).clone()) for t in range(len(self.shapes))]
+
+
+def _grad_weight(h, dz, n_in, n_out, out, scratch):
+    m = h.shape[0]
+    tiles = ((n_in + 127) // 128) * ((n_out + 127) // 128)
+    ksplit = int(max(1, min(64, (512 + tiles - 1) // tiles, (m + 31) // 32)))
+    need = ksplit * n_in * n_out
+    if scratch[0] is None or scratch[0].numel() < need:
+        scratch[0] = torch.empty(need, device=h.device)
+    ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    _check(lib().mip360_grad_weight_bf16(_stream(), m, n_in, n_out, _p(h), ld(h), _p(dz), ld(dz), ksplit, _p(scratch[0]), _p(out),
+                                         n_out, 1.0), 'mip360_grad_weight_bf16')
+
+
+def _grad_bias(dz, n_out, out, scratch):
+    m = dz.shape[0]
+    nslice = int(max(1, min(256, m // 256)))
+    if scratch[1] is None or scratch[1].numel() < nslice * n_out:
+        scratch[1] = torch.empty(nslice * max(n_out, 1024), device=dz.device)
+    ld = dz.stride(0) if dz.shape[0] > 1 else max(dz.shape[1], dz.stride(0))
+    _check(lib().mip360_grad_bias_bf16(_stream(), m, n_out, _p(dz), ld, nslice, _p(scratch[1]), _p(out), 1.0),
+           'mip360_grad_bias_bf16')
+
+
+def mlp_forward_train(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
+    """mlp_forward keeping what the backward needs (every layer's bf16 output, the view-branch input and hidden state)."""
+    W, D = tm.W, tm.depth
+    dev = enc_buf.device
+    bf = lambda c: torch.empty(rows, c, dtype=torch.bfloat16, device=dev)
+    enc = enc_buf[:, W:]
+    saved = dict(enc_buf=enc_buf, H=[], inputs=[])
+    x, x_k = enc, IPE_LD
+    for i in range(D):
+        skip_out = (i % SKIP_LAYER == 0 and i > 0)
+        out = enc_buf[:, :W] if skip_out else bf(W)
+        linear(x, tm.w[i], tm.b[i], act=1, out_bf16=out, m=rows, n=W, k=x_k)
+        saved['inputs'].append((x, x_k))
+        saved['H'].append(out)
+        x, x_k = (enc_buf, W + IPE_LD) if skip_out else (out, W)
+    saved['trunk'] = (x, x_k)
+    density = torch.empty(rows, 1, device=dev)
+    linear(x, tm.w[D], tm.b[D], act=2, act_param=DENSITY_BIAS, out_f32=density, m=rows, n=1, k=x_k)
+    saved['density'] = density
+    rgb = None
+    if not tm.cfg['disable_rgb']:
+        view_in = bf(BOTTLENECK + DIR_LD)
+        linear(x, tm.w[D + 1], tm.b[D + 1], act=0, out_bf16=view_in, m=rows, n=BOTTLENECK, k=x_k)
+        _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0),
+                                       BOTTLENECK, DIR_LD), 'mip360_dir_encode')
+        h = bf(VIEW_WIDTH)
+        linear(view_in, tm.w[D + 2], tm.b[D + 2], act=1, out_bf16=h, m=rows, n=VIEW_WIDTH, k=BOTTLENECK + DIR_LD)
+        rgb = torch.empty(rows, 3, device=dev)
+        linear(h, tm.w[D + 3], tm.b[D + 3], act=3, act_param=RGB_PADDING, out_f32=rgb, m=rows, n=3, k=VIEW_WIDTH)
+        saved.update(view_in=view_in, h=h, rgb=rgb)
+    return density[:, 0], rgb, saved
+
+
+def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch):
+    """Parameter gradients of one MLP into tm.grads (oracle: mip360_oracle.mlp_backward).  g_density [rows] f32,
+    g_rgb [rows, 3] f32 or None."""
+    W, D = tm.W, tm.depth
+    dev = tm.device
+    G = tm.grads
+    bf = lambda c: torch.empty(rows, c, dtype=torch.bfloat16, device=dev)
+    nerf = not tm.cfg['disable_rgb']
+    trunk, trunk_k = saved['trunk']
+    heads = bf(tm.head_k)                                            # [d bottleneck (256) | d raw | 0] or [d raw | 0]
+    raw_col = BOTTLENECK if nerf else 0
+    d_pre = bf(32) if nerf else None
+    _check(lib().mip360_head_backward(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)),
+                                      _p(saved.get('rgb')), _p(_f32(g_rgb).reshape(-1, 3)) if nerf else None, RGB_PADDING,
+                                      _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
+    if nerf:
+        h, view_in = saved['h'], saved['view_in']
+        _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch)
+        _grad_bias(d_pre, 3, tm.bias(D + 3, G), scratch)
+        d_hz = bf(VIEW_WIDTH)
+        linear(d_pre, tm.wb[D + 3], None, act=4, out_bf16=d_hz, m=rows, n=VIEW_WIDTH, k=32, aux=h)
+        gk = torch.empty(BOTTLENECK + DIR_LD, VIEW_WIDTH, device=dev)
+        _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, gk, scratch)
+        tm.kernel(D + 2, G).copy_(gk[:BOTTLENECK + DIR_DIM])
+        _grad_bias(d_hz, VIEW_WIDTH, tm.bias(D + 2, G), scratch)
+        linear(d_hz, tm.wb[D + 2], None, act=0, out_bf16=heads, m=rows, n=BOTTLENECK, k=VIEW_WIDTH)     # -> heads[:, :256]
+        _grad_weight(trunk, heads, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch)
+        _grad_bias(heads, BOTTLENECK, tm.bias(D + 1, G), scratch)
+    d_raw = heads[:, raw_col:]
+    _grad_weight(trunk, d_raw, trunk_k, 1, tm.kernel(D, G), scratch)
+    _grad_bias(d_raw, 1, tm.bias(D, G), scratch)
+    # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
+    dz = bf(W)
+    linear(heads, tm.wb['heads'], None, act=4, out_bf16=dz, m=rows, n=W, k=tm.head_k, aux=saved['H'][D - 1])
+    for i in reversed(range(D)):
+        x, x_k = saved['inputs'][i]
+        if x_k == tm.shapes[i][0]:
+            _grad_weight(x, dz, x_k, W, tm.kernel(i, G), scratch)
+        else:                                                        # padded input (504 -> 512 encoding columns)
+            gk = torch.empty(x_k, W, device=dev)
+            _grad_weight(x, dz, x_k, W, gk, scratch)
+            tm.kernel(i, G).copy_(gk[:tm.shapes[i][0]])
+        _grad_bias(dz, W, tm.bias(i, G), scratch)
+        if i > 0:
+            nxt = bf(W)
+            linear(dz, tm.wb[i], None, act=4, out_bf16=nxt, m=rows, n=W, k=W, aux=saved['H'][i - 1])
+            dz = nxt
+
+
+class Mip360Trainer(object):
+    """One optimisation step of train_utils.create_train_step (:239-370) for configs/360.gin on the HIP kernels:
+    model forward (3 levels), loss terms (charb data + depth on distance_mean + interlevel + distortion), backward
+    through the compositing and the MLPs, per-MLP gradient-norm clipping, Adam with the log-decayed learning rate.
+    Data parallel: the flat gradient buffers are averaged over ranks (jax.lax.pmean, :340-342) with one all-reduce
+    per MLP (torch.distributed, backend nccl = RCCL)."""
+
+    def __init__(self, prop_params, nerf_params, device, max_steps=250000, lambda_depth=0.1, depth_loss_type='mse',
+                 world_size=1, grad_max_norm=0.001, adam_eps=1e-6, **model_kw):
+        self.device = torch.device(device)
+        self.prop = TrainableMLP(prop_params, PROP_CFG, device)
+        self.nerf = TrainableMLP(nerf_params, NERF_CFG, device)
+        self.basis_t = torch.from_numpy(pos_basis_t()).to(self.device)
+        self.cfg = dict(num_prop_samples=64, num_nerf_samples=32, num_levels=3, anneal_slope=10., dilation_multiplier=0.5,
+                        dilation_bias=0.0025, bg_rgb=1.0)
+        self.cfg.update(model_kw)
+        self.max_steps, self.lambda_depth, self.depth_loss_type = max_steps, lambda_depth, depth_loss_type
+        self.world_size, self.grad_max_norm, self.adam_eps = world_size, grad_max_norm, adam_eps
+        self.step = 0
+        self.scratch = [None, None]
+        self.partials = torch.empty(2, 256, device=self.device)
+        self.clip = torch.empty(2, 2, device=self.device)
+
+    def forward(self, rays, train_frac, jitter01, training=True):
+        c = self.cfg
+        n = rays['origins'].shape[0]
+        dev = self.device
+        sdist = torch.tensor([[0., 1.]], device=dev).repeat(n, 1)
+        weights = torch.ones(n, 1, device=dev)
+        prod = 1
+        levels = []
+        for lvl in range(c['num_levels']):
+            is_prop = lvl < c['num_levels'] - 1
+            ns = c['num_prop_samples'] if is_prop else c['num_nerf_samples']
+            dilation = c['dilation_bias'] + c['dilation_multiplier'] / prod
+            prod *= ns
+            s = c['anneal_slope']
+            anneal = (s * train_frac) / ((s - 1) * train_frac + 1) if s > 0 else 1.
+            sdist, tdist = resample(sdist, weights, dilation if lvl > 0 else 0.0, anneal, ns, rays['near'], rays['far'],
+                                    None if jitter01 is None else jitter01[lvl])
+            tm = self.prop if is_prop else self.nerf
+            rows = n * ns
+            enc_buf = torch.empty(rows, tm.W + IPE_LD, dtype=torch.bfloat16, device=dev)
+            cast_encode(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, out=enc_buf[:, tm.W:],
+                        ld=tm.W + IPE_LD)
+            density, rgb, saved = mlp_forward_train(tm, enc_buf, rows, rays['viewdirs'], n, ns)
+            density = density.reshape(n, ns)
+            rgb_s = rgb.reshape(n, ns, 3) if rgb is not None else None
+            r = render_level(density, rgb_s, tdist, rays['directions'], True, c['bg_rgb'])
+            weights = r['weights']
+            levels.append(dict(sdist=sdist, tdist=tdist, density=density, rgb_s=rgb_s, saved=saved, rows=rows, ns=ns, **r))
+        return levels
+
+    def train_step(self, rays, rgb_gt, depth_sup, jitter01=None):
+        """rays / rgb_gt [n,3] / depth_sup [n] on the device.  Returns the scalars tensor of mip360_losses."""
+        self.step += 1
+        train_frac = float(np.clip((self.step - 1) / (self.max_steps - 1), 0, 1))          # train.py: step / max_steps
+        if jitter01 is None:
+            n = rays['origins'].shape[0]
+            jitter01 = [torch.rand(n, device=self.device) for _ in range(self.cfg['num_levels'])]
+        lv = self.forward(rays, train_frac, jitter01)
+        props, nerf = lv[:-1], lv[-1]
+        sc, g_rgb, g_dm, g_wn, g_wp, g_dmp = losses(
+            nerf['rgb'], rgb_gt, nerf['distance_mean'], depth_sup, nerf['sdist'], nerf['weights'], [p['sdist'] for p in props],
+            [p['weights'] for p in props], depth_loss_type=self.depth_loss_type, lambda_depth=self.lambda_depth,
+            dm_prop=[p['distance_mean'] for p in props] if self.depth_loss_type else None)
+        # NeRF level
+        gd, grgbs = render_level_backward(nerf['density'], nerf['rgb_s'], nerf['tdist'], rays['directions'], g_wn, g_rgb, g_dm,
+                                          True, self.cfg['bg_rgb'])
+        mlp_backward(self.nerf, nerf['saved'], nerf['rows'], gd, grgbs, self.scratch)
+        # proposal levels share the PropMLP: gradients add up
+        acc = None
+        for k, p in enumerate(props):
+            gd, _ = render_level_backward(p['density'], None, p['tdist'], rays['directions'], g_wp[k], None,
+                                          g_dmp[k] if g_dmp else None, True, self.cfg['bg_rgb'])
+            mlp_backward(self.prop, p['saved'], p['rows'], gd, None, self.scratch)
+            acc = self.prop.grads.clone() if acc is None else acc.add_(self.prop.grads)
+        self.prop.grads.copy_(acc)
+        lr = learning_rate(self.step, max_steps=self.max_steps)
+        L = lib()
+        for k, tm in enumerate((self.nerf, self.prop)):
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.all_reduce(tm.grads)
+                tm.grads.div_(self.world_size)
+            n = tm.grads.numel()
+            _check(L.mip360_sum_squares(_stream(), n, _p(tm.grads), _p(self.partials[k]), 256), 'mip360_sum_squares')
+            _check(L.mip360_clip_multiplier(_stream(), 256, _p(self.partials[k]), float(self.grad_max_norm), _p(self.clip[k])),
+                   'mip360_clip_multiplier')
+            _check(L.mip360_adam_step(_stream(), n, _p(tm.flat), _p(tm.grads), _p(tm.mu), _p(tm.nu), _p(self.clip[k]), self.step,
+                                      lr, 0.9, 0.999, self.adam_eps), 'mip360_adam_step')
+            tm.repack()
+        return sc

@@ -304,3 +304,96 @@ def test_model_forward_matches_oracle(M):
     for h in hist:
         s = N(h['sdist'])
         assert (np.diff(s) >= 0).all() and s.min() >= 0 and s.max() <= 1
+
+
+# ---------------------------------------------------------------------------------------------------- training side
+@pytest.mark.parametrize('m,n_in,n_out,ldz', [(1000, 512, 1024, 1024), (777, 128, 3, 32), (4096, 1536, 256, 288), (300, 256, 1, 32)])
+def test_grad_weight_and_bias_against_numpy(M, m, n_in, n_out, ldz):
+    """dK = H^T dZ (split-K MFMA with transposed LDS reads) and db = column sums, bf16 operands, float32 result."""
+    rs = np.random.RandomState(m)
+    h = round_bf16(rs.randn(m, n_in).astype(np.float32))
+    dz_full = np.zeros((m, ldz), np.float32)
+    dz_full[:, :n_out] = round_bf16(rs.randn(m, n_out).astype(np.float32))
+    th, tz = T(h).to(torch.bfloat16), T(dz_full).to(torch.bfloat16)
+    out = torch.empty(n_in, n_out, device=dev())
+    scratch = [None, None]
+    M._grad_weight(th, tz, n_in, n_out, out, scratch)
+    ref = h.astype(np.float64).T @ dz_full[:, :n_out].astype(np.float64)
+    np.testing.assert_allclose(N(out), ref, rtol=2e-4, atol=2e-4 * np.sqrt(m))
+    b = torch.empty(n_out, device=dev())
+    M._grad_bias(tz, n_out, b, scratch)
+    np.testing.assert_allclose(N(b), dz_full[:, :n_out].astype(np.float64).sum(0), rtol=2e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('which', ['prop', 'nerf'])
+def test_mlp_backward_matches_oracle(M, which):
+    """Parameter gradients of one MLP (dX chain with ReLU masks, stacked head GEMM, weight / bias gradient GEMMs) against
+    the oracle's closed-form backward in float64 on the same frustums: bf16-grade agreement per tensor."""
+    rs = np.random.RandomState(11)
+    n, S = 16, 32
+    cfg = O.PROP_CFG if which == 'prop' else O.NERF_CFG
+    params = O.init_mlp_params(cfg, rs)
+    params = [(w, (rs.randn(*b.shape) * 0.05).astype(np.float32)) for w, b in params]
+    rays = _rays(rs, n)
+    s = np.sort(rs.rand(n, S + 1), -1).astype(np.float32)
+    _, s_to_t = O.construct_ray_warps('reciprocal', rays['near'], np.full((n, 1), 30., np.float32))
+    tdist = s_to_t(s).astype(np.float32)
+    basis = O.pos_basis_t()
+    tm = M.TrainableMLP(params, M.PROP_CFG if which == 'prop' else M.NERF_CFG, dev())
+    W = cfg['net_width']
+    rows = n * S
+    buf = torch.empty(rows, W + 512, dtype=torch.bfloat16, device=dev())
+    M.cast_encode(T(tdist), T(rays['origins']), T(rays['directions']), T(rays['radii']), T(basis), out=buf[:, W:], ld=W + 512)
+    density, rgb, saved = M.mlp_forward_train(tm, buf, rows, T(rays['viewdirs']), n, S)
+    g_d = rs.randn(n, S).astype(np.float32)
+    g_c = rs.randn(n, S, 3).astype(np.float32) if which == 'nerf' else None
+    M.mlp_backward(tm, saved, rows, T(g_d).reshape(-1), None if g_c is None else T(g_c).reshape(-1, 3), [None, None])
+    means, covs = O.cast_rays(tdist.astype(np.float64), rays['origins'].astype(np.float64), rays['directions'].astype(np.float64),
+                              rays['radii'].astype(np.float64), 'cone', diag=False)
+    cache = {}
+    p64 = [(w.astype(np.float64), b.astype(np.float64)) for w, b in params]
+    out = O.mlp_forward(p64, cfg, means, covs, rays['viewdirs'].astype(np.float64), basis.astype(np.float64), cache=cache)
+    np.testing.assert_allclose(N(density).reshape(n, S), out['density'], rtol=5e-2, atol=5e-3)
+    ref = O.mlp_backward(p64, cache, g_d.astype(np.float64), None if g_c is None else g_c.astype(np.float64))
+    for t, (gk, gb) in enumerate(ref):
+        mine_k, mine_b = N(tm.kernel(t, tm.grads)), N(tm.bias(t, tm.grads))
+        rel_k = np.linalg.norm(mine_k - gk) / (np.linalg.norm(gk) + 1e-30)
+        rel_b = np.linalg.norm(mine_b - gb) / (np.linalg.norm(gb) + 1e-30)
+        assert rel_k < 6e-2, ('kernel', t, rel_k)
+        assert rel_b < 6e-2 or np.abs(mine_b - gb).max() < 1e-2 * np.abs(gb).max() + 1e-3, ('bias', t, rel_b)
+
+
+def test_trainer_steps_reduce_the_loss_and_are_deterministic(M):
+    """train_utils.create_train_step end to end on a toy target: 25 steps with fixed rays and jitter bring the total
+    loss down, every scalar stays finite, the clipping multiplier equals min(1, max_norm / ||g||), and two trainers fed
+    the same inputs end with bit-identical parameters (fixed-order reductions everywhere)."""
+    rs = np.random.RandomState(2)
+    n = 64
+    rays = {k: T(v) for k, v in _rays(rs, n).items()}
+    gt = T(np.tile(np.array([[0.2, 0.5, 0.7]], np.float32), (n, 1)))
+    sup = T(np.where(rs.rand(n) < .5, rs.uniform(1, 4, n), 0).astype(np.float32))
+    jit = [T(rs.rand(n).astype(np.float32)) for _ in range(3)]
+    init = (O.init_mlp_params(O.PROP_CFG, np.random.RandomState(0)), O.init_mlp_params(O.NERF_CFG, np.random.RandomState(1)))
+    finals = []
+    for rep in range(2):
+        tr = M.Mip360Trainer(init[0], init[1], dev(), max_steps=2000, grad_max_norm=0.0)
+        hist = []
+        for _ in range(25):
+            sc = tr.train_step(rays, gt, sup, jitter01=jit)
+            hist.append(N(sc))
+        hist = np.array(hist)
+        assert np.isfinite(hist).all()
+        assert hist[-5:, 1].mean() < 0.6 * hist[:3, 1].mean(), hist[:, 1]          # the data term goes down
+        finals.append((N(tr.nerf.flat), N(tr.prop.flat)))
+    np.testing.assert_array_equal(finals[0][0], finals[1][0])
+    np.testing.assert_array_equal(finals[0][1], finals[1][1])
+    tr = M.Mip360Trainer(init[0], init[1], dev(), max_steps=2000, grad_max_norm=0.001)
+    before = N(tr.nerf.flat).copy()
+    tr.train_step(rays, gt, sup, jitter01=jit)
+    clip = N(tr.clip)
+    norm = np.linalg.norm(N(tr.nerf.grads).astype(np.float64))
+    np.testing.assert_allclose(clip[0, 1], norm, rtol=1e-4)
+    np.testing.assert_allclose(clip[0, 0], min(1.0, 0.001 / (np.finfo(np.float32).eps + norm)), rtol=1e-4)
+    # first Adam step with clipped gradients: |delta| = lr * |g| / (|g| + eps_hat) <= lr
+    delta = np.abs(N(tr.nerf.flat) - before)
+    assert delta.max() <= M.learning_rate(1, max_steps=2000) * 1.001 and delta.max() > 0

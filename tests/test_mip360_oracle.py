@@ -526,3 +526,40 @@ def test_depth_terms_as_written_upstream():
     np.testing.assert_allclose(st['depth_losses'][0], (0.5 + 1.0) / 4)
     kl = M.depth_loss(hist[0]['weights'], hist[0]['tdist'], sup, dm, 0.01, np.ones((4, 3)), 'kl')
     assert np.isfinite(kl) and kl > 0
+
+
+@pytest.mark.parametrize('which', ['prop', 'nerf'])
+def test_mlp_backward_matches_finite_differences(which):
+    """The closed-form MLP backward (upstream: jax.grad) against float64 central differences, on a narrow copy of the
+    360.gin networks (same depth, skip, heads; width 24) so every parameter can be probed."""
+    rs = np.random.RandomState(0)
+    cfg = dict(M.PROP_CFG if which == 'prop' else M.NERF_CFG, net_width=24, bottleneck_width=8, net_width_viewdirs=6)
+    params = [(rs.randn(*w.shape) * 0.3, rs.randn(*b.shape) * 0.1) for w, b in
+              [(np.zeros(sh), np.zeros(sh[1])) for sh in M.mlp_param_shapes(cfg)]]
+    n, S = 3, 5
+    means = rs.randn(n, S, 3) * 1.5
+    half = rs.randn(n, S, 3, 3) * 0.05
+    covs = half @ np.swapaxes(half, -1, -2)
+    vd = rs.randn(n, 3)
+    vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    basis = M.pos_basis_t().astype(np.float64)
+    g_d, g_c = rs.randn(n, S), rs.randn(n, S, 3)
+
+    def scalar(ps):
+        out = M.mlp_forward(ps, cfg, means, covs, vd, basis)
+        return (out['density'] * g_d).sum() + (out['rgb'] * g_c).sum()
+
+    cache = {}
+    M.mlp_forward(params, cfg, means, covs, vd, basis, cache=cache)
+    grads = M.mlp_backward(params, cache, g_d, None if cfg['disable_rgb'] else g_c)
+    for li, (W, b) in enumerate(params):
+        for which_p, arr, g in ((0, W, grads[li][0]), (1, b, grads[li][1])):
+            idxs = [tuple(rs.randint(0, d) for d in arr.shape) for _ in range(6)]
+            for idx in idxs:
+                h = 1e-6
+                pp = [(w.copy(), bb.copy()) for w, bb in params]
+                pm = [(w.copy(), bb.copy()) for w, bb in params]
+                pp[li][which_p][idx] += h
+                pm[li][which_p][idx] -= h
+                num = (scalar(pp) - scalar(pm)) / (2 * h)
+                np.testing.assert_allclose(g[idx], num, rtol=2e-4, atol=1e-7, err_msg='layer %d %s %r' % (li, 'Wb'[which_p], idx))
