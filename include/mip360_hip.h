@@ -52,7 +52,8 @@ int mip360_resample(void* stream, int n_rays, int m_in, const float* sdist_in, c
  *   lift_and_diagonalize(., ., basis)                         coord.py:131-135
  *   integrated_pos_enc(., ., 0, 12)                           coord.py:103-128
  * tdist [n, S+1]; origins, directions [n,3]; radii [n]; basis_t [3, 21] row-major.
- * enc [n*S, ld]: float32 (out_bf16 = 0) or bfloat16 (out_bf16 = 1), columns 504..ld-1 zero-filled. */
+ * enc [n*S, ld]: float32 (out_bf16 = 0) or bfloat16 (out_bf16 = 1); columns 504..min(ld, 512)-1 are zero-filled (K
+ * padding of the first dense layer); ld may be larger when enc is a column window of a wider row (the skip buffer). */
 int mip360_cast_encode(void* stream, int n_rays, int n_samples, const float* tdist,
                        const float* origins, const float* directions, const float* radii,
                        const float* basis_t, void* enc, int out_bf16, int ld);

@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256) void cast_encode_kernel(
       e[HALF + k * MIP360_N_BASIS + j] = ec;
     }
   }
-  for (int col = 2 * HALF + j; col < ld; col += MIP360_N_BASIS) {        // zero padding 504..ld-1
+  const int pad_to = ld < MIP360_IPE_LD ? ld : MIP360_IPE_LD;               // zero padding 504..511 (K of the next layer)
+  for (int col = 2 * HALF + j; col < pad_to; col += MIP360_N_BASIS) {
     if (BF16) ((__bf16*)enc)[(size_t)row * ld + col] = (__bf16)0.f;
     else ((float*)enc)[(size_t)row * ld + col] = 0.f;
   }
