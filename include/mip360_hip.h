@@ -115,9 +115,11 @@ int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda
 
 /* d kernel [n_in, n_out] (flax layout, float32, row stride ldg) = scale * H[m, n_in]^T dZ[m, n_out]: bf16 operands,
  * MFMA with ds_read_b64_tr_b16 transposed fragments, split over `ksplit` row slices into `slabs`
- * (>= ksplit * n_in * ldg floats) that are summed in a fixed order. */
+ * (>= ksplit * (n_in * ldg + n_out) floats) that are summed in a fixed order.  grad_bias [n_out] (may be NULL) =
+ * scale * column sums of dZ, accumulated from the fragments the first input tile already holds. */
 int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz,
-                            int lddz, int ksplit, float* slabs, float* grad_kernel, int ldg, float scale);
+                            int lddz, int ksplit, float* slabs, float* grad_kernel, int ldg, float scale,
+                            float* grad_bias);
 
 /* d bias [n_out] = scale * column sums of dZ [m, n_out] (bf16); partial >= nslice * n_out floats. */
 int mip360_grad_bias_bf16(void* stream, int m, int n_out, const void* dz, int lddz, int nslice, float* partial,

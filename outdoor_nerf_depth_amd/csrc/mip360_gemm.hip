@@ -6,59 +6,86 @@
 // float32 accumulators = 512 VGPRs per lane), so its layers run as tiled GEMMs whose [rows, 1024] bf16 activations
 // round-trip through L2 / Infinity Cache (268 MB per layer at 4096 rays x 32 samples).
 //
-// Tiling: 256 threads = 2 x 2 waves, workgroup tile 128 x 128, K step 32, double-buffered LDS; a wave owns a
-// 64 x 64 sub-tile = 2 x 2 MFMA blocks.  Both operands are K-contiguous, so an MFMA fragment is one 16-byte LDS
-// read per lane (row l & 31, k offset 8 * (l >> 5)); LDS rows are padded to 80 bytes.  The next K tile is fetched
-// into registers while the current one is multiplied (one __syncthreads per K step).
+// Tiling: K step 32, double-buffered LDS.  Wide layers: 512 threads = 2 x 4 waves on a 256 x 256 tile, a wave owns
+// 128 x 64 = 4 x 2 MFMA blocks; narrow layers (N <= 128): 256 threads on 128 x 128.  Both operands are K-contiguous,
+// so an MFMA fragment is one 16-byte LDS read per lane (row l & 31, k offset 8 * (l >> 5)); LDS rows are padded to
+// 80 bytes.  The next K tile is fetched into registers while the current one is multiplied (one __syncthreads per K
+// step).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace mip360 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_ROW = 40;      // elements; 40 * 2 B = 80 B row stride
+constexpr int BK = 32, LDS_ROW = 40;      // elements; 40 * 2 B = 80 B row stride
 
-template <int ACT>
-__global__ __launch_bounds__(256) void linear_bf16_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda,
-                                                          const __bf16* __restrict__ W, int ldw,
-                                                          const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc,
-                                                          float* __restrict__ C32, int ldc32, float act_param,
-                                                          const __bf16* __restrict__ aux, int ldaux) {
+// Tile configuration: NWM x NWN waves, each owning FM x FN MFMA blocks of 32 x 32.
+//   small (2, 2, 2, 2): 256 threads, 128 x 128 tile -- narrow layers (N <= 128: heads, view branch)
+//   big   (2, 4, 4, 2): 512 threads, 256 x 256 tile, 128 x 64 per wave: 6 LDS fragment reads feed 8 MFMAs per k16 step
+template <int ACT, int NWM, int NWN, int FM, int FN>
+__global__ __launch_bounds__(NWM * NWN * 64) void linear_bf16_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda,
+                                                                     const __bf16* __restrict__ W, int ldw,
+                                                                     const float* __restrict__ bias, __bf16* __restrict__ C16,
+                                                                     int ldc, float* __restrict__ C32, int ldc32, float act_param,
+                                                                     const __bf16* __restrict__ aux, int ldaux) {
+  constexpr int NT = NWM * NWN * 64, BM = NWM * FM * 32, BN = NWN * FN * 32;
+  constexpr int QA = BM * 4 / NT, QB = BN * 4 / NT;               // 16-byte chunks per thread per operand tile
+  static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile / thread mismatch");
   __shared__ __attribute__((aligned(16))) __bf16 sA[2][BM * LDS_ROW];
   __shared__ __attribute__((aligned(16))) __bf16 sB[2][BN * LDS_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: consecutive workgroups (which land on different XCDs) take different N tiles of the
-  // same M tile, so an A tile is read by all XCDs at about the same time and W (small) stays in every L2
-  const int tiles_n = (N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int wm = wave / NWN, wn = wave - wm * NWN;
+  // XCD-aware tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so the tiles_n workgroups that
+  // read the SAME A tile are given ids b, b + 8, b + 16, ... : they execute back to back on one XCD and share the A
+  // tile (BM x K) through that XCD's L2 instead of fetching it eight times from HBM; W (<= 3 MB) lives in every L2.
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  int tile_m, tile_n;
+  {
+    const int b = blockIdx.x, xcd = b & 7, id = b >> 3;
+    const int full = (tiles_m / 8) * 8;                       // M tiles that can be dealt 8 at a time
+    const int group = id / tiles_n;                           // which group of 8 M tiles
+    if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
+    else {                                                    // remainder (tiles_m % 8 M tiles): plain order
+      const int r = b - full * tiles_n;
+      tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n;
+    }
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  // global -> LDS: 512 16-byte chunks per operand tile, 2 per thread: chunk c -> row c >> 2, k offset (c & 3) * 8
-  uint4 ra[2], rb[2];
+  uint4 ra[QA], rb[QB];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c = tid + q * 256, row = c >> 2, kc = (c & 3) * 8;
-      const int m = m0 + row, n = n0 + row;
+    for (int q = 0; q < QA; ++q) {
+      const int c = tid + q * NT, row = c >> 2, kc = (c & 3) * 8;
+      const int m = m0 + row;
       ra[q] = m < M ? *(const uint4*)(A + (size_t)m * lda + k0 + kc) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int c = tid + q * NT, row = c >> 2, kc = (c & 3) * 8;
+      const int n = n0 + row;
       rb[q] = n < N ? *(const uint4*)(W + (size_t)n * ldw + k0 + kc) : make_uint4(0, 0, 0, 0);
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c = tid + q * 256, row = c >> 2, kc = (c & 3) * 8;
+    for (int q = 0; q < QA; ++q) {
+      const int c = tid + q * NT, row = c >> 2, kc = (c & 3) * 8;
       *(uint4*)(&sA[buf][row * LDS_ROW + kc]) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int c = tid + q * NT, row = c >> 2, kc = (c & 3) * 8;
       *(uint4*)(&sB[buf][row * LDS_ROW + kc]) = rb[q];
     }
   };
-  f32x16 acc[2][2];
+  f32x16 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int nk = K / BK;
@@ -71,15 +98,15 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(int M, int N, int K, c
     if (kt + 1 < nk) fetch((kt + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[FM], fb[FN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(&sA[buf][(wm * 64 + i * 32 + frow) * LDS_ROW + ks * 16 + fk]);
+      for (int i = 0; i < FM; ++i) fa[i] = *(const bf16x8*)(&sA[buf][(wm * FM * 32 + i * 32 + frow) * LDS_ROW + ks * 16 + fk]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *(const bf16x8*)(&sB[buf][(wn * 64 + j * 32 + frow) * LDS_ROW + ks * 16 + fk]);
+      for (int j = 0; j < FN; ++j) fb[j] = *(const bf16x8*)(&sB[buf][(wn * FN * 32 + j * 32 + frow) * LDS_ROW + ks * 16 + fk]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) stash(buf ^ 1);
     __syncthreads();
@@ -87,15 +114,15 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(int M, int N, int K, c
   // epilogue: lane (j = lane & 31, hi = lane >> 5), register r -> row (r & 3) + 8 (r >> 2) + 4 hi, column j
   const int hi = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + frow;
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * FN * 32 + j * 32 + frow;
     if (n >= N) continue;
     const float b = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int m = m0 + wm * FM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (m >= M) continue;
         float v = acc[i][j][r] + b;
         if (ACT == 1) v = fmaxf(v, 0.f);
@@ -109,18 +136,159 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(int M, int N, int K, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wide layers (N >= 192): 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), K step 32, operands streamed
+// global -> LDS with global_load_lds_dwordx4 into a 4-deep ring (no VGPR staging, three K steps in flight, counted
+// vmcnt + one raw s_barrier per step).  A DMA instruction fills 1 KiB of LDS linearly (lane l -> byte 16 l) but every
+// lane supplies its own global address, so the 16-byte chunks of a 64-byte tile row are stored XOR-swizzled
+// (position p of row r holds chunk p ^ ((r >> 2) & 3)): the 16 lanes one ds_read_b128 services together then hit 16
+// different 16-byte slots of the 256-byte bank line (conflict-free) without padding.
+// Rows beyond M / N are clamped to the last valid row on the load side (their results are never stored).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RT = 256, RBK = 32, RNBUF = 4;
+constexpr int RSTAGE = 2 * RT * RBK * 2;            // bytes per stage: A tile + B tile = 32 KiB
+extern __shared__ __attribute__((aligned(16))) char ring_smem[];
+
+__device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512) void linear_bf16_ring_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda,
+                                                               const __bf16* __restrict__ W, int ldw,
+                                                               const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc,
+                                                               float* __restrict__ C32, int ldc32, float act_param,
+                                                               const __bf16* __restrict__ aux, int ldaux) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = (N + RT - 1) / RT, tiles_m = (M + RT - 1) / RT;
+  int tile_m, tile_n;
+  {                                                           // XCD-aware order, see linear_bf16_kernel
+    const int b = blockIdx.x, xcd = b & 7, id = b >> 3;
+    const int full = (tiles_m / 8) * 8;
+    const int group = id / tiles_n;
+    if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
+    else { const int r = b - full * tiles_n; tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n; }
+  }
+  const int m0 = tile_m * RT, n0 = tile_n * RT;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_smem;
+  // DMA lane map: instruction q of this wave covers tile rows [16 * (wave * 2 + (q & 1)) ... + 16) of operand q >> 1
+  const int drow = lane >> 2, dpos = lane & 3;
+  const char* gsrc[4];
+  uint32_t ldst[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int op = q >> 1, row = 16 * (wave * 2 + (q & 1)) + drow;
+    const int chunk = dpos ^ ((row >> 2) & 3);
+    if (op == 0) {
+      int m = m0 + row; m = m < M ? m : M - 1;
+      gsrc[q] = (const char*)(A + (size_t)m * lda + chunk * 8);
+    } else {
+      int n = n0 + row; n = n < N ? n : N - 1;
+      gsrc[q] = (const char*)(W + (size_t)n * ldw + chunk * 8);
+    }
+    ldst[q] = (uint32_t)(op * RT * RBK * 2 + 16 * (wave * 2 + (q & 1)) * 64);      // + slot * RSTAGE, + lane * 16 by the hardware
+  }
+  const int nk = K / RBK;
+  auto issue = [&](int kt) {
+    if (kt >= nk) return;
+    const uint32_t slot = (uint32_t)(kt % RNBUF) * RSTAGE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16_asm(gsrc[q] + (size_t)kt * RBK * 2, lds0 + slot + ldst[q]);
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int s_ = 0; s_ < RNBUF - 1; ++s_) issue(s_);
+  // fragment read: row R = block row + (lane & 31), k chunk c = 2 ks + (lane >> 5) -> position c ^ ((R >> 2) & 3)
+  const int frow = lane & 31, fkh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int younger = nk - 1 - kt < RNBUF - 2 ? nk - 1 - kt : RNBUF - 2;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(kt + RNBUF - 1);
+    const char* st = ring_smem + (kt % RNBUF) * RSTAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int R = wm * 128 + i * 32 + frow;
+        fa[i] = *(const bf16x8*)(st + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int R = wn * 64 + j * 32 + frow;
+        fb[j] = *(const bf16x8*)(st + RT * RBK * 2 + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + frow;
+    if (n >= N) continue;
+    const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m >= M) continue;
+        float v = acc[i][j][r] + b;
+        if (ACT == 1) v = fmaxf(v, 0.f);
+        if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+        if (ACT == 4) v = (float)aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;
+        if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
+        if (C16) C16[(size_t)m * ldc + n] = (__bf16)v;
+        if (C32) C32[(size_t)m * ldc32 + n] = v;
+      }
+    }
+  }
+}
+
 }  // namespace mip360
+
+template <int ACT>
+static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
+                            float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux) {
+  using namespace mip360;
+  static const bool force_small = getenv("MIP360_GEMM_SMALL") != nullptr;
+  static const bool no_ring = getenv("MIP360_GEMM_NORING") != nullptr;
+  if (N >= 192 && M >= 256 && !force_small && !no_ring) {
+    const int tiles = ((M + RT - 1) / RT) * ((N + RT - 1) / RT);
+    hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT>), dim3(tiles), dim3(512), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A, lda,
+                       (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+  } else if (N >= 192 && M >= 256 && !force_small) {
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    hipLaunchKernelGGL((linear_bf16_kernel<ACT, 2, 4, 4, 2>), dim3(tiles), dim3(512), 0, st, M, N, K, (const __bf16*)A, lda,
+                       (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+  } else {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    hipLaunchKernelGGL((linear_bf16_kernel<ACT, 2, 2, 2, 2>), dim3(tiles), dim3(256), 0, st, M, N, K, (const __bf16*)A, lda,
+                       (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+  }
+}
 
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                           int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux) {
-  using namespace mip360;
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-#define MIP360_LAUNCH(ACT) hipLaunchKernelGGL(linear_bf16_kernel<ACT>, dim3(tiles), dim3(256), 0, st, M, N, K, (const __bf16*)A, \
-                                              lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux)
-  if (act == 1) MIP360_LAUNCH(1);
-  else if (act == 2) MIP360_LAUNCH(2);
-  else if (act == 3) MIP360_LAUNCH(3);
-  else if (act == 4) MIP360_LAUNCH(4);
-  else MIP360_LAUNCH(0);
-#undef MIP360_LAUNCH
+  if (act == 1) launch_linear_t<1>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
+  else if (act == 2) launch_linear_t<2>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
+  else if (act == 3) launch_linear_t<3>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
+  else if (act == 4) launch_linear_t<4>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
+  else launch_linear_t<0>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
 }

@@ -34,13 +34,21 @@ __device__ __forceinline__ bf16x8 tr_frag(uint32_t off) {
 
 __global__ __launch_bounds__(256) void grad_weight_kernel(int M, int I, int O, const __bf16* __restrict__ H, int ldh,
                                                           const __bf16* __restrict__ dZ, int lddz, int ksplit,
-                                                          float* __restrict__ slabs, int ldc) {
+                                                          float* __restrict__ slabs, int ldc, float* __restrict__ bias_slabs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wo = wave & 1;
   const int tiles_o = (O + GT - 1) / GT, tiles_i = (I + GT - 1) / GT;
-  int b = blockIdx.x;
-  const int slice = b / (tiles_i * tiles_o);
-  b -= slice * tiles_i * tiles_o;
+  // XCD-aware order (workgroup b runs on XCD b % 8, one L2 per XCD): all tiles of a row slice go to ONE XCD, so the
+  // slice's H / dZ row tiles are fetched from HBM once and re-used by its tiles_i * tiles_o workgroups through that L2
+  int slice, b;
+  if ((ksplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, id = blockIdx.x >> 3, per_xcd = ksplit >> 3;
+    slice = xcd * per_xcd + id / (tiles_i * tiles_o);
+    b = id % (tiles_i * tiles_o);
+  } else {
+    slice = blockIdx.x / (tiles_i * tiles_o);
+    b = blockIdx.x - slice * tiles_i * tiles_o;
+  }
   const int ti = b / tiles_o, to = b - ti * tiles_o;
   const int i0 = ti * GT, o0 = to * GT;
   // rows of this slice, in multiples of GK
@@ -76,6 +84,10 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(int M, int I, int O, c
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  // bias gradient = column sums of dZ: the dZ fragments of the first input tile's first wave row already hold every
+  // column of this output tile (lane = column, 8 rows per fragment), so they are summed on the side (VALU)
+  const bool do_bias = bias_slabs != nullptr && ti == 0 && wi == 0;
+  float bsum[2] = {0.f, 0.f};
   // transposed-read lane map (see nerfpp_dw.hip): 16-lane group g = lane >> 4: k half g >> 1, column sub-block g & 1;
   // lane a16 = lane & 15: row pair a16 >> 2, 4-column piece a16 & 3
   const int g = lane >> 4, a16 = lane & 15;
@@ -100,6 +112,12 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(int M, int I, int O, c
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[x], fz[y], acc[x][y], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[y] += (float)fz[y][e];
+      }
     }
     if (st + 1 < s_end) stash(buf ^ 1);
     __syncthreads();
@@ -117,6 +135,14 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(int M, int I, int O, c
         const int i = i0 + wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (i < I) slab[(size_t)i * ldc + o] = acc[x][y][r];
       }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const float tot = bsum[y] + __shfl_xor(bsum[y], 32, 64);       // the two k halves of a column
+      const int o = o0 + wo * 64 + y * 32 + j;
+      if (hi == 0 && o < O) bias_slabs[(size_t)slice * O + o] = tot;
+    }
   }
 }
 
@@ -218,13 +244,17 @@ __global__ void pack_weight_kernel(int n_in, int n_out, const float* __restrict_
 using namespace mip360;
 
 void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
-                               float* slabs, float* out, int ldc, float scale) {
+                               float* slabs, float* out, int ldc, float scale, float* bias_out) {
   const int tiles = ((I + GT - 1) / GT) * ((O + GT - 1) / GT);
   const size_t lds = 4 * GK * GROWB;
-  hipLaunchKernelGGL(grad_weight_kernel, dim3(tiles * ksplit), dim3(256), lds, st, M, I, O, (const __bf16*)H, ldh,
-                     (const __bf16*)dZ, lddz, ksplit, slabs, ldc);
   const int64_t n = (int64_t)I * ldc;
+  float* bias_slabs = bias_out ? slabs + (size_t)ksplit * n : nullptr;            // [ksplit][O] after the kernel slabs
+  hipLaunchKernelGGL(grad_weight_kernel, dim3(tiles * ksplit), dim3(256), lds, st, M, I, O, (const __bf16*)H, ldh,
+                     (const __bf16*)dZ, lddz, ksplit, slabs, ldc, bias_slabs);
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ksplit, slabs, scale, out);
+  if (bias_out)
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((O + 255) / 256)), dim3(256), 0, st, (int64_t)O, ksplit, bias_slabs, scale,
+                       bias_out);
 }
 void mip360_launch_col_sum(hipStream_t st, int M, int O, const void* dZ, int ld, int nslice, float* partial, float* out,
                            float scale) {

@@ -38,7 +38,7 @@ SYMBOLS = {
     'mip360_linear_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, _fp,
                                      C.c_int, _fp, C.c_int, _fp, C.c_int]),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
-                                          C.c_float]),
+                                          C.c_float, _fp]),
     'mip360_grad_bias_bf16': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_float]),
     'mip360_head_backward': (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'mip360_sum_squares': (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int]),
@@ -402,16 +402,19 @@ class TrainableMLP(object):
         return [(self.kernel(t).clone(), self.bias(t).clone()) for t in range(len(self.shapes))]
 
 
-def _grad_weight(h, dz, n_in, n_out, out, scratch):
+def _grad_weight(h, dz, n_in, n_out, out, scratch, bias_out=None):
+    """d kernel = H^T dZ into `out` [n_in, n_out]; bias_out [n_out] = column sums of dZ from the same pass."""
     m = h.shape[0]
     tiles = ((n_in + 127) // 128) * ((n_out + 127) // 128)
-    ksplit = int(max(1, min(64, (512 + tiles - 1) // tiles, (m + 31) // 32)))
-    need = ksplit * n_in * n_out
+    ksplit = int(max(1, min(64, (256 + tiles - 1) // tiles, (m + 31) // 32)))
+    if ksplit >= 8 or m >= 8 * 256:
+        ksplit = max(8, (ksplit // 8) * 8)            # multiples of 8: one or more whole row slices per XCD
+    need = ksplit * (n_in * n_out + n_out)
     if scratch[0] is None or scratch[0].numel() < need:
         scratch[0] = torch.empty(need, device=h.device)
     ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
     _check(lib().mip360_grad_weight_bf16(_stream(), m, n_in, n_out, _p(h), ld(h), _p(dz), ld(dz), ksplit, _p(scratch[0]), _p(out),
-                                         n_out, 1.0), 'mip360_grad_weight_bf16')
+                                         n_out, 1.0, _p(bias_out)), 'mip360_grad_weight_bf16')
 
 
 def _grad_bias(dz, n_out, out, scratch):
@@ -474,32 +477,27 @@ def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch):
                                       _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
     if nerf:
         h, view_in = saved['h'], saved['view_in']
-        _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch)
-        _grad_bias(d_pre, 3, tm.bias(D + 3, G), scratch)
+        _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G))
         d_hz = bf(VIEW_WIDTH)
         linear(d_pre, tm.wb[D + 3], None, act=4, out_bf16=d_hz, m=rows, n=VIEW_WIDTH, k=32, aux=h)
         gk = torch.empty(BOTTLENECK + DIR_LD, VIEW_WIDTH, device=dev)
-        _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, gk, scratch)
+        _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, gk, scratch, tm.bias(D + 2, G))
         tm.kernel(D + 2, G).copy_(gk[:BOTTLENECK + DIR_DIM])
-        _grad_bias(d_hz, VIEW_WIDTH, tm.bias(D + 2, G), scratch)
         linear(d_hz, tm.wb[D + 2], None, act=0, out_bf16=heads, m=rows, n=BOTTLENECK, k=VIEW_WIDTH)     # -> heads[:, :256]
-        _grad_weight(trunk, heads, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch)
-        _grad_bias(heads, BOTTLENECK, tm.bias(D + 1, G), scratch)
+        _grad_weight(trunk, heads, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch, tm.bias(D + 1, G))
     d_raw = heads[:, raw_col:]
-    _grad_weight(trunk, d_raw, trunk_k, 1, tm.kernel(D, G), scratch)
-    _grad_bias(d_raw, 1, tm.bias(D, G), scratch)
+    _grad_weight(trunk, d_raw, trunk_k, 1, tm.kernel(D, G), scratch, tm.bias(D, G))
     # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
     dz = bf(W)
     linear(heads, tm.wb['heads'], None, act=4, out_bf16=dz, m=rows, n=W, k=tm.head_k, aux=saved['H'][D - 1])
     for i in reversed(range(D)):
         x, x_k = saved['inputs'][i]
         if x_k == tm.shapes[i][0]:
-            _grad_weight(x, dz, x_k, W, tm.kernel(i, G), scratch)
+            _grad_weight(x, dz, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G))
         else:                                                        # padded input (504 -> 512 encoding columns)
             gk = torch.empty(x_k, W, device=dev)
-            _grad_weight(x, dz, x_k, W, gk, scratch)
+            _grad_weight(x, dz, x_k, W, gk, scratch, tm.bias(i, G))
             tm.kernel(i, G).copy_(gk[:tm.shapes[i][0]])
-        _grad_bias(dz, W, tm.bias(i, G), scratch)
         if i > 0:
             nxt = bf(W)
             linear(dz, tm.wb[i], None, act=4, out_bf16=nxt, m=rows, n=W, k=W, aux=saved['H'][i - 1])
