@@ -238,24 +238,88 @@ __global__ __launch_bounds__(512) void linear_bf16_ring_kernel(int M, int N, int
     }
   }
   const int hi = lane >> 5;
+  if (C32 != nullptr) {                                       // float32 outputs (rare for wide layers): direct stores
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + frow;
-    if (n >= N) continue;
-    const float b = bias ? bias[n] : 0.f;
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + frow;
+      if (n >= N) continue;
+      const float b = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m >= M) continue;
-        float v = acc[i][j][r] + b;
-        if (ACT == 1) v = fmaxf(v, 0.f);
-        if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
-        if (ACT == 4) v = (float)aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;
-        if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
-        if (C16) C16[(size_t)m * ldc + n] = (__bf16)v;
-        if (C32) C32[(size_t)m * ldc32 + n] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (m >= M) continue;
+          float v = acc[i][j][r] + b;
+          if (ACT == 1) v = fmaxf(v, 0.f);
+          if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+          if (ACT == 4) v = (float)aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;
+          if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
+          C32[(size_t)m * ldc32 + n] = v;
+          if (C16) C16[(size_t)m * ldc + n] = (__bf16)v;
+        }
+      }
+    }
+    return;
+  }
+  // bf16 output: the accumulator layout gives a lane ONE column and 16 scattered rows, i.e. 2-byte stores in 64-byte row
+  // segments.  The ring is idle now, so the tile is transposed through it ([256][256] bf16 = its 128 KiB, rows rotated by
+  // 16 bytes per row against bank conflicts) and leaves as 16 bytes per lane = whole 512-byte rows per 32 lanes; the ReLU
+  // mask (ACT 4) is applied on the way out from equally coalesced 16-byte loads of the saved activation.
+  __builtin_amdgcn_s_barrier();
+  {
+    __bf16* tile = (__bf16*)ring_smem;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nl = wn * 64 + j * 32 + frow;
+      const int n = n0 + nl;
+      const float b = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          float v = acc[i][j][r] + b;
+          if (ACT == 1) v = fmaxf(v, 0.f);
+          if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+          if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
+          tile[ml * 256 + ((nl + 8 * ml) & 255)] = (__bf16)v;
+        }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    const __bf16* tile = (const __bf16*)ring_smem;
+    const bool vec_ok = ((ldc & 7) == 0) && (ACT != 4 || (ldaux & 7) == 0);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int c = it * 512 + tid, ml = c >> 5, piece = c & 31;          // 32 pieces of 8 columns per row
+      const int m = m0 + ml, n = n0 + piece * 8;
+      if (m >= M || n >= N) continue;
+      uint4 v = *(const uint4*)(tile + ml * 256 + ((piece * 8 + 8 * ml) & 255));
+      if (vec_ok && n + 8 <= N) {
+        if (ACT == 4) {
+          const uint4 a4 = *(const uint4*)(aux + (size_t)m * ldaux + n);
+          const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
+          uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            // keep a bf16 where the saved activation is > 0: positive sign and non-zero magnitude
+            const uint32_t lo = ((aw[k] & 0x8000u) == 0 && (aw[k] & 0x7FFFu) != 0) ? 0x0000FFFFu : 0u;
+            const uint32_t hi16 = ((aw[k] & 0x80000000u) == 0 && (aw[k] & 0x7FFF0000u) != 0) ? 0xFFFF0000u : 0u;
+            vw[k] &= (lo | hi16);
+          }
+          v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+        }
+        *(uint4*)(C16 + (size_t)m * ldc + n) = v;
+      } else {
+        const __bf16* pv = (const __bf16*)&v;
+        for (int k = 0; k < 8 && n + k < N; ++k) {
+          float x = (float)pv[k];
+          if (ACT == 4) x = (float)aux[(size_t)m * ldaux + n + k] > 0.f ? x : 0.f;
+          C16[(size_t)m * ldc + n + k] = (__bf16)x;
+        }
       }
     }
   }
