@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERFPP_ABI_VERSION 2
+#define NERFPP_ABI_VERSION 3
 
 #define NERFPP_OK 0
 #define NERFPP_ERR_ARG 1          /* bad argument (null pointer, size out of range) */
@@ -214,10 +214,18 @@ typedef struct {
   void* ev_dw_end;
   const float* params;             /* [NERFPP_LEVEL_PARAMS] the level's float32 parameters (the remap /
                                       colour-head weight gradients are derived through them) */
+  int32_t defer_reduce;            /* != 0: stop after the weight-gradient GEMMs (their split-K slabs stay in
+                                      `workspace`); the caller finishes with nerfpp_level_reduce_grads, e.g. on
+                                      another stream so that it runs under the next level's forward */
 } nerfpp_backward_args;
 
 /* loss.backward() for one level (autograd in the reference)         ddp_train_nerf.py:497 */
 int nerfpp_level_backward(void* stream, const nerfpp_backward_args* args);
+
+/* Second half of nerfpp_level_backward when it was called with defer_reduce: sums the split-K slabs in a fixed order
+ * into `grads` (x grad_scale) and derives the remap / colour-head gradients.  Same args struct; the caller orders it
+ * after the backward call (stream order or an event) and before anything that overwrites `workspace`. */
+int nerfpp_level_reduce_grads(void* stream, const nerfpp_backward_args* args);
 
 /* torch.optim.Adam single step (ddp_train_nerf.py:324,498); step is the 1-based step count */
 int nerfpp_adam_step(void* stream, float* params, const float* grads, float* exp_avg,

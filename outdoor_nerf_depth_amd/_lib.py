@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hip.so')   # override: diagnostic builds
 
 OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2
 PREC_SPLIT_FWD = 3        # host-side combination: split-bf16 forward, bf16 backward (ops.LevelEngine)
 LOSS_RGB_ONLY, LOSS_MSE, LOSS_L1, LOSS_KL = 0, 1, 2, 3
@@ -38,7 +38,8 @@ class BackwardArgs(C.Structure):
                [(k, _fp) for k in ('ray_d', 'fg_far', 'fg_z', 'bg_z', 'packed', 'workspace', 'tables',
                                    'g_rgb', 'g_depth', 'g_fg_weights')] + \
                [('grad_scale', C.c_float), ('grads', _fp)] + \
-               [(k, _fp) for k in ('ev_bwd_begin', 'ev_bwd_end', 'ev_dw_begin', 'ev_dw_end', 'params')]
+               [(k, _fp) for k in ('ev_bwd_begin', 'ev_bwd_end', 'ev_dw_begin', 'ev_dw_end', 'params')] + \
+               [('defer_reduce', C.c_int32)]
 
 
 # every symbol include/nerfpp_hip.h declares: name -> (restype, argtypes)
@@ -67,6 +68,7 @@ SYMBOLS = {
     'nerfpp_level_forward': (C.c_int, [_fp, C.POINTER(ForwardArgs)]),
     'nerfpp_loss': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [_fp] * 12),
     'nerfpp_level_backward': (C.c_int, [_fp, C.POINTER(BackwardArgs)]),
+    'nerfpp_level_reduce_grads': (C.c_int, [_fp, C.POINTER(BackwardArgs)]),
     'nerfpp_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_double, C.c_double,
                                    C.c_double, C.c_double]),
 }

@@ -17,7 +17,8 @@ COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-
 SOURCES = {
     'nerfpp_tables.hip': [],
     'nerfpp_render.hip': ['-ffp-contract=off'],     # bit-exact sample bins: no implicit FMA
-    'nerfpp_mlp.hip': [],
+    # the fully unrolled MLP kernels: one translation unit per instantiation (nerfpp_mlp.hip, NERFPP_MLP_PART)
+    **{('nerfpp_mlp.hip', k): ['-DNERFPP_MLP_PART=%d' % k] for k in range(13)},
     'nerfpp_dw.hip': [],
     'nerfpp_optim.hip': ['-ffp-contract=off'],      # Adam rounds like torch
     'nerfpp_api.hip': [],
@@ -42,7 +43,10 @@ def _stale(target, deps):
 
 
 def _compile(src, flags, headers=None):
-    obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+    part = ''
+    if isinstance(src, tuple):
+        src, part = src[0], '_%d' % src[1]
+    obj = os.path.join(OBJ, src.replace('.hip', part + '.o'))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in (headers or HEADERS)] + [__file__]
     if _stale(obj, deps):
         cmd = [HIPCC] + COMMON + flags + ['-c', os.path.join(HERE, src), '-o', obj]
@@ -54,8 +58,9 @@ def build(force=False):
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
-    with ThreadPoolExecutor(max_workers=4) as ex:
+            if os.path.isfile(os.path.join(OBJ, f)):
+                os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=int(os.environ.get('NERFPP_BUILD_JOBS', '8'))) as ex:
         objs = list(ex.map(lambda kv: _compile(*kv), SOURCES.items()))
         objs2 = list(ex.map(lambda kv: _compile(kv[0], kv[1], HEADERS_MIP360), SOURCES_MIP360.items()))
     if force or _stale(OUT, objs):

@@ -340,6 +340,39 @@ int nerfpp_loss(void* stream, int n_rays, int n_samples, int loss_type, float la
   return check_launch("loss");
 }
 
+}  // extern "C"
+
+// split-K slabs -> flat gradient (fixed summation order, x grad_scale), then the derived remap / colour-head gradients
+static void reduce_grads(hipStream_t st, const nerfpp_backward_args* a, const WsLayout& L, const TblLayout& T) {
+  char* ws = (char*)a->workspace;
+  const DwPlan plan = dw_plan(L.rows);
+  const float* slabs[N_NET];
+  int64_t slab_floats[N_NET];
+  const int32_t* utbl[N_NET];
+  float* m_out[N_NET];
+  for (int net = 0; net < N_NET; ++net) {
+    slabs[net] = (const float*)(ws + L.slabs[net]);
+    slab_floats[net] = gslab_floats(net);
+    utbl[net] = a->tables + T.unpack[net];
+    m_out[net] = (float*)(ws + L.fix_m[net]);
+  }
+  launch_unpack_grads(st, slabs, slab_floats, plan, utbl, m_out, a->grad_scale, a->grads);
+  launch_remap_fixup(st, a->grads, a->params, m_out[0], m_out[1]);
+}
+
+extern "C" {
+
+int nerfpp_level_reduce_grads(void* stream, const nerfpp_backward_args* a) {
+  REQUIRE(a, "args");
+  REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");
+  REQUIRE(prec_ok(a->precision), "precision must be 1 or 2");
+  REQUIRE(a->workspace && a->tables && a->grads && a->params, "workspace / tables / grads / params");
+  const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
+  REQUIRE(prec_ok(WP) && WP >= a->precision, "workspace_precision must be 0, or >= precision");
+  reduce_grads((hipStream_t)stream, a, ws_layout(a->n_rays, a->n_samples, WP, true), tbl_layout());
+  return check_launch("level_reduce_grads");
+}
+
 int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   REQUIRE(a, "args");
   REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");
@@ -383,18 +416,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
   launch_dw(st, P, dw);
   if (a->ev_dw_end) (void)hipEventRecord((hipEvent_t)a->ev_dw_end, st);
-  const float* slabs[N_NET];
-  int64_t slab_floats[N_NET];
-  const int32_t* utbl[N_NET];
-  float* m_out[N_NET];
-  for (int net = 0; net < N_NET; ++net) {
-    slabs[net] = dw.slabs[net];
-    slab_floats[net] = gslab_floats(net);
-    utbl[net] = a->tables + T.unpack[net];
-    m_out[net] = (float*)(ws + L.fix_m[net]);
-  }
-  launch_unpack_grads(st, slabs, slab_floats, dw.plan, utbl, m_out, a->grad_scale, a->grads);
-  launch_remap_fixup(st, a->grads, a->params, m_out[0], m_out[1]);
+  if (!a->defer_reduce) reduce_grads(st, a, L, T);
   return check_launch("level_backward");
 }
 

@@ -1028,16 +1028,68 @@ static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a) {
   hipLaunchKernelGGL((mlp_bwd_kernel<NET, P, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
 
+// The kernels are fully unrolled instruction streams (1200 MFMAs each) and take about a minute each to compile, so the
+// in-tree build compiles this file once per kernel instantiation: -DNERFPP_MLP_PART=k emits instantiation k only
+// (k = 0..11, bit layout below; 12 = the dispatchers), no define = everything in one translation unit.
+#ifndef NERFPP_MLP_PART
+#define NERFPP_MLP_PART -1
+#endif
+#define MLP_PART(k) (NERFPP_MLP_PART == -1 || NERFPP_MLP_PART == (k))
+// forward: k = net + 2 * (P - 1) + 4 * train;  backward: k = 8 + net + 2 * (P - 1)
+#define FWD_ENTRY(NET, P, TRAIN) void launch_fwd_##NET##_##P##_##TRAIN(hipStream_t st, const MlpFwdArgs& a)
+#define BWD_ENTRY(NET, P) void launch_bwd_##NET##_##P(hipStream_t st, const MlpBwdArgs& a)
+FWD_ENTRY(0, 1, 0); FWD_ENTRY(1, 1, 0); FWD_ENTRY(0, 2, 0); FWD_ENTRY(1, 2, 0);
+FWD_ENTRY(0, 1, 1); FWD_ENTRY(1, 1, 1); FWD_ENTRY(0, 2, 1); FWD_ENTRY(1, 2, 1);
+BWD_ENTRY(0, 1); BWD_ENTRY(1, 1); BWD_ENTRY(0, 2); BWD_ENTRY(1, 2);
+#if MLP_PART(0)
+FWD_ENTRY(0, 1, 0) { launch_fwd_t<0, 1, false>(st, a); }
+#endif
+#if MLP_PART(1)
+FWD_ENTRY(1, 1, 0) { launch_fwd_t<1, 1, false>(st, a); }
+#endif
+#if MLP_PART(2)
+FWD_ENTRY(0, 2, 0) { launch_fwd_t<0, 2, false>(st, a); }
+#endif
+#if MLP_PART(3)
+FWD_ENTRY(1, 2, 0) { launch_fwd_t<1, 2, false>(st, a); }
+#endif
+#if MLP_PART(4)
+FWD_ENTRY(0, 1, 1) { launch_fwd_t<0, 1, true>(st, a); }
+#endif
+#if MLP_PART(5)
+FWD_ENTRY(1, 1, 1) { launch_fwd_t<1, 1, true>(st, a); }
+#endif
+#if MLP_PART(6)
+FWD_ENTRY(0, 2, 1) { launch_fwd_t<0, 2, true>(st, a); }
+#endif
+#if MLP_PART(7)
+FWD_ENTRY(1, 2, 1) { launch_fwd_t<1, 2, true>(st, a); }
+#endif
+#if MLP_PART(8)
+BWD_ENTRY(0, 1) { launch_bwd_t<0, 1>(st, a); }
+#endif
+#if MLP_PART(9)
+BWD_ENTRY(1, 1) { launch_bwd_t<1, 1>(st, a); }
+#endif
+#if MLP_PART(10)
+BWD_ENTRY(0, 2) { launch_bwd_t<0, 2>(st, a); }
+#endif
+#if MLP_PART(11)
+BWD_ENTRY(1, 2) { launch_bwd_t<1, 2>(st, a); }
+#endif
+
+#if MLP_PART(12)
 void launch_mlp_fwd(hipStream_t st, int net, int P, bool train, const MlpFwdArgs& a) {
   if (net == 0) {
-    if (P == 1) { if (train) launch_fwd_t<0, 1, true>(st, a); else launch_fwd_t<0, 1, false>(st, a); }
-    else        { if (train) launch_fwd_t<0, 2, true>(st, a); else launch_fwd_t<0, 2, false>(st, a); }
+    if (P == 1) { if (train) launch_fwd_0_1_1(st, a); else launch_fwd_0_1_0(st, a); }
+    else        { if (train) launch_fwd_0_2_1(st, a); else launch_fwd_0_2_0(st, a); }
   } else {
-    if (P == 1) { if (train) launch_fwd_t<1, 1, true>(st, a); else launch_fwd_t<1, 1, false>(st, a); }
-    else        { if (train) launch_fwd_t<1, 2, true>(st, a); else launch_fwd_t<1, 2, false>(st, a); }
+    if (P == 1) { if (train) launch_fwd_1_1_1(st, a); else launch_fwd_1_1_0(st, a); }
+    else        { if (train) launch_fwd_1_2_1(st, a); else launch_fwd_1_2_0(st, a); }
   }
 }
 void launch_mlp_bwd(hipStream_t st, int net, int P, const MlpBwdArgs& a) {
-  if (net == 0) { if (P == 1) launch_bwd_t<0, 1>(st, a); else launch_bwd_t<0, 2>(st, a); }
-  else          { if (P == 1) launch_bwd_t<1, 1>(st, a); else launch_bwd_t<1, 2>(st, a); }
+  if (net == 0) { if (P == 1) launch_bwd_0_1(st, a); else launch_bwd_0_2(st, a); }
+  else          { if (P == 1) launch_bwd_1_1(st, a); else launch_bwd_1_2(st, a); }
 }
+#endif

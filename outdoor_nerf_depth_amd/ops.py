@@ -264,9 +264,10 @@ class LevelEngine(object):
             self._fwd = (n, S, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
         return out
 
-    def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None, events=None):
+    def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None, events=None, defer_reduce=False):
         """Gradient of the loss w.r.t. the flat parameters given dL/d rgb, dL/d depth and (KL)
-        dL/d fg_weights, for the last training-mode forward."""
+        dL/d fg_weights, for the last training-mode forward.  defer_reduce: stop after the weight-gradient
+        GEMMs; `reduce_grads()` (on any stream ordered after this call) then fills the returned tensor."""
         if self._fwd is None:
             raise L.NerfppError('backward() needs a preceding forward(training=True)')
         n, S, ray_d, fg_far, fg_z, bg_z = self._fwd
@@ -285,7 +286,19 @@ class LevelEngine(object):
         a.params = self.params.data_ptr()
         if events is not None:          # (bwd begin, bwd end, dw begin, dw end)
             a.ev_bwd_begin, a.ev_bwd_end, a.ev_dw_begin, a.ev_dw_end = [e.cuda_event for e in events]
+        a.defer_reduce = int(bool(defer_reduce))
         L.check(L.lib().nerfpp_level_backward(_stream(), C.byref(a)), 'nerfpp_level_backward')
+        # the reduction reads nothing of the batch: keep only what nerfpp_level_reduce_grads looks at alive
+        self._bwd_args = (a, grads) if defer_reduce else None
+        return grads
+
+    def reduce_grads(self):
+        """Second half of backward(defer_reduce=True): split-K slabs -> gradient tensor, on the current stream."""
+        if getattr(self, '_bwd_args', None) is None:
+            raise L.NerfppError('reduce_grads() needs a preceding backward(defer_reduce=True)')
+        a, grads = self._bwd_args
+        self._bwd_args = None
+        L.check(L.lib().nerfpp_level_reduce_grads(_stream(), C.byref(a)), 'nerfpp_level_reduce_grads')
         return grads
 
 

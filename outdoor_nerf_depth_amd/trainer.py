@@ -61,49 +61,60 @@ class NerfppTrainer(object):
                              for _ in self.engines]
         self._ae_grad = [None] * len(self.engines)
         self.last_autoexpo = [None] * len(self.engines)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if (world_size > 1 and overlap_allreduce) else None
-        self._pending = {}
-        self._late = None                 # last level whose all-reduce + Adam are finished at its next use
+        # The parameter update of a level (split-K slab sum -> [RCCL all-reduce] -> Adam -> re-pack of the bf16 weight
+        # streams: four to six short launches that leave most CUs idle) runs on a side stream under the NEXT level's
+        # sampling + forward; the main stream waits for it right before the level's streams are used again, i.e. at
+        # the same level of the next step.  overlap_allreduce=False keeps everything on the caller's stream.
+        self.update_stream = torch.cuda.Stream(device=self.device) if overlap_allreduce else None
+        self._pending = {}                # level -> event recorded after its update on the side stream
 
-    # -- distributed -------------------------------------------------------------------------------
-    def _allreduce_begin(self, m):
-        """Average gradients over ranks (DDP semantics).  grads were pre-scaled by 1/world_size in
-        the backward kernel, so a SUM all-reduce yields the mean.  Runs on a side stream so level
-        0's reduction overlaps level 1's sampling + forward."""
-        if self.world_size <= 1:
-            return
-        import torch.distributed as dist
-        if self.autoexpo is not None:
-            # [n_img, 3]: grads | used flag; a few hundred bytes.  EVERY rank issues this collective every
-            # step: a rank whose image has no auto-exposure entry (ddp_model.py:186 falls back to the plain
-            # rgb loss) contributes zeros, otherwise the ranks' collective sequences would diverge
-            if self._ae_grad[m] is None:
-                self._ae_grad[m] = torch.zeros(len(self.autoexpo[m].names), 3, device=self.device)
-            dist.all_reduce(self._ae_grad[m])
-        if self.comm_stream is None:
+    # -- parameter update ----------------------------------------------------------------------------
+    def _update(self, m, step):
+        """reduce the weight-gradient slabs, average over ranks (DDP semantics: grads were pre-scaled by
+        1/world_size in the reduction, so a SUM all-reduce yields the mean, ddp_train_nerf.py:323), Adam, re-pack."""
+        eng = self.engines[m]
+        eng.reduce_grads()
+        if self.world_size > 1:
+            import torch.distributed as dist
+            if self.autoexpo is not None:
+                # [n_img, 3]: grads | used flag; a few hundred bytes.  EVERY rank issues this collective every
+                # step: a rank whose image has no auto-exposure entry (ddp_model.py:186 falls back to the plain
+                # rgb loss) contributes zeros, otherwise the ranks' collective sequences would diverge
+                if self._ae_grad[m] is None:
+                    self._ae_grad[m] = torch.zeros(len(self.autoexpo[m].names), 3, device=self.device)
+                dist.all_reduce(self._ae_grad[m])
             dist.all_reduce(self.grads[m])
+        ops.adam_step(eng.params, self.grads[m], self.exp_avg[m], self.exp_avg_sq[m], step, lr=self.lrate)
+        eng.repack()
+        if self._ae_grad[m] is not None:
+            self.autoexpo[m].apply(self._ae_grad[m][:, :2], self._ae_grad[m][:, 2] > 0)
+            self._ae_grad[m] = None
+
+    def _update_begin(self, m):
+        if self.update_stream is None:
+            self._update(m, self.step_count)
             return
         ev = torch.cuda.Event()
         ev.record()
-        self.comm_stream.wait_event(ev)
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(self.grads[m])
+        self.update_stream.wait_event(ev)
+        if self._ae_grad[m] is not None:
+            self._ae_grad[m].record_stream(self.update_stream)
+        with torch.cuda.stream(self.update_stream):
+            self._update(m, self.step_count)
             done = torch.cuda.Event()
             done.record()
         self._pending[m] = done
 
-    def _allreduce_end(self, m):
+    def _update_end(self, m):
         done = self._pending.pop(m, None)
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
 
     def flush(self):
-        """Finish the parameter update a multi-GPU step left in flight (the last level's all-reduce is
-        overlapped with the NEXT step's level-0 work).  Call before reading parameters: checkpoints,
-        rendering, end of a timed region."""
-        if self._late is not None:
-            self._apply(*self._late)
-            self._late = None
+        """Order the caller's stream after the parameter updates still running on the side stream.  Call before
+        reading parameters or using the engines directly: checkpoints, rendering, the end of a timed region."""
+        for m in list(self._pending):
+            self._update_end(m)
 
     def check_cameras(self):
         """Raise the reference's exception (ddp_train_nerf.py:62-63) if any ray of any step since the last
@@ -112,16 +123,6 @@ class NerfppTrainer(object):
         if int(self.bad_cameras.item()) != 0:
             self.bad_cameras.zero_()
             raise Exception(ops.CAMERA_ERROR)
-
-    def _apply(self, m, step=None):
-        self._allreduce_end(m)
-        eng = self.engines[m]
-        ops.adam_step(eng.params, self.grads[m], self.exp_avg[m], self.exp_avg_sq[m],
-                      self.step_count if step is None else step, lr=self.lrate)
-        eng.repack()
-        if self._ae_grad[m] is not None:
-            self.autoexpo[m].apply(self._ae_grad[m][:, :2], self._ae_grad[m][:, 2] > 0)
-            self._ae_grad[m] = None
 
     # -- one optimisation step ----------------------------------------------------------------------
     def train_step(self, batch, uniforms=None, events=None):
@@ -148,7 +149,6 @@ class NerfppTrainer(object):
         depth_sup = batch.get('depth_sup') if self.loss_type != 'rgbonly' else None
         scalars = []
         ret = None
-        deferred = None
         ae_idx = None
         if self.autoexpo is not None:
             name = batch.get('img_name')
@@ -156,9 +156,7 @@ class NerfppTrainer(object):
                 name = self.img_names[int(batch['frame'])]
             ae_idx = self.autoexpo[0].lookup(name)
         for m, eng in enumerate(self.engines):
-            if self._late is not None and self._late[0] == m:     # this level's update from the previous step
-                self._apply(*self._late)
-                self._late = None
+            self._update_end(m)                   # this level's update from the previous step
             if m > 0 and rng is not None:
                 fg_z, bg_z = ops.sample_fine_pair(fg_z, ret['fg_weights'], bg_z, ret['bg_weights'], S1, rng=rng)
             elif m > 0:
@@ -181,19 +179,9 @@ class NerfppTrainer(object):
                 self._ae_grad[m] = rows
                 self.last_autoexpo[m] = ae.scale_shift(ae_idx)
             eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m],
-                         events=ev['bwd'] if ev else None)
+                         events=ev['bwd'] if ev else None, defer_reduce=True)
             scalars.append(sc)
-            if deferred is not None:              # level m-1's Adam after level m's work was queued
-                self._apply(deferred)
-                deferred = None
-            self._allreduce_begin(m)
-            if self.world_size > 1 and self.comm_stream is not None:
-                if m + 1 < len(self.engines):
-                    deferred = m                  # overlap this level's all-reduce with the next level
-                else:
-                    self._late = (m, self.step_count)   # ... and the last level's with the next step's level 0
-            else:
-                self._apply(m)
+            self._update_begin(m)
         return scalars
 
 

@@ -428,6 +428,7 @@ def test_autoexposure_training_steps_match_reference(ops, golden):
         close(N(sc[0])[0], g['s%d.loss' % step], 5e-4, 0)
         close(N(sc[0])[1], g['s%d.rgb_loss' % step], 5e-4, 1e-7)
         close(float(tr.last_autoexpo[0][0]), g['s%d.scale' % step], 1e-6, 0)
+        tr.flush()                                    # the parameter updates run on the trainer's side stream
         np.testing.assert_allclose(N(tr.autoexpo[0].params), g['s%d.params_after' % step], rtol=2e-4, atol=2e-7)
     w = state_dict_from_flat(tr.engines[0].params)['module.nerf_net.fg_net.rgb_layers.2.weight']
     np.testing.assert_allclose(N(w), g['final.fg_rgb2_weight'], rtol=0, atol=2e-4)

@@ -211,6 +211,7 @@ def test_config1_rgbonly_32_coarse_samples_steps_match_oracle(ops):
         close(N(sc[0])[0], logs[0]['loss'], 1e-4, 0)
         close(N(sc[1])[0], logs[1]['loss'], 2e-3, 0)
         assert N(sc[0])[2] == 0 and rets[0][0]['fg_weights'].shape == (n, 32) and rets[1][0]['fg_weights'].shape == (n, 96)
+    tr.flush()                                        # the parameter updates run on the trainer's side stream
     for m in range(2):
         now = unflat(N(tr.engines[m].params))
         for k in O.param_order():
