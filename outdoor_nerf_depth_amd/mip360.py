@@ -557,6 +557,25 @@ class Mip360Trainer(object):
             levels.append(dict(sdist=sdist, tdist=tdist, density=density, rgb_s=rgb_s, saved=saved, rows=rows, ns=ns, **r))
         return levels
 
+    def apply_gradients(self):
+        """train_utils.py:340-364 on the flat gradient buffers of both MLPs: mean over ranks (jax.lax.pmean; SUM
+        all-reduce over RCCL, then / world_size), per-MLP global-norm clipping, Adam with the log-decayed learning
+        rate, re-pack of the bf16 weight copies."""
+        lr = learning_rate(self.step, max_steps=self.max_steps)
+        L = lib()
+        for k, tm in enumerate((self.nerf, self.prop)):
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.all_reduce(tm.grads)
+                tm.grads.div_(self.world_size)
+            n = tm.grads.numel()
+            _check(L.mip360_sum_squares(_stream(), n, _p(tm.grads), _p(self.partials[k]), 256), 'mip360_sum_squares')
+            _check(L.mip360_clip_multiplier(_stream(), 256, _p(self.partials[k]), float(self.grad_max_norm), _p(self.clip[k])),
+                   'mip360_clip_multiplier')
+            _check(L.mip360_adam_step(_stream(), n, _p(tm.flat), _p(tm.grads), _p(tm.mu), _p(tm.nu), _p(self.clip[k]), self.step,
+                                      lr, 0.9, 0.999, self.adam_eps), 'mip360_adam_step')
+            tm.repack()
+
     def train_step(self, rays, rgb_gt, depth_sup, jitter01=None):
         """rays / rgb_gt [n,3] / depth_sup [n] on the device.  Returns the scalars tensor of mip360_losses."""
         self.step += 1
@@ -582,18 +601,5 @@ class Mip360Trainer(object):
             mlp_backward(self.prop, p['saved'], p['rows'], gd, None, self.scratch)
             acc = self.prop.grads.clone() if acc is None else acc.add_(self.prop.grads)
         self.prop.grads.copy_(acc)
-        lr = learning_rate(self.step, max_steps=self.max_steps)
-        L = lib()
-        for k, tm in enumerate((self.nerf, self.prop)):
-            if self.world_size > 1:
-                import torch.distributed as dist
-                dist.all_reduce(tm.grads)
-                tm.grads.div_(self.world_size)
-            n = tm.grads.numel()
-            _check(L.mip360_sum_squares(_stream(), n, _p(tm.grads), _p(self.partials[k]), 256), 'mip360_sum_squares')
-            _check(L.mip360_clip_multiplier(_stream(), 256, _p(self.partials[k]), float(self.grad_max_norm), _p(self.clip[k])),
-                   'mip360_clip_multiplier')
-            _check(L.mip360_adam_step(_stream(), n, _p(tm.flat), _p(tm.grads), _p(tm.mu), _p(tm.nu), _p(self.clip[k]), self.step,
-                                      lr, 0.9, 0.999, self.adam_eps), 'mip360_adam_step')
-            tm.repack()
+        self.apply_gradients()
         return sc

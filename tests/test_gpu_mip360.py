@@ -448,3 +448,87 @@ def test_trainer_steps_reduce_the_loss_and_are_deterministic(M):
     # first Adam step with clipped gradients: |delta| = lr * |g| / (|g| + eps_hat) <= lr
     delta = np.abs(N(tr.nerf.flat) - before)
     assert delta.max() <= M.learning_rate(1, max_steps=2000) * 1.001 and delta.max() > 0
+
+
+# ------------------------------------------------------------------------------------------- data parallel (pmean)
+def _dp_inputs(rank, n=48):
+    rs = np.random.RandomState(100 + rank)
+    rays = _rays(rs, n)
+    gt = rs.rand(n, 3).astype(np.float32)
+    sup = np.where(rs.rand(n) < .5, rs.uniform(1, 4, n), 0).astype(np.float32)
+    jit = [rs.rand(n).astype(np.float32) for _ in range(3)]
+    return rays, gt, sup, jit
+
+
+def _dp_init():
+    return O.init_mlp_params(O.PROP_CFG, np.random.RandomState(0)), O.init_mlp_params(O.NERF_CFG, np.random.RandomState(1))
+
+
+def _dp_worker(rank, world, port, out_dir, backend):
+    import os
+    import torch.distributed as dist
+    from outdoor_nerf_depth_amd import mip360 as M3
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    d = torch.device('cuda:%d' % (rank if backend == 'nccl' else 0))
+    torch.cuda.set_device(d)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    prop, nerf = _dp_init()
+    tr = M3.Mip360Trainer(prop, nerf, d, max_steps=2000, world_size=world)
+    rays, gt, sup, jit = _dp_inputs(rank)
+    rays = {k: to(v) for k, v in rays.items()}
+    for _ in range(2):
+        tr.train_step(rays, to(gt), to(sup), jitter01=[to(j) for j in jit])
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, 'mip360_rank%d.npy' % rank),
+            np.concatenate([tr.nerf.flat.cpu().numpy(), tr.prop.flat.cpu().numpy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_run_and_check(M, tmp_path, backend):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), backend), nprocs=2, join=True)
+    got = [np.load(str(tmp_path / ('mip360_rank%d.npy' % r))) for r in range(2)]
+    np.testing.assert_array_equal(got[0], got[1])                       # every rank applies the identical update
+    # single process: each rank's gradients from its own trainer, averaged by hand (train_utils.py:340-342), then the
+    # same clip + Adam
+    prop, nerf = _dp_init()
+    trs = [M.Mip360Trainer(prop, nerf, dev(), max_steps=2000) for _ in range(3)]
+    main = trs[2]
+    for step in range(2):
+        for r in range(2):
+            rays, gt, sup, jit = _dp_inputs(r)
+            t = trs[r]
+            t.nerf.flat.copy_(main.nerf.flat); t.prop.flat.copy_(main.prop.flat)
+            t.nerf.repack(); t.prop.repack()
+            t.step = main.step
+            apply = t.apply_gradients
+            t.apply_gradients = lambda: None                            # gradients only
+            t.train_step({k: T(v) for k, v in rays.items()}, T(gt), T(sup), jitter01=[T(j) for j in jit])
+            t.apply_gradients = apply
+        main.step += 1
+        for name in ('nerf', 'prop'):
+            g = getattr(trs[0], name).grads + getattr(trs[1], name).grads
+            getattr(main, name).grads.copy_(g.div_(2))
+        main.apply_gradients()
+    want = np.concatenate([N(main.nerf.flat), N(main.prop.flat)])
+    np.testing.assert_array_equal(got[0], want)
+
+
+def test_two_ranks_pmean_matches_hand_averaged_gradients_gloo(M, tmp_path):
+    """train_utils.py:340-342 (jax.lax.pmean over the device axis): two ranks sharing cuda:0, gloo all-reduce."""
+    _dp_run_and_check(M, tmp_path, 'gloo')
+
+
+def test_two_ranks_pmean_rccl(M, tmp_path):
+    """The same over RCCL (backend nccl), one GPU per rank."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    _dp_run_and_check(M, tmp_path, 'nccl')
