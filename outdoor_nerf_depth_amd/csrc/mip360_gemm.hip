@@ -156,14 +156,18 @@ __device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
                : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 
-template <int ACT>
-__global__ __launch_bounds__(512) void linear_bf16_ring_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda,
+// WM x WN waves, each owning FM x FN MFMA blocks: (2, 4, 4, 2) = 8 waves of 128 x 64, two per SIMD;
+// (2, 2, 4, 4) = 4 waves of 128 x 128, one per SIMD with the whole register file (8 fragment reads feed 16 MFMAs)
+template <int ACT, int WM, int WN, int FM, int FN>
+__global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda,
                                                                const __bf16* __restrict__ W, int ldw,
                                                                const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc,
                                                                float* __restrict__ C32, int ldc32, float act_param,
                                                                const __bf16* __restrict__ aux, int ldaux) {
+  static_assert(WM * FM * 32 == RT && WN * FN * 32 == RT, "256 x 256 tile");
+  constexpr int NW = WM * WN, NT = NW * 64, QD = 16 / NW;        // QD: DMA instructions per operand per wave per stage
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (N + RT - 1) / RT, tiles_m = (M + RT - 1) / RT;
   int tile_m, tile_n;
   {                                                           // XCD-aware order, see linear_bf16_kernel
@@ -175,13 +179,13 @@ __global__ __launch_bounds__(512) void linear_bf16_ring_kernel(int M, int N, int
   }
   const int m0 = tile_m * RT, n0 = tile_n * RT;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_smem;
-  // DMA lane map: instruction q of this wave covers tile rows [16 * (wave * 2 + (q & 1)) ... + 16) of operand q >> 1
+  // DMA lane map: instruction q of this wave covers tile rows [16 * (wave * QD + q % QD) ... + 16) of operand q / QD
   const int drow = lane >> 2, dpos = lane & 3;
-  const char* gsrc[4];
-  uint32_t ldst[4];
+  const char* gsrc[2 * QD];
+  uint32_t ldst[2 * QD];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int op = q >> 1, row = 16 * (wave * 2 + (q & 1)) + drow;
+  for (int q = 0; q < 2 * QD; ++q) {
+    const int op = q / QD, row = 16 * (wave * QD + q % QD) + drow;
     const int chunk = dpos ^ ((row >> 2) & 3);
     if (op == 0) {
       int m = m0 + row; m = m < M ? m : M - 1;
@@ -190,20 +194,20 @@ __global__ __launch_bounds__(512) void linear_bf16_ring_kernel(int M, int N, int
       int n = n0 + row; n = n < N ? n : N - 1;
       gsrc[q] = (const char*)(W + (size_t)n * ldw + chunk * 8);
     }
-    ldst[q] = (uint32_t)(op * RT * RBK * 2 + 16 * (wave * 2 + (q & 1)) * 64);      // + slot * RSTAGE, + lane * 16 by the hardware
+    ldst[q] = (uint32_t)(op * RT * RBK * 2 + 16 * (wave * QD + q % QD) * 64);      // + slot * RSTAGE, + lane * 16 by the hardware
   }
   const int nk = K / RBK;
   auto issue = [&](int kt) {
     if (kt >= nk) return;
     const uint32_t slot = (uint32_t)(kt % RNBUF) * RSTAGE;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16_asm(gsrc[q] + (size_t)kt * RBK * 2, lds0 + slot + ldst[q]);
+    for (int q = 0; q < 2 * QD; ++q) glds16_asm(gsrc[q] + (size_t)kt * RBK * 2, lds0 + slot + ldst[q]);
   };
-  f32x16 acc[4][2];
+  f32x16 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
@@ -212,79 +216,91 @@ __global__ __launch_bounds__(512) void linear_bf16_ring_kernel(int M, int N, int
   const int frow = lane & 31, fkh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int younger = nk - 1 - kt < RNBUF - 2 ? nk - 1 - kt : RNBUF - 2;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * QD) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(kt + RNBUF - 1);
     const char* st = ring_smem + (kt % RNBUF) * RSTAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[2];
+      bf16x8 fa[FM], fb[FN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int R = wm * 128 + i * 32 + frow;
+      for (int i = 0; i < FM; ++i) {
+        const int R = wm * FM * 32 + i * 32 + frow;
         fa[i] = *(const bf16x8*)(st + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int R = wn * 64 + j * 32 + frow;
+      for (int j = 0; j < FN; ++j) {
+        const int R = wn * FN * 32 + j * 32 + frow;
         fb[j] = *(const bf16x8*)(st + RT * RBK * 2 + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        // operands swapped (W fragment as "A"): the accumulator block is C^T, i.e. lane (l & 31) holds ROW m of the
+        // tile and register r column (r & 3) + 8 (r >> 2) + 4 (l >> 5) -- four consecutive columns per register
+        // quad, which the epilogue packs into one 8-byte LDS write
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   }
   const int hi = lane >> 5;
+  auto activate = [&](float v) {
+    if (ACT == 1) v = fmaxf(v, 0.f);
+    if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+    if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
+    return v;
+  };
   if (C32 != nullptr) {                                       // float32 outputs (rare for wide layers): direct stores
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + frow;
-      if (n >= N) continue;
-      const float b = bias ? bias[n] : 0.f;
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm * FM * 32 + i * 32 + frow;
+      if (m >= M) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (m >= M) continue;
-          float v = acc[i][j][r] + b;
-          if (ACT == 1) v = fmaxf(v, 0.f);
-          if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+          const int n = n0 + wn * FN * 32 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (n >= N) continue;
+          float v = activate(acc[i][j][r] + (bias ? bias[n] : 0.f));
           if (ACT == 4) v = (float)aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;
-          if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
           C32[(size_t)m * ldc32 + n] = v;
           if (C16) C16[(size_t)m * ldc + n] = (__bf16)v;
         }
-      }
     }
     return;
   }
-  // bf16 output: the accumulator layout gives a lane ONE column and 16 scattered rows, i.e. 2-byte stores in 64-byte row
-  // segments.  The ring is idle now, so the tile is transposed through it ([256][256] bf16 = its 128 KiB, rows rotated by
-  // 16 bytes per row against bank conflicts) and leaves as 16 bytes per lane = whole 512-byte rows per 32 lanes; the ReLU
-  // mask (ACT 4) is applied on the way out from equally coalesced 16-byte loads of the saved activation.
+  // bf16 output.  The ring is idle now, so the tile is staged through it ([256][256] bf16 = its 128 KiB, rows rotated by
+  // 16 bytes per row against bank conflicts; 8-byte writes: a register quad is 4 consecutive columns of one row) and
+  // leaves as 16 bytes per lane = whole 512-byte rows per 32 lanes; the ReLU mask (ACT 4) is applied on the way out
+  // from equally coalesced 16-byte loads of the saved activation.
   __builtin_amdgcn_s_barrier();
   {
     __bf16* tile = (__bf16*)ring_smem;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nl = wn * 64 + j * 32 + frow;
-      const int n = n0 + nl;
-      const float b = (bias && n < N) ? bias[n] : 0.f;
+    for (int j = 0; j < FN; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          float v = acc[i][j][r] + b;
-          if (ACT == 1) v = fmaxf(v, 0.f);
-          if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
-          if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
-          tile[ml * 256 + ((nl + 8 * ml) & 255)] = (__bf16)v;
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn * FN * 32 + j * 32 + 8 * q + 4 * hi;        // first of 4 consecutive columns
+        const int n = n0 + nl;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) {
+          if (n + 4 <= N) b4 = *(const float4*)(bias + n);
+          else { if (n < N) b4.x = bias[n]; if (n + 1 < N) b4.y = bias[n + 1]; if (n + 2 < N) b4.z = bias[n + 2]; }
         }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int ml = wm * FM * 32 + i * 32 + frow;
+          const f32x2 lo = {activate(acc[i][j][4 * q] + b4.x), activate(acc[i][j][4 * q + 1] + b4.y)};
+          const f32x2 hi2 = {activate(acc[i][j][4 * q + 2] + b4.z), activate(acc[i][j][4 * q + 3] + b4.w)};
+          uint2 pk;
+          pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+          pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
+          *(uint2*)(tile + ml * 256 + ((nl + 8 * ml) & 255)) = pk;
+        }
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -293,8 +309,8 @@ __global__ __launch_bounds__(512) void linear_bf16_ring_kernel(int M, int N, int
     const __bf16* tile = (const __bf16*)ring_smem;
     const bool vec_ok = ((ldc & 7) == 0) && (ACT != 4 || (ldaux & 7) == 0);
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int c = it * 512 + tid, ml = c >> 5, piece = c & 31;          // 32 pieces of 8 columns per row
+    for (int it = 0; it < 8192 / NT; ++it) {
+      const int c = it * NT + tid, ml = c >> 5, piece = c & 31;           // 32 pieces of 8 columns per row
       const int m = m0 + ml, n = n0 + piece * 8;
       if (m >= M || n >= N) continue;
       uint4 v = *(const uint4*)(tile + ml * 256 + ((piece * 8 + 8 * ml) & 255));
@@ -333,9 +349,14 @@ static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, 
   using namespace mip360;
   static const bool force_small = getenv("MIP360_GEMM_SMALL") != nullptr;
   static const bool no_ring = getenv("MIP360_GEMM_NORING") != nullptr;
+  static const bool four_waves = getenv("MIP360_GEMM_4WAVES") != nullptr;
   if (N >= 192 && M >= 256 && !force_small && !no_ring) {
     const int tiles = ((M + RT - 1) / RT) * ((N + RT - 1) / RT);
-    hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT>), dim3(tiles), dim3(512), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A, lda,
+    if (four_waves)
+      hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, 2, 2, 4, 4>), dim3(tiles), dim3(256), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A,
+                         lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+    else
+    hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, 2, 4, 4, 2>), dim3(tiles), dim3(512), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A, lda,
                        (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
   } else if (N >= 192 && M >= 256 && !force_small) {
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256);

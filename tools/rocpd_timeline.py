@@ -3,7 +3,7 @@
 training step (a step starts at sample_coarse_kernel of level 0) with its start offset, duration and
 the idle gap since the previous kernel ended; then busy / idle totals.
 
-    python tools/rocpd_timeline.py gpurun_out/prof/*/*.db [anchor_kernel_substring]
+    python tools/rocpd_timeline.py gpurun_out/prof/*/*.db [anchor_kernel_substring [anchors_per_step]]
 """
 import re
 import sqlite3
@@ -12,17 +12,19 @@ import sys
 
 def short(name):
     name = re.sub(r'\(.*$', '', name)
-    return name.replace('nerfpp::', '').replace('void ', '')[:60]
+    return name.replace('nerfpp::', '').replace('mip360::', '').replace('void ', '')[:60]
 
 
-def main(path, anchor='sample_coarse_kernel'):
+def main(path, anchor='sample_coarse_kernel', per_step=1):
+    per_step = int(per_step)
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
     name_col = 'name' if 'name' in cols else [x for x in cols if 'name' in x][0]
     rows = sorted(c.execute('select %s, start, end from kernels' % name_col).fetchall(), key=lambda r: r[1])
     starts = [i for i, r in enumerate(rows) if anchor in r[0]]
-    if len(starts) < 3:
-        raise SystemExit('need at least 3 anchors')
+    if len(starts) < 3 * per_step:
+        raise SystemExit('need at least 3 steps of anchors')
+    starts = starts[len(starts) % per_step::per_step]          # first anchor of every step
     lo, hi = starts[-3], starts[-2]
     step = rows[lo:hi]
     t0 = step[0][1]
@@ -39,4 +41,4 @@ def main(path, anchor='sample_coarse_kernel'):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])
