@@ -200,6 +200,18 @@ __device__ __forceinline__ float safe_sin(float x) {      // math.py:26-38 with 
   return sinf(x);
 }
 
+// bf16 features only need bf16-grade sines: the same safe_sin argument handling, then a two-constant Cody-Waite
+// reduction to [-pi, pi] and the hardware v_sin_f32 (argument in revolutions) instead of libm's sinf (~50 VALU ops;
+// the kernel is VALU-bound on them: 24 sines + 12 exponentials per lane).  Absolute error ~2e-6.
+__device__ __forceinline__ float safe_sin_fast(float x) {
+  const float t = 314.15927f;
+  if (fabsf(x) >= t) x = x - floorf(x / t) * t;
+  const float n = rintf(x * 0.15915494309189535f);
+  float r = fmaf(-n, 6.2831854820251465f, x);
+  r = fmaf(-n, -1.7484556000744883e-7f, r);
+  return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void cast_encode_kernel(
     int n, int S, const float* __restrict__ tdist, const float* __restrict__ origins,
@@ -207,9 +219,11 @@ __global__ __launch_bounds__(256) void cast_encode_kernel(
     void* __restrict__ enc, int ld) {
   const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   const int sub = lane / MIP360_N_BASIS, j = lane - sub * MIP360_N_BASIS;
-  const int64_t row = (int64_t)wave_g * 3 + sub;
+  const int64_t row_raw = (int64_t)wave_g * 3 + sub;
   const int64_t rows = (int64_t)n * S;
-  if (sub >= 3 || row >= rows) return;
+  const bool live = sub < 3 && row_raw < rows;
+  const int64_t row = live ? row_raw : rows - 1;                 // idle lanes compute a valid row and store nothing
+  if ((int64_t)wave_g * 3 >= rows) return;
   const int ray = (int)(row / S), smp = (int)(row - (int64_t)ray * S);
   const float t0 = tdist[(size_t)ray * (S + 1) + smp], t1 = tdist[(size_t)ray * (S + 1) + smp + 1];
   const float d[3] = {directions[ray * 3], directions[ray * 3 + 1], directions[ray * 3 + 2]};
@@ -268,14 +282,24 @@ __global__ __launch_bounds__(256) void cast_encode_kernel(
   for (int a = 0; a < 3; ++a) lv += v[a] * (cov[a][0] * v[0] + cov[a][1] * v[1] + cov[a][2] * v[2]);
   // integrated_pos_enc, degrees [0, 12) (coord.py:108-128): column k*21 + j = sin, 252 + k*21 + j = cos
   constexpr int ND = 12, HALF = ND * MIP360_N_BASIS;
+  // bf16 rows feeding a GEMM (ld >= 512 columns, 16-byte aligned): the 21-lane pieces of a row are 42-byte runs of
+  // 2-byte stores, so the wave's 3 rows (1 KiB each incl. the zero padding 504..511) are assembled in LDS and leave
+  // as 16 bytes per lane (3 wave-stores instead of 24 partial ones)
+  __shared__ __attribute__((aligned(16))) __bf16 rows_lds[4][3][MIP360_IPE_LD];
+  const bool staged = BF16 && ld >= MIP360_IPE_LD && (ld & 7) == 0 && (((uintptr_t)enc) & 15) == 0;
+  const int wave_l = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < ND; ++k) {
     const float sc = (float)(1 << k);
     const float sm = lm * sc, sv = lv * sc * sc;
-    const float damp = expf(-0.5f * sv);
-    const float es = damp * safe_sin(sm);
-    const float ec = damp * safe_sin(sm + 1.5707963267948966f);
-    if (BF16) {
+    const float damp = BF16 ? __expf(-0.5f * sv) : expf(-0.5f * sv);
+    const float es = !live ? 0.f : damp * (BF16 ? safe_sin_fast(sm) : safe_sin(sm));
+    const float ec = !live ? 0.f : damp * (BF16 ? safe_sin_fast(sm + 1.5707963267948966f) : safe_sin(sm + 1.5707963267948966f));
+    if (!live) continue;
+    if (staged) {
+      rows_lds[wave_l][sub][k * MIP360_N_BASIS + j] = (__bf16)es;
+      rows_lds[wave_l][sub][HALF + k * MIP360_N_BASIS + j] = (__bf16)ec;
+    } else if (BF16) {
       __bf16* e = (__bf16*)enc + (size_t)row * ld;
       e[k * MIP360_N_BASIS + j] = (__bf16)es;
       e[HALF + k * MIP360_N_BASIS + j] = (__bf16)ec;
@@ -285,6 +309,19 @@ __global__ __launch_bounds__(256) void cast_encode_kernel(
       e[HALF + k * MIP360_N_BASIS + j] = ec;
     }
   }
+  if (staged) {
+    if (live && j < MIP360_IPE_LD - 2 * HALF) rows_lds[wave_l][sub][2 * HALF + j] = (__bf16)0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t row0 = (int64_t)wave_g * 3;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int piece = it * 64 + lane, r = piece >> 6, c8 = (piece & 63) * 8;
+      if (row0 + r < rows) *(uint4*)((__bf16*)enc + (size_t)(row0 + r) * ld + c8) = *(const uint4*)&rows_lds[wave_l][r][c8];
+    }
+    return;
+  }
+  if (!live) return;
   const int pad_to = ld < MIP360_IPE_LD ? ld : MIP360_IPE_LD;               // zero padding 504..511 (K of the next layer)
   for (int col = 2 * HALF + j; col < pad_to; col += MIP360_N_BASIS) {
     if (BF16) ((__bf16*)enc)[(size_t)row * ld + col] = (__bf16)0.f;

@@ -104,10 +104,11 @@ def test_cast_encode_matches_oracle(M):
     err = np.abs(enc[:, :504] - want)
     assert (err <= 2e-6 + 3e-6 * scale[None, :] * np.maximum(1.0, np.abs(np.tile(np.repeat(lm.reshape(n * S, 1, 21), 12, 1).reshape(n * S, 252), 2)))).all(), err.max()
     assert err[:, :21 * 4].max() < 2e-5                                # the low degrees are tight
-    # bf16 output = rounding of the same values, written through a strided view (the MLP's skip buffer)
+    # bf16 output = rounding of the same values (hardware sine / exp2 in that path: a few 1e-6 absolute, far below the
+    # bf16 grid), written through a strided view (the MLP's skip buffer)
     buf = torch.full((n * S + 1, 256 + 512), 7.0, dtype=torch.bfloat16, device=dev())
     M.cast_encode(T(tdist), T(rays['origins']), T(rays['directions']), T(rays['radii']), T(basis), out=buf[:, 256:], ld=768)
-    np.testing.assert_allclose(N(buf[:n * S, 256:256 + 504]), enc[:, :504], rtol=2 ** -8, atol=1e-6)
+    np.testing.assert_allclose(N(buf[:n * S, 256:256 + 504]), enc[:, :504], rtol=2 ** -8, atol=8e-6)
     assert not N(buf[:n * S, 256 + 504:]).any()                        # K padding of the window
     assert (N(buf[:, :256]) == 7).all() and (N(buf[n * S]) == 7).all()   # nothing outside the window is touched
 
