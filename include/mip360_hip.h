@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MIP360_ABI_VERSION 1
+#define MIP360_ABI_VERSION 2
 #define MIP360_OK 0
 #define MIP360_ERR_ARG 1
 #define MIP360_ERR_HIP 2
@@ -120,6 +120,9 @@ int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda
 int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz,
                             int lddz, int ksplit, float* slabs, float* grad_kernel, int ldg, float scale,
                             float* grad_bias);
+/* Output tile edge (256 or 128) the call above will use for these sizes: the caller picks ksplit (1..256) so that
+ * ceil(n_in / tile) * ceil(n_out / tile) * ksplit fills the 256 CUs (multiples of 8 keep a row slice on one XCD). */
+int mip360_grad_weight_tile(int m, int n_in, int n_out, int ldh, int lddz);
 
 /* d bias [n_out] = scale * column sums of dZ [m, n_out] (bf16); partial >= nslice * n_out floats. */
 int mip360_grad_bias_bf16(void* stream, int m, int n_out, const void* dz, int lddz, int nslice, float* partial,

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace mip360 {
 
@@ -146,6 +147,132 @@ __global__ __launch_bounds__(256) void grad_weight_kernel(int M, int I, int O, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wide layers (I and O multiples of 256, M a multiple of 32): 256 x 256 output tile per workgroup, 8 waves (2 along I x
+// 4 along O, 128 x 64 = 4 x 2 MFMA blocks each), operands DMA'd unchanged (row-major, 32 rows x 512 B per operand and
+// K step) into a 4-deep LDS ring with global_load_lds_dwordx4 -- no VGPR staging, three K steps in flight, counted
+// vmcnt, one raw s_barrier per step -- and read back through ds_read_b64_tr_b16 (same image as the NeRF++ dw_kernel:
+// a 1 KiB DMA instruction covers 2 rows, every 1 KiB segment is followed by 64 B of padding so that the 4 rows one
+// transposed read touches fall into disjoint bank windows).  Per K step a wave reads 6 fragments for 8 MFMAs (the
+// 128 x 128 kernel above: 4 for 4) and a workgroup's operand bytes per FLOP are halved.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WSEG = 1024 + 64, WOPER = 16 * WSEG, WNBUF = 4;       // LDS: 4 x 2 x 17 KiB = 136 KiB
+
+__device__ __forceinline__ void glds16_nt(const void* g, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+__device__ __forceinline__ bf16x8 tr_frag_wide(uint32_t off) {
+  __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)gw_smem;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + 512));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(512) void grad_weight_wide_kernel(int M, int I, int O, const __bf16* __restrict__ H, int ldh,
+                                                               const __bf16* __restrict__ dZ, int lddz, int ksplit,
+                                                               float* __restrict__ slabs, int ldc, float* __restrict__ bias_slabs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 2, wo = wave & 3;
+  const int tiles_o = O / 256, tiles = (I / 256) * tiles_o;
+  int slice, b;                                         // XCD-aware order, see grad_weight_kernel
+  if ((ksplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, id = blockIdx.x >> 3, per_xcd = ksplit >> 3;
+    slice = xcd * per_xcd + id / tiles;
+    b = id % tiles;
+  } else {
+    slice = blockIdx.x / tiles;
+    b = blockIdx.x - slice * tiles;
+  }
+  const int ti = b / tiles_o, to = b - ti * tiles_o;
+  const int i0 = ti * 256, o0 = to * 256;
+  const int64_t chunks_total = M / 32;
+  const int64_t per = (chunks_total + ksplit - 1) / ksplit;
+  const int64_t c_begin = (int64_t)slice * per, c_end = c_begin + per < chunks_total ? c_begin + per : chunks_total;
+  const int nchunk = c_end > c_begin ? (int)(c_end - c_begin) : 0;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)gw_smem;
+  // DMA: 2 operands x 16 segments per chunk = 32 wave-instructions, 4 per wave; lane -> (row of the pair, 16-byte column)
+  const int dma_col = (lane & 31) * 16, dma_row = lane >> 5;
+  const char* gh = (const char*)(H + i0) + (size_t)dma_row * ldh * 2 + dma_col;
+  const char* gz = (const char*)(dZ + o0) + (size_t)dma_row * lddz * 2 + dma_col;
+  auto issue = [&](int c) {
+    if (c >= nchunk) return;
+    const int64_t r0 = (c_begin + c) * 32;
+    const uint32_t buf = lds_base + (uint32_t)(c % WNBUF) * (2 * WOPER);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int id = x * 8 + wave, op = id >> 4, seg = id & 15;
+      const char* src = op == 0 ? gh + (size_t)(r0 + 2 * seg) * ldh * 2 : gz + (size_t)(r0 + 2 * seg) * lddz * 2;
+      glds16_nt(src, buf + op * WOPER + seg * WSEG);
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  const bool do_bias = bias_slabs != nullptr && ti == 0 && wi == 0;
+  float bsum[2] = {0.f, 0.f};
+  // transposed-read lane map: 16-lane group g = lane >> 4: k half g >> 1, column sub-block g & 1; a16 = lane & 15: row
+  // pair (segment) a16 >> 2 of the half, 4-column piece a16 & 3
+  const int g = lane >> 4, a16 = lane & 15;
+  const uint32_t lane_off = (uint32_t)((4 * (g >> 1) + (a16 >> 2)) * WSEG + (16 * (g & 1) + 4 * (a16 & 3)) * 2);
+#pragma unroll
+  for (int c = 0; c < WNBUF - 1; ++c) issue(c);
+  for (int c = 0; c < nchunk; ++c) {
+    const int younger = nchunk - 1 - c < WNBUF - 2 ? nchunk - 1 - c : WNBUF - 2;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(c + WNBUF - 1);
+    const uint32_t buf = (uint32_t)(c % WNBUF) * (2 * WOPER) + lane_off;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fh[4], fz[2];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) fh[x] = tr_frag_wide(buf + kk * 8 * WSEG + (4 * wi + x) * 64);
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fz[y] = tr_frag_wide(buf + WOPER + kk * 8 * WSEG + (2 * wo + y) * 64);
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[x], fz[y], acc[x][y], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[y] += (float)fz[y][e];
+      }
+    }
+  }
+  float* slab = slabs + (size_t)slice * I * ldc;
+  const int hi = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    const int o = o0 + wo * 64 + y * 32 + j;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * 128 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        slab[(size_t)i * ldc + o] = acc[x][y][r];
+      }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const float tot = bsum[y] + __shfl_xor(bsum[y], 32, 64);
+      const int o = o0 + wo * 64 + y * 32 + j;
+      if (hi == 0) bias_slabs[(size_t)slice * O + o] = tot;
+    }
+  }
+}
+
 // out[e] = scale * sum_s slabs[s][e], fixed order
 __global__ void slab_sum_kernel(int64_t n, int ksplit, const float* __restrict__ slabs, float scale, float* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,12 +370,21 @@ __global__ void pack_weight_kernel(int n_in, int n_out, const float* __restrict_
 
 using namespace mip360;
 
+// the 256 x 256-tile kernel needs whole tiles, whole 32-row chunks and 16-byte aligned rows
+bool mip360_grad_weight_is_wide(int M, int I, int O, int ldh, int lddz) {
+  static const bool off = getenv("MIP360_DW_NARROW") != nullptr;
+  return !off && M % 32 == 0 && M >= 256 && I % 256 == 0 && O % 256 == 0 && ldh % 8 == 0 && lddz % 8 == 0;
+}
 void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
                                float* slabs, float* out, int ldc, float scale, float* bias_out) {
   const int tiles = ((I + GT - 1) / GT) * ((O + GT - 1) / GT);
   const size_t lds = 4 * GK * GROWB;
   const int64_t n = (int64_t)I * ldc;
   float* bias_slabs = bias_out ? slabs + (size_t)ksplit * n : nullptr;            // [ksplit][O] after the kernel slabs
+  if (mip360_grad_weight_is_wide(M, I, O, ldh, lddz))
+    hipLaunchKernelGGL(grad_weight_wide_kernel, dim3((I / 256) * (O / 256) * ksplit), dim3(512), WNBUF * 2 * WOPER, st, M, I, O,
+                       (const __bf16*)H, ldh, (const __bf16*)dZ, lddz, ksplit, slabs, ldc, bias_slabs);
+  else
   hipLaunchKernelGGL(grad_weight_kernel, dim3(tiles * ksplit), dim3(256), lds, st, M, I, O, (const __bf16*)H, ldh,
                      (const __bf16*)dZ, lddz, ksplit, slabs, ldc, bias_slabs);
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ksplit, slabs, scale, out);

@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MIP360_HIP_LIB') or os.path.join(_HERE, 'libmip360_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
 _fp = C.c_void_p
 _fpp = C.POINTER(C.c_void_p)
@@ -37,6 +37,7 @@ SYMBOLS = {
                                 _fpp, _fp, C.c_float, _fpp, _fpp]),
     'mip360_linear_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, _fp,
                                      C.c_int, _fp, C.c_int, _fp, C.c_int]),
+    'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                           C.c_float, _fp]),
     'mip360_grad_bias_bf16': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_float]),
@@ -405,14 +406,15 @@ class TrainableMLP(object):
 def _grad_weight(h, dz, n_in, n_out, out, scratch, bias_out=None):
     """d kernel = H^T dZ into `out` [n_in, n_out]; bias_out [n_out] = column sums of dZ from the same pass."""
     m = h.shape[0]
-    tiles = ((n_in + 127) // 128) * ((n_out + 127) // 128)
-    ksplit = int(max(1, min(64, (256 + tiles - 1) // tiles, (m + 31) // 32)))
+    ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    tile = lib().mip360_grad_weight_tile(m, n_in, n_out, ld(h), ld(dz))
+    tiles = ((n_in + tile - 1) // tile) * ((n_out + tile - 1) // tile)
+    ksplit = int(max(1, min(256 if tile == 256 else 64, (256 + tiles - 1) // tiles, (m + 31) // 32)))
     if ksplit >= 8 or m >= 8 * 256:
         ksplit = max(8, (ksplit // 8) * 8)            # multiples of 8: one or more whole row slices per XCD
     need = ksplit * (n_in * n_out + n_out)
     if scratch[0] is None or scratch[0].numel() < need:
         scratch[0] = torch.empty(need, device=h.device)
-    ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
     _check(lib().mip360_grad_weight_bf16(_stream(), m, n_in, n_out, _p(h), ld(h), _p(dz), ld(dz), ksplit, _p(scratch[0]), _p(out),
                                          n_out, 1.0, _p(bias_out)), 'mip360_grad_weight_bf16')
 

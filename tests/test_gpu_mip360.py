@@ -310,7 +310,8 @@ def test_model_forward_matches_oracle(M):
 
 
 # ---------------------------------------------------------------------------------------------------- training side
-@pytest.mark.parametrize('m,n_in,n_out,ldz', [(1000, 512, 1024, 1024), (777, 128, 3, 32), (4096, 1536, 256, 288), (300, 256, 1, 32)])
+@pytest.mark.parametrize('m,n_in,n_out,ldz', [(1000, 512, 1024, 1024), (777, 128, 3, 32), (4096, 1536, 256, 288), (300, 256, 1, 32),
+                                               (8192, 1024, 1024, 1024), (2080, 256, 512, 512)])
 def test_grad_weight_and_bias_against_numpy(M, m, n_in, n_out, ldz):
     """dK = H^T dZ (split-K MFMA with transposed LDS reads) and db = column sums, bf16 operands, float32 result."""
     rs = np.random.RandomState(m)
