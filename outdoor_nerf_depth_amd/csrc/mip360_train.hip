@@ -273,13 +273,42 @@ __global__ __launch_bounds__(512) void grad_weight_wide_kernel(int M, int I, int
   }
 }
 
-// out[e] = scale * sum_s slabs[s][e], fixed order
-__global__ void slab_sum_kernel(int64_t n, int ksplit, const float* __restrict__ slabs, float scale, float* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float acc = 0.f;
-  for (int s = 0; s < ksplit; ++s) acc += slabs[(size_t)s * n + e];
-  out[e] = acc * scale;
+// out[e] = scale * sum_s slabs[s][e] in a fixed order: a thread sums every 4th slab (group g: s = g, g + 4, ...) for 4
+// consecutive elements, the 4 group sums are added in group order through LDS.  (One thread per element over all
+// slabs has too few loads in flight: 64 MB of slabs took 64 us.)
+__global__ __launch_bounds__(256) void slab_sum_kernel(int64_t n, int ksplit, const float* __restrict__ slabs, float scale,
+                                                       float* __restrict__ out) {
+  __shared__ float4 part[4][64];
+  const int t = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t e = ((int64_t)blockIdx.x * 64 + t) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < n) {
+    if ((n & 3) == 0) {
+      for (int s_ = g; s_ < ksplit; s_ += 4) {
+        const float4 v = *(const float4*)(slabs + (size_t)s_ * n + e);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    } else {
+      for (int s_ = g; s_ < ksplit; s_ += 4) {
+        const float* p = slabs + (size_t)s_ * n + e;
+        acc.x += p[0];
+        if (e + 1 < n) acc.y += p[1];
+        if (e + 2 < n) acc.z += p[2];
+        if (e + 3 < n) acc.w += p[3];
+      }
+    }
+  }
+  part[g][t] = acc;
+  __syncthreads();
+  if (g == 0 && e < n) {
+    float4 r = part[0][t];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { r.x += part[k][t].x; r.y += part[k][t].y; r.z += part[k][t].z; r.w += part[k][t].w; }
+    out[e] = r.x * scale;
+    if (e + 1 < n) out[e + 1] = r.y * scale;
+    if (e + 2 < n) out[e + 2] = r.z * scale;
+    if (e + 3 < n) out[e + 3] = r.w * scale;
+  }
 }
 
 // bias gradients: partial[slice][o] = sum over the slice's rows of dZ[m][o]
