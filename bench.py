@@ -65,6 +65,7 @@ def parse():
     p.add_argument('--precision', choices=['both', 'bf16', 'split'], default='both')
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--large_batch', type=int, default=8192, help='also report this N_rand (0 = skip)')
+    p.add_argument('--mip360_rays', type=int, default=4096, help='also time the MipNeRF-360 step (config 5) at this many rays (0 = skip)')
     # BASELINE.json configs[1] by default (gt / mse / 0.1); configs[2] = mono_crop / kl, configs[3] = stereo_crop / l1
     p.add_argument('--depth_sup_type', default='gt')
     p.add_argument('--depth_loss_type', default='mse', choices=['mse', 'l1', 'kl'])
@@ -336,6 +337,10 @@ def main():
         out['large_batch'] = {'n_rand_per_gpu': a2.n_rand, 'value': r2['value'], 'unit': 'rays/s',
                               'ms_per_step': r2['ms_per_step'], 'steps': a2.steps,
                               'note': 'same workload at a larger ray batch than the 1024 of the reference (labelled, not the headline)'}
+    if world == 1 and args.mip360_rays > 0:
+        # BASELINE configs[4], labelled extra: the MipNeRF-360 step on its own library (libmip360_hip.so)
+        from outdoor_nerf_depth_amd import mip360
+        out['config5_mip360'] = mip360.benchmark_step(device, args.mip360_rays, steps=5, warmup=2)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

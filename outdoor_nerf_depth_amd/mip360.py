@@ -605,3 +605,55 @@ class Mip360Trainer(object):
         self.prop.grads.copy_(acc)
         self.apply_gradients()
         return sc
+
+
+# ------------------------------------------------------------------------------------------------- measurement
+def mlp_shapes(cfg):
+    """(fan_in, fan_out) of every dense layer of MLP.__call__ (models.py:436-606) for a PROP_CFG / NERF_CFG dict."""
+    W, D = cfg['net_width'], cfg['net_depth']
+    out, dim = [], 504
+    for i in range(D):
+        out.append((dim, W))
+        dim = W + (504 if (i % SKIP_LAYER == 0 and i > 0) else 0)
+    out.append((dim, 1))
+    if not cfg['disable_rgb']:
+        out += [(dim, BOTTLENECK), (BOTTLENECK + DIR_DIM, VIEW_WIDTH), (VIEW_WIDTH, 3)]
+    return out
+
+
+def benchmark_step(device, n_rays=4096, steps=10, warmup=3, forward_only=False, seed=0):
+    """configs/360.gin shape on synthetic rays (2 x 64 proposal samples through the 4 x 256 PropMLP, 32 samples through the
+    8 x 1024 NerfMLP, he_uniform weights): whole training steps (forward, losses, backward, clip, Adam, re-pack) or
+    forwards only.  Dense-layer FLOP per ray (forward) = 2 * (2 * 64 * prop MACs + 32 * nerf MACs); training = 3x."""
+    import time
+    rs = np.random.RandomState(seed)
+    he = lambda shapes: [(rs.uniform(-np.sqrt(6.0 / i), np.sqrt(6.0 / i), (i, o)).astype(np.float32), np.zeros(o, np.float32))
+                         for i, o in shapes]
+    prop, nerf = he(mlp_shapes(PROP_CFG)), he(mlp_shapes(NERF_CFG))
+    n = n_rays
+    d = rs.randn(n, 3).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    T = lambda x: torch.from_numpy(x).to(device)
+    rays = dict(origins=T((rs.randn(n, 3) * 0.3).astype(np.float32)), directions=T(d), viewdirs=T(d.copy()),
+                radii=T(np.full((n, 1), 2e-3, np.float32)), near=T(np.full((n, 1), 0.2, np.float32)),
+                far=T(np.full((n, 1), 1e6, np.float32)))
+    gt = T(rs.rand(n, 3).astype(np.float32))
+    sup = T(np.where(rs.rand(n) < .5, rs.uniform(1, 6, n), 0).astype(np.float32))
+    tr = Mip360Trainer(prop, nerf, device)
+    macs = lambda sh: sum(i * o for i, o in sh)
+    fwd_flop = 2.0 * (2 * 64 * macs(mlp_shapes(PROP_CFG)) + 32 * macs(mlp_shapes(NERF_CFG)))
+    step = (lambda: tr.forward(rays, 0.5, None)) if forward_only else (lambda: tr.train_step(rays, gt, sup))
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    flop = fwd_flop * (1 if forward_only else 3) * n
+    return {'workload': 'MipNeRF-360 configs/360.gin shape, %d rays/step, %s, depth_loss_type=mse on distance_mean, synthetic rays'
+                        % (n, 'forward' if forward_only else 'train step'),
+            'value': n / dt, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt, 'steps': steps, 'dense_tflops': flop / dt / 1e12,
+            'frac_of_bf16_mfma_peak': flop / dt / 2.5e15, 'fwd_gflop_per_ray': fwd_flop / 1e9,
+            'dtype': 'bf16 MFMA operands, f32 accumulate / f32 master weights'}

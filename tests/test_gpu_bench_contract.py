@@ -16,7 +16,7 @@ def test_bench_json_contract():
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1',
-                          '--n_rand', '128', '--large_batch', '256', '--cpu_rays', '8'], capture_output=True, text=True,
+                          '--n_rand', '128', '--large_batch', '256', '--cpu_rays', '8', '--mip360_rays', '256'], capture_output=True, text=True,
                          timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
@@ -36,3 +36,4 @@ def test_bench_json_contract():
     cb = r['cpu_baseline']
     assert cb['kind'] == 'port' and cb['unit'] == 'rays/s' and cb['value'] > 0 and cb['cores'] >= 1 and cb['sample']
     assert r['parity_mode']['value'] > 0 and r['large_batch']['n_rand_per_gpu'] == 256
+    assert r['config5_mip360']['value'] > 0 and r['config5_mip360']['unit'] == 'rays/s'
