@@ -342,6 +342,27 @@ int nerfpp_loss(void* stream, int n_rays, int n_samples, int loss_type, float la
 
 }  // extern "C"
 
+// weight-gradient GEMMs of both nets (two launches) over the tensors the forward / dX kernels saved
+static void weight_grads(hipStream_t st, const nerfpp_backward_args* a, const WsLayout& L) {
+  char* ws = (char*)a->workspace;
+  DwArgs dw{};
+  for (int net = 0; net < N_NET; ++net) {
+    dw.ws[net] = make_netws(ws, L, net);
+    dw.slabs[net] = (float*)(ws + L.slabs[net]);
+  }
+  dw.rows = L.rows;
+  dw.rows_padded = L.rows_padded;
+  dw.plan = dw_plan(L.rows);
+  if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
+  launch_dw(st, a->precision, dw);
+  if (a->ev_dw_end) (void)hipEventRecord((hipEvent_t)a->ev_dw_end, st);
+}
+// experiment (NERFPP_DEFER_DW=1): with defer_reduce the weight-gradient GEMMs move to the deferred half as well
+static bool defer_dw() {
+  static const bool on = getenv("NERFPP_DEFER_DW") != nullptr;
+  return on;
+}
+
 // split-K slabs -> flat gradient (fixed summation order, x grad_scale), then the derived remap / colour-head gradients
 static void reduce_grads(hipStream_t st, const nerfpp_backward_args* a, const WsLayout& L, const TblLayout& T) {
   char* ws = (char*)a->workspace;
@@ -369,7 +390,9 @@ int nerfpp_level_reduce_grads(void* stream, const nerfpp_backward_args* a) {
   REQUIRE(a->workspace && a->tables && a->grads && a->params, "workspace / tables / grads / params");
   const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
   REQUIRE(prec_ok(WP) && WP >= a->precision, "workspace_precision must be 0, or >= precision");
-  reduce_grads((hipStream_t)stream, a, ws_layout(a->n_rays, a->n_samples, WP, true), tbl_layout());
+  const WsLayout L = ws_layout(a->n_rays, a->n_samples, WP, true);
+  if (defer_dw()) weight_grads((hipStream_t)stream, a, L);
+  reduce_grads((hipStream_t)stream, a, L, tbl_layout());
   return check_launch("level_reduce_grads");
 }
 
@@ -392,7 +415,6 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
                        (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
                        a->fg_z, a->bg_z, a->g_rgb, a->g_depth, a->g_fg_weights, (float*)(ws + L.d_out[0]),
                        (float*)(ws + L.d_out[1]));
-  DwArgs dw{};
   SideStream* side = side_stream();
   for (int net = 0; net < N_NET; ++net) {
     MlpBwdArgs m{};
@@ -407,15 +429,8 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
     launch_mlp_bwd(side && net == 1 ? side->s : st, net, P, m);
     if (side && net == 1) { (void)hipEventRecord(side->join, side->s); (void)hipStreamWaitEvent(st, side->join, 0); }
     if (net == N_NET - 1 && a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);
-    dw.ws[net] = m.ws;
-    dw.slabs[net] = (float*)(ws + L.slabs[net]);
   }
-  dw.rows = L.rows;
-  dw.rows_padded = L.rows_padded;
-  dw.plan = dw_plan(L.rows);
-  if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
-  launch_dw(st, P, dw);
-  if (a->ev_dw_end) (void)hipEventRecord((hipEvent_t)a->ev_dw_end, st);
+  if (!(a->defer_reduce && defer_dw())) weight_grads(st, a, L);
   if (!a->defer_reduce) reduce_grads(st, a, L, T);
   return check_launch("level_backward");
 }

@@ -525,6 +525,8 @@ class Mip360Trainer(object):
         self.max_steps, self.lambda_depth, self.depth_loss_type = max_steps, lambda_depth, depth_loss_type
         self.world_size, self.grad_max_norm, self.adam_eps = world_size, grad_max_norm, adam_eps
         self.step = 0
+        self.overlap_update = True
+        self._update_stream = torch.cuda.Stream(device=self.device)
         self.scratch = [None, None]
         self.partials = torch.empty(2, 256, device=self.device)
         self.clip = torch.empty(2, 2, device=self.device)
@@ -559,24 +561,28 @@ class Mip360Trainer(object):
             levels.append(dict(sdist=sdist, tdist=tdist, density=density, rgb_s=rgb_s, saved=saved, rows=rows, ns=ns, **r))
         return levels
 
-    def apply_gradients(self):
-        """train_utils.py:340-364 on the flat gradient buffers of both MLPs: mean over ranks (jax.lax.pmean; SUM
-        all-reduce over RCCL, then / world_size), per-MLP global-norm clipping, Adam with the log-decayed learning
-        rate, re-pack of the bf16 weight copies."""
+    def _apply_one(self, k, tm):
+        """train_utils.py:340-364 on the flat gradient buffer of one MLP: mean over ranks (jax.lax.pmean; SUM all-reduce
+        over RCCL, then / world_size), global-norm clipping (per MLP), Adam with the log-decayed learning rate, re-pack
+        of the bf16 weight copies."""
         lr = learning_rate(self.step, max_steps=self.max_steps)
         L = lib()
-        for k, tm in enumerate((self.nerf, self.prop)):
-            if self.world_size > 1:
-                import torch.distributed as dist
-                dist.all_reduce(tm.grads)
-                tm.grads.div_(self.world_size)
-            n = tm.grads.numel()
-            _check(L.mip360_sum_squares(_stream(), n, _p(tm.grads), _p(self.partials[k]), 256), 'mip360_sum_squares')
-            _check(L.mip360_clip_multiplier(_stream(), 256, _p(self.partials[k]), float(self.grad_max_norm), _p(self.clip[k])),
-                   'mip360_clip_multiplier')
-            _check(L.mip360_adam_step(_stream(), n, _p(tm.flat), _p(tm.grads), _p(tm.mu), _p(tm.nu), _p(self.clip[k]), self.step,
-                                      lr, 0.9, 0.999, self.adam_eps), 'mip360_adam_step')
-            tm.repack()
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(tm.grads)
+            tm.grads.div_(self.world_size)
+        n = tm.grads.numel()
+        _check(L.mip360_sum_squares(_stream(), n, _p(tm.grads), _p(self.partials[k]), 256), 'mip360_sum_squares')
+        _check(L.mip360_clip_multiplier(_stream(), 256, _p(self.partials[k]), float(self.grad_max_norm), _p(self.clip[k])),
+               'mip360_clip_multiplier')
+        _check(L.mip360_adam_step(_stream(), n, _p(tm.flat), _p(tm.grads), _p(tm.mu), _p(tm.nu), _p(self.clip[k]), self.step,
+                                  lr, 0.9, 0.999, self.adam_eps), 'mip360_adam_step')
+        tm.repack()
+
+    def apply_gradients(self):
+        """Both MLPs, on the caller's stream (NerfMLP first, like the pmean order of the step)."""
+        self._apply_one(0, self.nerf)
+        self._apply_one(1, self.prop)
 
     def train_step(self, rays, rgb_gt, depth_sup, jitter01=None):
         """rays / rgb_gt [n,3] / depth_sup [n] on the device.  Returns the scalars tensor of mip360_losses."""
@@ -595,6 +601,17 @@ class Mip360Trainer(object):
         gd, grgbs = render_level_backward(nerf['density'], nerf['rgb_s'], nerf['tdist'], rays['directions'], g_wn, g_rgb, g_dm,
                                           True, self.cfg['bg_rgb'])
         mlp_backward(self.nerf, nerf['saved'], nerf['rows'], gd, grgbs, self.scratch)
+        # the NerfMLP's update (all-reduce, norm, clip, Adam, 12 re-pack launches: 0.2 ms of short kernels) runs on a
+        # side stream under the proposal levels' backward GEMMs; joined at the end of the step
+        side = self._update_stream if self.overlap_update else None
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self._apply_one(0, self.nerf)
+                done = torch.cuda.Event()
+                done.record()
         # proposal levels share the PropMLP: gradients add up
         acc = None
         for k, p in enumerate(props):
@@ -603,7 +620,11 @@ class Mip360Trainer(object):
             mlp_backward(self.prop, p['saved'], p['rows'], gd, None, self.scratch)
             acc = self.prop.grads.clone() if acc is None else acc.add_(self.prop.grads)
         self.prop.grads.copy_(acc)
-        self.apply_gradients()
+        if side is not None:
+            self._apply_one(1, self.prop)
+            torch.cuda.current_stream().wait_event(done)
+        else:
+            self.apply_gradients()
         return sc
 
 

@@ -512,6 +512,7 @@ def _dp_run_and_check(M, tmp_path, backend):
             t.nerf.repack(); t.prop.repack()
             t.step = main.step
             apply = t.apply_gradients
+            t.overlap_update = False                                    # (the overlapped path calls _apply_one itself)
             t.apply_gradients = lambda: None                            # gradients only
             t.train_step({k: T(v) for k, v in rays.items()}, T(gt), T(sup), jitter01=[T(j) for j in jit])
             t.apply_gradients = apply
