@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MIP360_ABI_VERSION 2
+#define MIP360_ABI_VERSION 3
 #define MIP360_OK 0
 #define MIP360_ERR_ARG 1
 #define MIP360_ERR_HIP 2
@@ -110,6 +110,21 @@ int mip360_losses(void* stream, int n_rays, int s_nerf, int s_prop, int n_prop, 
 int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
                        const float* bias, int act, float act_param, void* c_bf16, int ldc, float* c_f32,
                        int ldc32, const void* aux, int ldaux);
+
+/* The same layer with its ReLU pattern kept as one BIT per element instead of being re-derived from the saved bf16
+ * output in the backward pass (jax.grad of nn.relu: the cotangent is passed where the output is > 0).
+ *   mip360_linear_relu_mask_bf16 : C = relu(A W^T + b) as bf16, and mask byte [(n >> 3) * ldmask + m], bit (n & 7) =
+ *                                  (C[m][n] > 0) -- column-byte-major, so that the 16 consecutive rows a thread of the
+ *                                  GEMM epilogue owns are 16 consecutive bytes.
+ *   mip360_linear_masked_bf16    : C = (A W^T) with the elements whose mask bit is clear set to zero: the dX chain
+ *                                  dZ_l = (dZ_{l+1} K_{l+1}^T) * relu'(H_l) reading 1/16 of the bytes act 4 reads
+ *                                  (the 16 mask bytes of a thread are fetched ahead of its K loop).
+ * The mask buffer holds mip360_relu_mask_bytes(m, n, &ldmask) bytes; ldmask = m rounded up to 256. */
+int64_t mip360_relu_mask_bytes(int m, int n, int* ldmask);
+int mip360_linear_relu_mask_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
+                                 const float* bias, void* c_bf16, int ldc, void* mask, int ldmask);
+int mip360_linear_masked_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
+                              void* c_bf16, int ldc, const void* mask, int ldmask);
 
 /* ---- training side (upstream: jax.value_and_grad + optax, train_utils.py:215-236, 303-370) ---------------------- */
 

@@ -23,7 +23,8 @@ void mip360_launch_losses(hipStream_t st, int n, int s_nerf, int s_prop, int n_p
                           float* const* g_w_prop, float* ws, float prop_depth_weight, const float* const* dm_prop,
                           float* const* g_dm_prop);
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
-                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux);
+                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux,
+                          void* mask, int ldmask);
 bool mip360_grad_weight_is_wide(int M, int I, int O, int ldh, int lddz);
 void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
                                float* slabs, float* out, int ldc, float scale, float* bias_out);
@@ -139,8 +140,41 @@ int mip360_linear_bf16(void* stream, int m, int n, int k, const void* a, int lda
   REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k, "leading dimensions: multiples of 8, >= k");
   REQUIRE(act >= 0 && act <= 4, "act in 0..4");
   REQUIRE(act != 4 || (aux && ldaux >= n), "act 4 needs the mask tensor");
-  mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, bias, act, act_param, c_bf16, ldc, c_f32, ldc32, aux, ldaux);
+  mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, bias, act, act_param, c_bf16, ldc, c_f32, ldc32, aux, ldaux,
+                       nullptr, 0);
   return check_launch("linear_bf16");
+}
+
+static bool mask_args_ok(int m, int n, const void* mask, int ldmask) {
+  return mask && ldmask % 16 == 0 && ldmask >= (m + 255) / 256 * 256 && n > 0;
+}
+
+int64_t mip360_relu_mask_bytes(int m, int n, int* ldmask) {
+  if (m <= 0 || n <= 0) return 0;
+  const int ld = (m + 255) / 256 * 256;
+  if (ldmask) *ldmask = ld;
+  return (int64_t)((n + 255) / 256 * 32) * ld;
+}
+
+int mip360_linear_relu_mask_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
+                                 const float* bias, void* c_bf16, int ldc, void* mask, int ldmask) {
+  REQUIRE(m > 0 && n > 0 && k > 0 && k % 32 == 0, "k must be a positive multiple of 32");
+  REQUIRE(a && w && c_bf16, "non-null operands and output");
+  REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k && ldc >= n, "leading dimensions: multiples of 8, >= k / n");
+  REQUIRE(mask_args_ok(m, n, mask, ldmask), "mask buffer: ldmask = roundup(m, 256) (mip360_relu_mask_bytes)");
+  mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, bias, 5, 0.f, c_bf16, ldc, nullptr, 0, nullptr, 0, mask, ldmask);
+  return check_launch("linear_relu_mask_bf16");
+}
+
+int mip360_linear_masked_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw, void* c_bf16,
+                              int ldc, const void* mask, int ldmask) {
+  REQUIRE(m > 0 && n > 0 && k > 0 && k % 32 == 0, "k must be a positive multiple of 32");
+  REQUIRE(a && w && c_bf16, "non-null operands and output");
+  REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k && ldc >= n, "leading dimensions: multiples of 8, >= k / n");
+  REQUIRE(mask_args_ok(m, n, mask, ldmask), "mask buffer: ldmask = roundup(m, 256) (mip360_relu_mask_bytes)");
+  mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, nullptr, 6, 0.f, c_bf16, ldc, nullptr, 0, nullptr, 0,
+                       (void*)mask, ldmask);
+  return check_launch("linear_masked_bf16");
 }
 
 int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz, int lddz,

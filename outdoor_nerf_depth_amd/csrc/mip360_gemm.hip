@@ -163,9 +163,12 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
                                                                const __bf16* __restrict__ W, int ldw,
                                                                const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc,
                                                                float* __restrict__ C32, int ldc32, float act_param,
-                                                               const __bf16* __restrict__ aux, int ldaux) {
+                                                               const __bf16* __restrict__ aux, int ldaux,
+                                                               uint8_t* __restrict__ mask, int ldmask) {
   static_assert(WM * FM * 32 == RT && WN * FN * 32 == RT, "256 x 256 tile");
   constexpr int NW = WM * WN, NT = NW * 64, QD = 16 / NW;        // QD: DMA instructions per operand per wave per stage
+  constexpr int IT = 8192 / NT;                                  // output rows per thread in the bf16 epilogue
+  static_assert(IT % 16 == 0, "mask words: whole 16-byte groups per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (N + RT - 1) / RT, tiles_m = (M + RT - 1) / RT;
@@ -203,6 +206,20 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
 #pragma unroll
     for (int q = 0; q < 2 * QD; ++q) glds16_asm(gsrc[q] + (size_t)kt * RBK * 2, lds0 + slot + ldst[q]);
   };
+  // ReLU bit mask (ACT 5 writes it, ACT 6 applies it), column-byte-major: byte [(n >> 3) * ldmask + m], bit n & 7 =
+  // (C[m][n] > 0).  In the bf16 epilogue a thread owns columns [8 piece, 8 piece + 8) of IT consecutive rows, i.e. IT
+  // consecutive mask bytes: ACT 6 fetches them here, ahead of the K loop (IT / 4 registers), ACT 5 stores them at the end.
+  uint32_t mw[IT / 4];
+  uint8_t* const mask_at = mask + (size_t)((n0 >> 3) + (tid & 31)) * ldmask + m0 + (tid >> 5) * IT;
+#pragma unroll
+  for (int q = 0; q < IT / 4; ++q) mw[q] = 0u;
+  if (ACT == 6) {
+#pragma unroll
+    for (int q = 0; q < IT / 16; ++q) {
+      const uint4 t = *(const uint4*)(mask_at + 16 * q);
+      mw[4 * q] = t.x; mw[4 * q + 1] = t.y; mw[4 * q + 2] = t.z; mw[4 * q + 3] = t.w;
+    }
+  }
   f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
   }
   const int hi = lane >> 5;
   auto activate = [&](float v) {
-    if (ACT == 1) v = fmaxf(v, 0.f);
+    if (ACT == 1 || ACT == 5) v = fmaxf(v, 0.f);
     if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
     if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
     return v;
@@ -308,35 +325,60 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
   {
     const __bf16* tile = (const __bf16*)ring_smem;
     const bool vec_ok = ((ldc & 7) == 0) && (ACT != 4 || (ldaux & 7) == 0);
-#pragma unroll 4
-    for (int it = 0; it < 8192 / NT; ++it) {
-      const int c = it * NT + tid, ml = c >> 5, piece = c & 31;           // 32 pieces of 8 columns per row
-      const int m = m0 + ml, n = n0 + piece * 8;
-      if (m >= M || n >= N) continue;
-      uint4 v = *(const uint4*)(tile + ml * 256 + ((piece * 8 + 8 * ml) & 255));
-      if (vec_ok && n + 8 <= N) {
-        if (ACT == 4) {
-          const uint4 a4 = *(const uint4*)(aux + (size_t)m * ldaux + n);
-          const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
-          uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+    const int piece = tid & 31, n = n0 + piece * 8;                    // 32 pieces of 8 columns per row
+#pragma unroll
+    for (int q = 0; q < IT / 4; ++q) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ml = (tid >> 5) * IT + 4 * q + b, m = m0 + ml;
+        if (m >= M || n >= N) continue;
+        uint4 v = *(const uint4*)(tile + ml * 256 + ((piece * 8 + 8 * ml) & 255));
+        if (ACT == 5) {                                                // bit k: bf16 k is > 0 (sign clear, magnitude non-zero)
+          const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+          uint32_t bits = 0u;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            // keep a bf16 where the saved activation is > 0: positive sign and non-zero magnitude
-            const uint32_t lo = ((aw[k] & 0x8000u) == 0 && (aw[k] & 0x7FFFu) != 0) ? 0x0000FFFFu : 0u;
-            const uint32_t hi16 = ((aw[k] & 0x80000000u) == 0 && (aw[k] & 0x7FFF0000u) != 0) ? 0xFFFF0000u : 0u;
-            vw[k] &= (lo | hi16);
+            bits |= (((vw[k] & 0x8000u) == 0 && (vw[k] & 0x7FFFu) != 0) ? 1u : 0u) << (2 * k);
+            bits |= (((vw[k] & 0x80000000u) == 0 && (vw[k] & 0x7FFF0000u) != 0) ? 1u : 0u) << (2 * k + 1);
           }
+          mw[q] |= bits << (8 * b);
+        }
+        if (ACT == 6) {
+          const uint32_t bits = mw[q] >> (8 * b);
+          uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            vw[k] &= ((0u - ((bits >> (2 * k)) & 1u)) & 0x0000FFFFu) | ((0u - ((bits >> (2 * k + 1)) & 1u)) & 0xFFFF0000u);
           v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
         }
-        *(uint4*)(C16 + (size_t)m * ldc + n) = v;
-      } else {
-        const __bf16* pv = (const __bf16*)&v;
-        for (int k = 0; k < 8 && n + k < N; ++k) {
-          float x = (float)pv[k];
-          if (ACT == 4) x = (float)aux[(size_t)m * ldaux + n + k] > 0.f ? x : 0.f;
-          C16[(size_t)m * ldc + n + k] = (__bf16)x;
+        if (vec_ok && n + 8 <= N) {
+          if (ACT == 4) {
+            const uint4 a4 = *(const uint4*)(aux + (size_t)m * ldaux + n);
+            const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
+            uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              // keep a bf16 where the saved activation is > 0: positive sign and non-zero magnitude
+              const uint32_t lo = ((aw[k] & 0x8000u) == 0 && (aw[k] & 0x7FFFu) != 0) ? 0x0000FFFFu : 0u;
+              const uint32_t hi16 = ((aw[k] & 0x80000000u) == 0 && (aw[k] & 0x7FFF0000u) != 0) ? 0xFFFF0000u : 0u;
+              vw[k] &= (lo | hi16);
+            }
+            v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+          }
+          *(uint4*)(C16 + (size_t)m * ldc + n) = v;
+        } else {
+          const __bf16* pv = (const __bf16*)&v;
+          for (int k = 0; k < 8 && n + k < N; ++k) {
+            float x = (float)pv[k];
+            if (ACT == 4) x = (float)aux[(size_t)m * ldaux + n + k] > 0.f ? x : 0.f;
+            C16[(size_t)m * ldc + n + k] = (__bf16)x;
+          }
         }
       }
+    }
+    if (ACT == 5) {
+#pragma unroll
+      for (int q = 0; q < IT / 16; ++q) *(uint4*)(mask_at + 16 * q) = make_uint4(mw[4 * q], mw[4 * q + 1], mw[4 * q + 2], mw[4 * q + 3]);
     }
   }
 }
@@ -345,35 +387,50 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
 
 template <int ACT>
 static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
-                            float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux) {
+                            float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux, void* mask,
+                            int ldmask) {
   using namespace mip360;
   static const bool force_small = getenv("MIP360_GEMM_SMALL") != nullptr;
   static const bool no_ring = getenv("MIP360_GEMM_NORING") != nullptr;
   static const bool four_waves = getenv("MIP360_GEMM_4WAVES") != nullptr;
-  if (N >= 192 && M >= 256 && !force_small && !no_ring) {
+  constexpr bool MASKED = ACT == 5 || ACT == 6;                 // bit-mask variants exist in the ring kernel only
+  if (MASKED || (N >= 192 && M >= 256 && !force_small && !no_ring)) {
     const int tiles = ((M + RT - 1) / RT) * ((N + RT - 1) / RT);
-    if (four_waves)
+    if (four_waves && !MASKED)
       hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, 2, 2, 4, 4>), dim3(tiles), dim3(256), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A,
-                         lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+                         lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux,
+                         (uint8_t*)mask, ldmask);
     else
-    hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, 2, 4, 4, 2>), dim3(tiles), dim3(512), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A, lda,
-                       (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
-  } else if (N >= 192 && M >= 256 && !force_small) {
-    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    hipLaunchKernelGGL((linear_bf16_kernel<ACT, 2, 4, 4, 2>), dim3(tiles), dim3(512), 0, st, M, N, K, (const __bf16*)A, lda,
-                       (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
-  } else {
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    hipLaunchKernelGGL((linear_bf16_kernel<ACT, 2, 2, 2, 2>), dim3(tiles), dim3(256), 0, st, M, N, K, (const __bf16*)A, lda,
-                       (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+      hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, 2, 4, 4, 2>), dim3(tiles), dim3(512), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A,
+                         lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux,
+                         (uint8_t*)mask, ldmask);
+  } else if constexpr (!MASKED) {
+    if (N >= 192 && M >= 256 && !force_small) {
+      const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+      hipLaunchKernelGGL((linear_bf16_kernel<ACT, 2, 4, 4, 2>), dim3(tiles), dim3(512), 0, st, M, N, K, (const __bf16*)A, lda,
+                         (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+    } else {
+      const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+      hipLaunchKernelGGL((linear_bf16_kernel<ACT, 2, 2, 2, 2>), dim3(tiles), dim3(256), 0, st, M, N, K, (const __bf16*)A, lda,
+                         (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux);
+    }
   }
 }
 
+// act 5: ReLU + its bit mask written to `mask`; act 6: output multiplied by the bits of `mask` (mip360_hip.h)
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
-                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux) {
-  if (act == 1) launch_linear_t<1>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
-  else if (act == 2) launch_linear_t<2>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
-  else if (act == 3) launch_linear_t<3>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
-  else if (act == 4) launch_linear_t<4>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
-  else launch_linear_t<0>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux);
+                          int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux,
+                          void* mask, int ldmask) {
+  static const bool exp_nomask = getenv("MIP360_EXP_NOMASK") != nullptr;       // timing experiment: dX without its ReLU mask
+  if (exp_nomask && (act == 4 || act == 6)) act = 0;
+#define MIP360_LINEAR_CASE(ACT_) \
+  launch_linear_t<ACT_>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux, mask, ldmask)
+  if (act == 1) MIP360_LINEAR_CASE(1);
+  else if (act == 2) MIP360_LINEAR_CASE(2);
+  else if (act == 3) MIP360_LINEAR_CASE(3);
+  else if (act == 4) MIP360_LINEAR_CASE(4);
+  else if (act == 5) MIP360_LINEAR_CASE(5);
+  else if (act == 6) MIP360_LINEAR_CASE(6);
+  else MIP360_LINEAR_CASE(0);
+#undef MIP360_LINEAR_CASE
 }

@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MIP360_HIP_LIB') or os.path.join(_HERE, 'libmip360_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
 _fp = C.c_void_p
 _fpp = C.POINTER(C.c_void_p)
@@ -37,6 +37,10 @@ SYMBOLS = {
                                 _fpp, _fp, C.c_float, _fpp, _fpp]),
     'mip360_linear_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, _fp,
                                      C.c_int, _fp, C.c_int, _fp, C.c_int]),
+    'mip360_relu_mask_bytes': (C.c_int64, [C.c_int, C.c_int, _fp]),
+    'mip360_linear_relu_mask_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp,
+                                               C.c_int]),
+    'mip360_linear_masked_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                           C.c_float, _fp]),
@@ -149,6 +153,33 @@ def linear(a, w, bias, act=0, act_param=0.0, out_bf16=None, out_f32=None, m=None
     ld = lambda t: 0 if t is None else (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))   # size-1 dims have free strides
     _check(lib().mip360_linear_bf16(_stream(), m, n, k, _p(a), ld(a), _p(w), ld(w), _p(bias), int(act), float(act_param),
                                     _p(out_bf16), ld(out_bf16), _p(out_f32), ld(out_f32), _p(aux), ld(aux)), 'mip360_linear_bf16')
+
+
+def relu_mask_buffer(m, n, device):
+    """(uint8 buffer, ldmask) for the ReLU bit mask of an [m, n] layer output (include/mip360_hip.h)."""
+    ld = C.c_int(0)
+    nbytes = lib().mip360_relu_mask_bytes(int(m), int(n), C.byref(ld))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), ld.value
+
+
+def linear_relu_mask(a, w, bias, out_bf16, mask, ldmask, m=None, n=None, k=None):
+    """relu(A W^T + b) -> out_bf16, bit (out > 0) -> mask."""
+    m = a.shape[0] if m is None else m
+    n = w.shape[0] if n is None else n
+    k = w.shape[1] if k is None else k
+    ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    _check(lib().mip360_linear_relu_mask_bf16(_stream(), m, n, k, _p(a), ld(a), _p(w), ld(w), _p(bias), _p(out_bf16), ld(out_bf16),
+                                              _p(mask), int(ldmask)), 'mip360_linear_relu_mask_bf16')
+
+
+def linear_masked(a, w, out_bf16, mask, ldmask, m=None, n=None, k=None):
+    """(A W^T) * mask bits -> out_bf16: one step of the dX chain."""
+    m = a.shape[0] if m is None else m
+    n = w.shape[0] if n is None else n
+    k = w.shape[1] if k is None else k
+    ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    _check(lib().mip360_linear_masked_bf16(_stream(), m, n, k, _p(a), ld(a), _p(w), ld(w), _p(out_bf16), ld(out_bf16), _p(mask),
+                                           int(ldmask)), 'mip360_linear_masked_bf16')
 
 
 def render_level(density, rgb_samples, tdist, directions, opaque_background=True, bg_rgb=1.0):
@@ -435,14 +466,16 @@ def mlp_forward_train(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
     dev = enc_buf.device
     bf = lambda c: torch.empty(rows, c, dtype=torch.bfloat16, device=dev)
     enc = enc_buf[:, W:]
-    saved = dict(enc_buf=enc_buf, H=[], inputs=[])
+    saved = dict(enc_buf=enc_buf, H=[], inputs=[], masks=[])
     x, x_k = enc, IPE_LD
     for i in range(D):
         skip_out = (i % SKIP_LAYER == 0 and i > 0)
         out = enc_buf[:, :W] if skip_out else bf(W)
-        linear(x, tm.w[i], tm.b[i], act=1, out_bf16=out, m=rows, n=W, k=x_k)
+        mask = relu_mask_buffer(rows, W, dev)                          # 1 bit per element for the dX chain
+        linear_relu_mask(x, tm.w[i], tm.b[i], out, mask[0], mask[1], m=rows, n=W, k=x_k)
         saved['inputs'].append((x, x_k))
         saved['H'].append(out)
+        saved['masks'].append(mask)
         x, x_k = (enc_buf, W + IPE_LD) if skip_out else (out, W)
     saved['trunk'] = (x, x_k)
     density = torch.empty(rows, 1, device=dev)
@@ -491,7 +524,7 @@ def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch):
     _grad_weight(trunk, d_raw, trunk_k, 1, tm.kernel(D, G), scratch, tm.bias(D, G))
     # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
     dz = bf(W)
-    linear(heads, tm.wb['heads'], None, act=4, out_bf16=dz, m=rows, n=W, k=tm.head_k, aux=saved['H'][D - 1])
+    linear_masked(heads, tm.wb['heads'], dz, *saved['masks'][D - 1], m=rows, n=W, k=tm.head_k)
     for i in reversed(range(D)):
         x, x_k = saved['inputs'][i]
         if x_k == tm.shapes[i][0]:
@@ -502,7 +535,7 @@ def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch):
             tm.kernel(i, G).copy_(gk[:tm.shapes[i][0]])
         if i > 0:
             nxt = bf(W)
-            linear(dz, tm.wb[i], None, act=4, out_bf16=nxt, m=rows, n=W, k=W, aux=saved['H'][i - 1])
+            linear_masked(dz, tm.wb[i], nxt, *saved['masks'][i - 1], m=rows, n=W, k=W)
             dz = nxt
 
 

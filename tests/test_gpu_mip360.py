@@ -139,6 +139,38 @@ def test_linear_bf16_against_numpy(M, m, n, k):
     np.testing.assert_allclose(N(o32), ref - b, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('m,n,k', [(1000, 320, 64), (512, 1024, 1024), (77, 256, 32)])
+def test_linear_relu_bit_mask_equals_the_saved_activation_path(M, m, n, k):
+    """mip360_linear_relu_mask_bf16 / mip360_linear_masked_bf16 (one bit per element) against act 1 / act 4 (mask re-derived
+    from the saved bf16 output): identical bf16 results bit for bit, mask bits = (output > 0); ragged M and N tiles."""
+    rs = np.random.RandomState(m + n + k)
+    ta = T(round_bf16(rs.randn(m, k).astype(np.float32))).to(torch.bfloat16)
+    tw = T(round_bf16((rs.randn(n, k) / np.sqrt(k)).astype(np.float32))).to(torch.bfloat16)
+    b = T(rs.randn(n).astype(np.float32) * 0.3)
+    h_ref = torch.empty(m, n, dtype=torch.bfloat16, device=dev())
+    M.linear(ta, tw, b, act=1, out_bf16=h_ref)
+    h = torch.zeros(m, n, dtype=torch.bfloat16, device=dev())
+    mask, ld = M.relu_mask_buffer(m, n, dev())
+    mask.zero_()
+    M.linear_relu_mask(ta, tw, b, h, mask, ld)
+    assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16))
+    bits = N(mask).reshape(-1, ld)[:(n + 7) // 8, :m]                       # [column byte, row]
+    want = np.zeros(((n + 7) // 8 * 8, m), np.uint8)
+    want[:n] = (N(h_ref.float()) > 0).T
+    want = np.packbits(want.reshape(-1, 8, m), axis=1, bitorder='little')[:, 0]
+    np.testing.assert_array_equal(bits, want)
+    # dX step: dz [m, kk] times a [n, kk] transposed kernel, masked by this layer's pattern
+    kk = 96
+    dz = T(round_bf16(rs.randn(m, kk).astype(np.float32))).to(torch.bfloat16)
+    wb = T(round_bf16(rs.randn(n, kk).astype(np.float32))).to(torch.bfloat16)
+    want16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev())
+    M.linear(dz, wb, None, act=4, out_bf16=want16, aux=h_ref)
+    got16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev())
+    M.linear_masked(dz, wb, got16, mask, ld)
+    assert torch.equal((got16.float() + 0.0).view(torch.int32), (want16.float() + 0.0).view(torch.int32))    # -0 == +0
+    assert float((got16 != 0).float().mean()) > 0.2
+
+
 def _mlp_bf16_reference(params, cfg, enc504, viewdirs_rows):
     """MLP.__call__ with every dense layer's operands rounded to bfloat16 (what the matrix cores see), float64 sums."""
     c = dict(O.MLP_DEFAULTS, **cfg)
