@@ -145,8 +145,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void linear_bf16_kernel(int M, int 
 // different 16-byte slots of the 256-byte bank line (conflict-free) without padding.
 // Rows beyond M / N are clamped to the last valid row on the load side (their results are never stored).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int RT = 256, RBK = 32, RNBUF = 4;
-constexpr int RSTAGE = 2 * RT * RBK * 2;            // bytes per stage: A tile + B tile = 32 KiB
+constexpr int RBK = 32;
 extern __shared__ __attribute__((aligned(16))) char ring_smem[];
 
 __device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
@@ -156,111 +155,36 @@ __device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
                : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 
-// WM x WN waves, each owning FM x FN MFMA blocks: (2, 4, 4, 2) = 8 waves of 128 x 64, two per SIMD;
-// (2, 2, 4, 4) = 4 waves of 128 x 128, one per SIMD with the whole register file (8 fragment reads feed 16 MFMAs)
-template <int ACT, int WM, int WN, int FM, int FN>
-__global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda,
-                                                               const __bf16* __restrict__ W, int ldw,
-                                                               const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc,
-                                                               float* __restrict__ C32, int ldc32, float act_param,
-                                                               const __bf16* __restrict__ aux, int ldaux,
-                                                               uint8_t* __restrict__ mask, int ldmask) {
-  static_assert(WM * FM * 32 == RT && WN * FN * 32 == RT, "256 x 256 tile");
-  constexpr int NW = WM * WN, NT = NW * 64, QD = 16 / NW;        // QD: DMA instructions per operand per wave per stage
-  constexpr int IT = 8192 / NT;                                  // output rows per thread in the bf16 epilogue
-  static_assert(IT % 16 == 0, "mask words: whole 16-byte groups per thread");
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int tiles_n = (N + RT - 1) / RT, tiles_m = (M + RT - 1) / RT;
-  int tile_m, tile_n;
-  {                                                           // XCD-aware order, see linear_bf16_kernel
-    const int b = blockIdx.x, xcd = b & 7, id = b >> 3;
-    const int full = (tiles_m / 8) * 8;
-    const int group = id / tiles_n;
-    if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
-    else { const int r = b - full * tiles_n; tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n; }
-  }
-  const int m0 = tile_m * RT, n0 = tile_n * RT;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_smem;
-  // DMA lane map: instruction q of this wave covers tile rows [16 * (wave * QD + q % QD) ... + 16) of operand q / QD
-  const int drow = lane >> 2, dpos = lane & 3;
-  const char* gsrc[2 * QD];
-  uint32_t ldst[2 * QD];
-#pragma unroll
-  for (int q = 0; q < 2 * QD; ++q) {
-    const int op = q / QD, row = 16 * (wave * QD + q % QD) + drow;
-    const int chunk = dpos ^ ((row >> 2) & 3);
-    if (op == 0) {
-      int m = m0 + row; m = m < M ? m : M - 1;
-      gsrc[q] = (const char*)(A + (size_t)m * lda + chunk * 8);
-    } else {
-      int n = n0 + row; n = n < N ? n : N - 1;
-      gsrc[q] = (const char*)(W + (size_t)n * ldw + chunk * 8);
-    }
-    ldst[q] = (uint32_t)(op * RT * RBK * 2 + 16 * (wave * QD + q % QD) * 64);      // + slot * RSTAGE, + lane * 16 by the hardware
-  }
-  const int nk = K / RBK;
-  auto issue = [&](int kt) {
-    if (kt >= nk) return;
-    const uint32_t slot = (uint32_t)(kt % RNBUF) * RSTAGE;
-#pragma unroll
-    for (int q = 0; q < 2 * QD; ++q) glds16_asm(gsrc[q] + (size_t)kt * RBK * 2, lds0 + slot + ldst[q]);
-  };
-  // ReLU bit mask (ACT 5 writes it, ACT 6 applies it), column-byte-major: byte [(n >> 3) * ldmask + m], bit n & 7 =
-  // (C[m][n] > 0).  In the bf16 epilogue a thread owns columns [8 piece, 8 piece + 8) of IT consecutive rows, i.e. IT
-  // consecutive mask bytes: ACT 6 fetches them here, ahead of the K loop (IT / 4 registers), ACT 5 stores them at the end.
-  uint32_t mw[IT / 4];
-  uint8_t* const mask_at = mask + (size_t)((n0 >> 3) + (tid & 31)) * ldmask + m0 + (tid >> 5) * IT;
-#pragma unroll
-  for (int q = 0; q < IT / 4; ++q) mw[q] = 0u;
-  if (ACT == 6) {
-#pragma unroll
-    for (int q = 0; q < IT / 16; ++q) {
-      const uint4 t = *(const uint4*)(mask_at + 16 * q);
-      mw[4 * q] = t.x; mw[4 * q + 1] = t.y; mw[4 * q + 2] = t.z; mw[4 * q + 3] = t.w;
-    }
-  }
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-  for (int s_ = 0; s_ < RNBUF - 1; ++s_) issue(s_);
-  // fragment read: row R = block row + (lane & 31), k chunk c = 2 ks + (lane >> 5) -> position c ^ ((R >> 2) & 3)
-  const int frow = lane & 31, fkh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int younger = nk - 1 - kt < RNBUF - 2 ? nk - 1 - kt : RNBUF - 2;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * QD) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QD) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(kt + RNBUF - 1);
-    const char* st = ring_smem + (kt % RNBUF) * RSTAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[FM], fb[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int R = wm * FM * 32 + i * 32 + frow;
-        fa[i] = *(const bf16x8*)(st + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int R = wn * FN * 32 + j * 32 + frow;
-        fb[j] = *(const bf16x8*)(st + RT * RBK * 2 + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        // operands swapped (W fragment as "A"): the accumulator block is C^T, i.e. lane (l & 31) holds ROW m of the
-        // tile and register r column (r & 3) + 8 (r >> 2) + 4 (l >> 5) -- four consecutive columns per register
-        // quad, which the epilogue packs into one 8-byte LDS write
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-  }
+// WM x WN waves, each owning FM x FN MFMA blocks of 32 x 32; NBUF ring stages of (BM + BN) rows x 64 bytes:
+//   (2, 4, 4, 2, 4) = 8 waves of 128 x 64 on a 256 x 256 tile, 128 KiB ring, one workgroup per CU
+//   (2, 2, 4, 2, 3) = 4 waves of 128 x 64 on a 256 x 128 tile,  72 KiB ring, TWO workgroups per CU: while one of them
+//                     drains its tile (epilogue) or primes its ring (prologue) the other one keeps the matrix pipe busy
+//   (2, 2, 4, 4, 4) = 4 waves of 128 x 128, one per SIMD with the whole register file (measured slower, kept for probes)
+template <int WM, int WN, int FM, int FN, int NBUF>
+struct RingCfg {
+  static constexpr int NW = WM * WN, NT = NW * 64, BM = WM * FM * 32, BN = WN * FN * 32;
+  static constexpr int STAGE = (BM + BN) * RBK * 2;             // bytes per stage
+  static constexpr int QW = (BM + BN) / 16 / NW;                // DMA instructions (16 rows x 64 B = 1 KiB) per wave per stage
+  static constexpr int PIECES = BN / 8;                         // 16-byte pieces per output row
+  static constexpr int IT = BM * PIECES / NT;                   // output rows per thread in the bf16 epilogue
+  static constexpr int LDS = NBUF * STAGE > BM * BN * 2 ? NBUF * STAGE : BM * BN * 2;
+  static_assert((BM + BN) / 16 % NW == 0, "DMA instructions divide among the waves");
+  static_assert(IT % 16 == 0 && NT % PIECES == 0, "mask words: whole 16-byte groups per thread");
+  static_assert(NBUF >= 3 && NBUF <= 5, "ring depth");
+};
+
+// Epilogue shared by the ring kernels: bias + activation on the accumulators (lane l & 31 = tile row, register r = column
+// (r & 3) + 8 (r >> 2) + 4 (l >> 5) of a 32 x 32 block), float32 outputs stored directly, bf16 outputs staged through the
+// (idle) ring memory and written as 16 bytes per lane; ReLU masks applied / emitted on the way out.
+template <int ACT, int WM, int WN, int FM, int FN, class Cfg>
+__device__ __forceinline__ void ring_epilogue(f32x16 (&acc)[FM][FN], uint32_t (&mw)[Cfg::IT / 4], uint8_t* const mask_at, const int tid,
+                                              const int wm, const int wn, const int m0, const int n0, const int M, const int N,
+                                              const float* __restrict__ bias, __bf16* __restrict__ C16, const int ldc,
+                                              float* __restrict__ C32, const int ldc32, const float act_param,
+                                              const __bf16* __restrict__ aux, const int ldaux) {
+  constexpr int BN = Cfg::BN, IT = Cfg::IT, PIECES = Cfg::PIECES;
+  const int lane = tid & 63, frow = lane & 31;
+  const int piece = tid % PIECES, rgroup = tid / PIECES;
   const int hi = lane >> 5;
   auto activate = [&](float v) {
     if (ACT == 1 || ACT == 5) v = fmaxf(v, 0.f);
@@ -287,10 +211,9 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
     }
     return;
   }
-  // bf16 output.  The ring is idle now, so the tile is staged through it ([256][256] bf16 = its 128 KiB, rows rotated by
-  // 16 bytes per row against bank conflicts; 8-byte writes: a register quad is 4 consecutive columns of one row) and
-  // leaves as 16 bytes per lane = whole 512-byte rows per 32 lanes; the ReLU mask (ACT 4) is applied on the way out
-  // from equally coalesced 16-byte loads of the saved activation.
+  // bf16 output.  The ring is idle now, so the tile is staged through it ([BM][BN] bf16, rows rotated by 16 bytes per row
+  // against bank conflicts; 8-byte writes: a register quad is 4 consecutive columns of one row) and leaves as 16 bytes per
+  // lane = whole row segments per PIECES lanes; the ReLU mask (ACT 4 / 6) is applied on the way out.
   __builtin_amdgcn_s_barrier();
   {
     __bf16* tile = (__bf16*)ring_smem;
@@ -315,7 +238,7 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
           uint2 pk;
           pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
           pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
-          *(uint2*)(tile + ml * 256 + ((nl + 8 * ml) & 255)) = pk;
+          *(uint2*)(tile + ml * BN + ((nl + 8 * ml) & (BN - 1))) = pk;
         }
       }
     }
@@ -325,14 +248,14 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
   {
     const __bf16* tile = (const __bf16*)ring_smem;
     const bool vec_ok = ((ldc & 7) == 0) && (ACT != 4 || (ldaux & 7) == 0);
-    const int piece = tid & 31, n = n0 + piece * 8;                    // 32 pieces of 8 columns per row
+    const int n = n0 + piece * 8;
 #pragma unroll
     for (int q = 0; q < IT / 4; ++q) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int ml = (tid >> 5) * IT + 4 * q + b, m = m0 + ml;
+        const int ml = rgroup * IT + 4 * q + b, m = m0 + ml;
         if (m >= M || n >= N) continue;
-        uint4 v = *(const uint4*)(tile + ml * 256 + ((piece * 8 + 8 * ml) & 255));
+        uint4 v = *(const uint4*)(tile + ml * BN + ((piece * 8 + 8 * ml) & (BN - 1)));
         if (ACT == 5) {                                                // bit k: bf16 k is > 0 (sign clear, magnitude non-zero)
           const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
           uint32_t bits = 0u;
@@ -383,7 +306,360 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_bf16_ring_kernel(int M, i
   }
 }
 
+template <int ACT, int WM, int WN, int FM, int FN, int NBUF>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && NBUF == 3) ? 2 : 1)
+void linear_bf16_ring_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ W, int ldw,
+                             const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc, float* __restrict__ C32, int ldc32,
+                             float act_param, const __bf16* __restrict__ aux, int ldaux, uint8_t* __restrict__ mask, int ldmask) {
+  using Cfg = RingCfg<WM, WN, FM, FN, NBUF>;
+  constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, STAGE = Cfg::STAGE, QW = Cfg::QW, PIECES = Cfg::PIECES, IT = Cfg::IT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  int tile_m, tile_n;
+  {                                                           // XCD-aware order, see linear_bf16_kernel
+    const int b = blockIdx.x, xcd = b & 7, id = b >> 3;
+    const int full = (tiles_m / 8) * 8;
+    const int group = id / tiles_n;
+    if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
+    else { const int r = b - full * tiles_n; tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n; }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_smem;
+  // DMA lane map: instruction q of this wave covers stage rows [16 g, 16 g + 16), g = wave * QW + q; stage rows
+  // [0, BM) are the A tile, [BM, BM + BN) the W tile
+  const int drow = lane >> 2, dpos = lane & 3;
+  const char* gsrc[QW];
+  uint32_t ldst[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const int srow = 16 * (wave * QW + q) + drow;
+    const int chunk = dpos ^ ((srow >> 2) & 3);               // (BM is a multiple of 16: the swizzle of a W row is that of its tile row)
+    if (srow < BM) {
+      int m = m0 + srow; m = m < M ? m : M - 1;
+      gsrc[q] = (const char*)(A + (size_t)m * lda + chunk * 8);
+    } else {
+      int n = n0 + srow - BM; n = n < N ? n : N - 1;
+      gsrc[q] = (const char*)(W + (size_t)n * ldw + chunk * 8);
+    }
+    ldst[q] = (uint32_t)(16 * (wave * QW + q) * 64);          // + slot * STAGE, + lane * 16 by the hardware
+  }
+  const int nk = K / RBK;
+  auto issue = [&](int kt) {
+    if (kt >= nk) return;
+#ifdef MIP360_EXP_NODMA
+    if (kt >= NBUF) return;
+#endif
+    const uint32_t slot = (uint32_t)(kt % NBUF) * STAGE;
+#pragma unroll
+    for (int q = 0; q < QW; ++q) glds16_asm(gsrc[q] + (size_t)kt * RBK * 2, lds0 + slot + ldst[q]);
+  };
+  // ReLU bit mask (ACT 5 writes it, ACT 6 applies it), column-byte-major: byte [(n >> 3) * ldmask + m], bit n & 7 =
+  // (C[m][n] > 0).  In the bf16 epilogue a thread owns columns [8 piece, 8 piece + 8) of IT consecutive rows, i.e. IT
+  // consecutive mask bytes: ACT 6 fetches them here, ahead of the K loop (IT / 4 registers), ACT 5 stores them at the end.
+  const int piece = tid % PIECES, rgroup = tid / PIECES;
+  uint32_t mw[IT / 4];
+  uint8_t* const mask_at = mask + (size_t)((n0 >> 3) + piece) * ldmask + m0 + rgroup * IT;
+#pragma unroll
+  for (int q = 0; q < IT / 4; ++q) mw[q] = 0u;
+  if (ACT == 6) {
+#pragma unroll
+    for (int q = 0; q < IT / 16; ++q) {
+      const uint4 t = *(const uint4*)(mask_at + 16 * q);
+      mw[4 * q] = t.x; mw[4 * q + 1] = t.y; mw[4 * q + 2] = t.z; mw[4 * q + 3] = t.w;
+    }
+  }
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int s_ = 0; s_ < NBUF - 1; ++s_) issue(s_);
+  // fragment read: row R = block row + (lane & 31), k chunk c = 2 ks + (lane >> 5) -> position c ^ ((R >> 2) & 3)
+  const int frow = lane & 31, fkh = lane >> 5;
+  auto read_frags = [&](const char* st, int ks, bf16x8 (&fa)[FM], bf16x8 (&fb)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int R = wm * FM * 32 + i * 32 + frow;
+      fa[i] = *(const bf16x8*)(st + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int R = wn * FN * 32 + j * 32 + frow;
+      fb[j] = *(const bf16x8*)(st + BM * RBK * 2 + R * 64 + (((2 * ks + fkh) ^ ((R >> 2) & 3)) << 4));
+    }
+  };
+  // operands swapped (W fragment as "A"): the accumulator block is C^T, i.e. lane (l & 31) holds ROW m of the tile and
+  // register r column (r & 3) + 8 (r >> 2) + 4 (l >> 5) -- four consecutive columns per register quad, which the
+  // epilogue packs into one 8-byte LDS write
+  auto multiply = [&](const bf16x8 (&fa)[FM], const bf16x8 (&fb)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  };
+  auto wait_stages = [&](int younger) {                       // all but the `younger` most recent stages of this wave have landed
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * QW) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QW) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_stages(nk - 1 - kt < NBUF - 2 ? nk - 1 - kt : NBUF - 2);
+    __builtin_amdgcn_s_barrier();
+    issue(kt + NBUF - 1);
+    const char* st = ring_smem + (kt % NBUF) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[FM], fb[FN];
+      read_frags(st, ks, fa, fb);
+      multiply(fa, fb);
+    }
+  }
+  ring_epilogue<ACT, WM, WN, FM, FN, Cfg>(acc, mw, mask_at, tid, wm, wn, m0, n0, M, N, bias, C16, ldc, C32, ldc32, act_param, aux, ldaux);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong kernel for K % 64 == 0 (every wide layer of both MLPs except the 288-column head GEMM).
+//
+// What the lock-step ring kernel above is bound by (profiles/r02_g_*): (1) its DMA instructions fetch 16 rows x 64 bytes,
+// i.e. HALF cache lines -- the CU's texture path then delivers 80 GB/s instead of 136 GB/s with whole lines
+// (tools/probes/dma_pattern_probe.hip), 0.41 us per 32 KiB K step against 0.63 us of MFMA work; (2) both waves of a SIMD
+// leave the barrier together, issue DMA and LDS reads together and queue their MFMAs together, so those times add up
+// instead of overlapping (1.02 us per step; matrix pipe busy 35 % of the cycles).  Here
+//   * a stage is 64 k-elements = one 128-byte line per row (32 KiB per operand); the A ring is 3 deep (its rows come from
+//     HBM), the W ring 2 deep (L2-resident): 160 KiB; a DMA instruction covers 8 rows x 128 B;
+//     the 16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7, which keeps ds_read_b128 conflict-free with
+//     128-byte rows;
+//   * the eight waves form two groups of four (one wave of each group per SIMD) that run half a step apart: while one
+//     group is in its 16-MFMA burst the other one issues its DMA and reads its next 12 fragments from LDS
+//     (MI355X_MICROARCH.md, "Two waves per SIMD"), a barrier after every phase.  With h = half step (32 k-elements):
+//         P0(h): group 0 multiplies h                        | group 1 [h even: DMA W rows of stage h/2 + 1] reads h
+//         P1(h): group 0 [h odd: DMA A rows of stage (h+3)/2] | group 1 multiplies h
+//                reads h + 1
+//     group 0 streams the A rows (HBM latency: issued two half steps ahead), group 1 the W rows (L2-resident: one and
+//     a half); every wave waits for its own part of stage s + 1 (vmcnt(0)) at the end of P0(2 s + 1);
+//   * LDS reads are inline asm with an explicit lgkmcnt wait (complete before the wave passes the barrier that lets
+//     the other group's DMA overwrite the slot).
+// ------------------------------------------------------------------------------------------------------------
+struct PP64Cfg {
+  static constexpr int NW = 8, NT = 512, BM = 256, BN = 256, BK = 64;
+  static constexpr int HALF = BM * BK * 2;                      // one operand's stage: 256 rows x 128 B = 32 KiB
+  static constexpr int NA = 3, NB = 2;                          // A ring (HBM latency) 3 deep, W ring (L2-resident) 2 deep
+  static constexpr int PIECES = BN / 8, IT = BM * PIECES / NT;  // epilogue: 32 pieces per row, 16 rows per thread
+  static constexpr int LDS = (NA + NB) * HALF;                  // 160 KiB (the bf16 output tile is staged in the first 128)
+};
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1)
+void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ W, int ldw,
+                             const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc, float* __restrict__ C32, int ldc32,
+                             float act_param, const __bf16* __restrict__ aux, int ldaux, uint8_t* __restrict__ mask, int ldmask) {
+  using Cfg = PP64Cfg;
+  constexpr int WM = 2, WN = 4, FM = 4, FN = 2, BM = Cfg::BM, BN = Cfg::BN, HALF = Cfg::HALF, NA = Cfg::NA, IT = Cfg::IT,
+                PIECES = Cfg::PIECES;
+  constexpr uint32_t WBASE = NA * HALF;                         // the W ring sits behind the A ring
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN, grp = wm;           // group 0 = waves 0-3 = tile rows 0-127
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  int tile_m, tile_n;
+  {                                                           // XCD-aware order, see linear_bf16_kernel
+    const int b = blockIdx.x, xcd = b & 7, id = b >> 3;
+    const int full = (tiles_m / 8) * 8;
+    const int group = id / tiles_n;
+    if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
+    else { const int r = b - full * tiles_n; tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n; }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_smem;
+  // DMA: wave w of group g covers rows [64 w', 64 w' + 64) (w' = w & 3) of operand g (0: A, 1: W) with 8 instructions of
+  // 8 rows x 128 B; lane l -> row l >> 3, position l & 7 holding chunk (l & 7) ^ ((row >> 1) & 7)
+  const char* gsrc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = 64 * (wave & 3) + 8 * q + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if (grp == 0) {
+      int m = m0 + row; m = m < M ? m : M - 1;
+      gsrc[q] = (const char*)(A + (size_t)m * lda + chunk * 8);
+    } else {
+      int n = n0 + row; n = n < N ? n : N - 1;
+      gsrc[q] = (const char*)(W + (size_t)n * ldw + chunk * 8);
+    }
+  }
+  const uint32_t ldst = lds0 + (uint32_t)(grp * WBASE + 64 * (wave & 3) * 128);        // + slot * HALF + q * 1024
+  const int ns = K / 64;                                        // stages
+  auto issue = [&](int st, uint32_t slot_bytes) {               // this wave's 8 KiB of stage st
+    if (st >= ns) return;
+#ifdef MIP360_EXP_NODMA
+    if (st >= 3) return;
+#endif
+#ifdef MIP360_EXP_NODMA_A
+    if (st >= 3 && grp == 0) return;
+#endif
+#ifdef MIP360_EXP_NODMA_W
+    if (st >= 3 && grp == 1) return;
+#endif
+    const uint32_t dst = ldst + slot_bytes;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) glds16_asm(gsrc[q] + (size_t)st * 128, dst + q * 1024);
+  };
+  // ReLU bit mask words of this thread's 16 output rows (see linear_bf16_ring_kernel)
+  const int piece = tid % PIECES, rgroup = tid / PIECES;
+  uint32_t mw[IT / 4];
+  uint8_t* const mask_at = mask + (size_t)((n0 >> 3) + piece) * ldmask + m0 + rgroup * IT;
+#pragma unroll
+  for (int q = 0; q < IT / 4; ++q) mw[q] = 0u;
+  if (ACT == 6) {
+    const uint4 t = *(const uint4*)mask_at;
+    mw[0] = t.x; mw[1] = t.y; mw[2] = t.z; mw[3] = t.w;         // (older than every DMA: loads return in order)
+  }
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // fragment addresses: row R = block row + (lane & 31); chunk c = 4 hh + 2 ks + (lane >> 5) at position c ^ ((R >> 1) & 7)
+  const int frow = lane & 31, fkh = lane >> 5, sw = (frow >> 1) & 7;
+  uint32_t offA[4], offB[4];
+#pragma unroll
+  for (int c2 = 0; c2 < 4; ++c2) {
+    offA[c2] = lds0 + (uint32_t)((wm * 128 + frow) * 128 + (((2 * c2 + fkh) ^ sw) << 4));
+    offB[c2] = lds0 + WBASE + (uint32_t)((wn * 64 + frow) * 128 + (((2 * c2 + fkh) ^ sw) << 4));
+  }
+  bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+#ifdef MIP360_EXP_NOLDS
+#define PP64_READ6(fa, fb, pa, pb) {}
+#else
+#define PP64_READ6(fa, fb, pa, pb)                                                                                     \
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:4096\n\tds_read_b128 %2, %6 offset:8192\n\t"         \
+               "ds_read_b128 %3, %6 offset:12288\n\tds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:4096"            \
+               : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fa[2]), "=&v"(fa[3]), "=&v"(fb[0]), "=&v"(fb[1])                    \
+               : "v"(pa), "v"(pb) : "memory");
+#endif
+  // fragments of one half step (A slot / W slot byte offsets sa_ / sb_, half HH): the 12 reads are issued first, then DMA_
+  // (this wave's share of a later stage: its issue time overlaps the reads' latency), then the wait
+#define PP64_LOAD(sa_, sb_, HH, DMA_)                                                                                  \
+  {                                                                                                                    \
+    PP64_READ6(fa0, fb0, offA[2 * (HH)] + (sa_), offB[2 * (HH)] + (sb_));                                              \
+    PP64_READ6(fa1, fb1, offA[2 * (HH) + 1] + (sa_), offB[2 * (HH) + 1] + (sb_));                                      \
+    DMA_;                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                \
+                 : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fa1[0]),    \
+                   "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fb1[0]), "+v"(fb1[1]) :: "memory");                  \
+  }
+#ifdef MIP360_EXP_NOMFMA
+#define PP64_MULTIPLY() {}
+#else
+#define PP64_MULTIPLY()                                                                                                \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                                     \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);                       \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                                     \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                       \
+  }
+#endif
+#define PP64_PHASE_END()                                                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_barrier();
+  // ring positions as byte offsets (A: 3 slots, W: 2 slots), advanced once per stage
+  uint32_t sa = 0, sb = 0;                                      // slots of the current stage
+  auto next_a = [&](uint32_t x) { return x == (NA - 1) * HALF ? 0u : x + HALF; };
+  // one loop per group (straight-line bodies); both execute the same sequence of barriers
+  if (grp == 0) {
+    issue(0, 0);
+    issue(1, HALF);
+    issue(2, 2 * HALF);
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // stage 0
+    else if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    PP64_LOAD(0u, 0u, 0, (void)0);
+    PP64_PHASE_END();
+    for (int st = 0; st < ns; ++st) {
+      const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;        // slots of stage st + 1
+      PP64_MULTIPLY();                                          // P0(2 st)
+      PP64_PHASE_END();
+      PP64_LOAD(sa, sb, 1, (void)0);                            // P1(2 st)
+      PP64_PHASE_END();
+      PP64_MULTIPLY();                                          // P0(2 st + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   //   own A rows of stage st + 1 (stage st + 2 may be out)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP64_PHASE_END();
+      // P1(2 st + 1): the A slot of stage st is free -> stage st + 3; fragments of (st + 1, half 0) (last stage: a harmless re-read)
+      if (st + 1 < ns) { PP64_LOAD(sa1, sb1, 0, issue(st + 3, sa)); } else { PP64_LOAD(sa, sb, 0, (void)0); }
+      PP64_PHASE_END();
+      sa = sa1; sb = sb1;
+    }
+  } else {
+    issue(0, 0);
+    issue(1, HALF);
+    if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // stage 0
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    PP64_PHASE_END();
+    for (int st = 0; st < ns; ++st) {
+      const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;
+      PP64_LOAD(sa, sb, 0, if (st >= 1) issue(st + 1, sb1));    // P0(2 st): the W slot of stage st - 1 is free -> stage st + 1
+      PP64_PHASE_END();
+      PP64_MULTIPLY();                                          // P1(2 st)
+      PP64_PHASE_END();
+      PP64_LOAD(sa, sb, 1, (void)0);                            // P0(2 st + 1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          //   own W rows of stage st + 1
+      PP64_PHASE_END();
+      PP64_MULTIPLY();                                          // P1(2 st + 1)
+      PP64_PHASE_END();
+      sa = sa1; sb = sb1;
+    }
+  }
+#undef PP64_READ6
+#undef PP64_LOAD
+#undef PP64_MULTIPLY
+#undef PP64_PHASE_END
+  ring_epilogue<ACT, WM, WN, FM, FN, Cfg>(acc, mw, mask_at, tid, wm, wn, m0, n0, M, N, bias, C16, ldc, C32, ldc32, act_param, aux, ldaux);
+}
+
 }  // namespace mip360
+
+template <int ACT, int WM, int WN, int FM, int FN, int NBUF>
+static void launch_ring(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
+                        float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux, void* mask, int ldmask) {
+  using namespace mip360;
+  using Cfg = RingCfg<WM, WN, FM, FN, NBUF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)linear_bf16_ring_kernel<ACT, WM, WN, FM, FN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              Cfg::LDS);
+    attr_set = true;
+  }
+  const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
+  hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, WM, WN, FM, FN, NBUF>), dim3(tiles), dim3(Cfg::NT), Cfg::LDS, st, M, N, K,
+                     (const __bf16*)A, lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux,
+                     ldaux, (uint8_t*)mask, ldmask);
+}
+
+template <int ACT>
+static void launch_pp64(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
+                        float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux, void* mask, int ldmask) {
+  using namespace mip360;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)linear_bf16_pp64_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PP64Cfg::LDS);
+    attr_set = true;
+  }
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  hipLaunchKernelGGL((linear_bf16_pp64_kernel<ACT>), dim3(tiles), dim3(512), PP64Cfg::LDS, st, M, N, K, (const __bf16*)A, lda,
+                     (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux, (uint8_t*)mask,
+                     ldmask);
+}
 
 template <int ACT>
 static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
@@ -392,18 +668,15 @@ static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, 
   using namespace mip360;
   static const bool force_small = getenv("MIP360_GEMM_SMALL") != nullptr;
   static const bool no_ring = getenv("MIP360_GEMM_NORING") != nullptr;
-  static const bool four_waves = getenv("MIP360_GEMM_4WAVES") != nullptr;
-  constexpr bool MASKED = ACT == 5 || ACT == 6;                 // bit-mask variants exist in the ring kernel only
+  static const char* ring_env = getenv("MIP360_GEMM_RING");     // probes: 1 = lock-step ring kernel everywhere, 4 = 4-wave 256 x 128
+  static const int ring_kind = ring_env ? atoi(ring_env) : 0;
+  constexpr bool MASKED = ACT == 5 || ACT == 6;                 // bit-mask variants exist in the ring kernels only
   if (MASKED || (N >= 192 && M >= 256 && !force_small && !no_ring)) {
-    const int tiles = ((M + RT - 1) / RT) * ((N + RT - 1) / RT);
-    if (four_waves && !MASKED)
-      hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, 2, 2, 4, 4>), dim3(tiles), dim3(256), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A,
-                         lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux,
-                         (uint8_t*)mask, ldmask);
-    else
-      hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, 2, 4, 4, 2>), dim3(tiles), dim3(512), RNBUF * RSTAGE, st, M, N, K, (const __bf16*)A,
-                         lda, (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux,
-                         (uint8_t*)mask, ldmask);
+#define MIP360_RING(...) launch_ring<ACT, __VA_ARGS__>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux, mask, ldmask)
+    if (ring_kind == 4) MIP360_RING(2, 2, 4, 2, 3);                  // 4 waves, 256 x 128, two workgroups per CU (measured slower)
+    else if (ring_kind == 1 || K % 64 != 0) MIP360_RING(2, 4, 4, 2, 4);
+    else launch_pp64<ACT>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux, mask, ldmask);
+#undef MIP360_RING
   } else if constexpr (!MASKED) {
     if (N >= 192 && M >= 256 && !force_small) {
       const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
