@@ -155,6 +155,17 @@ __device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
                : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (one VGPR instead of a pointer pair)
+__device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
 // WM x WN waves, each owning FM x FN MFMA blocks of 32 x 32; NBUF ring stages of (BM + BN) rows x 64 bytes:
 //   (2, 4, 4, 2, 4) = 8 waves of 128 x 64 on a 256 x 256 tile, 128 KiB ring, one workgroup per CU
 //   (2, 2, 4, 2, 3) = 4 waves of 128 x 64 on a 256 x 128 tile,  72 KiB ring, TWO workgroups per CU: while one of them
@@ -423,33 +434,38 @@ void linear_bf16_ring_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Ping-pong kernel for K % 64 == 0 (every wide layer of both MLPs except the 288-column head GEMM).
+// Persistent ping-pong kernel for K % 64 == 0 (every wide layer of both MLPs except the 288-column head GEMM).
 //
 // What the lock-step ring kernel above is bound by (profiles/r02_g_*): (1) its DMA instructions fetch 16 rows x 64 bytes,
 // i.e. HALF cache lines -- the CU's texture path then delivers 80 GB/s instead of 136 GB/s with whole lines
-// (tools/probes/dma_pattern_probe.hip), 0.41 us per 32 KiB K step against 0.63 us of MFMA work; (2) both waves of a SIMD
-// leave the barrier together, issue DMA and LDS reads together and queue their MFMAs together, so those times add up
-// instead of overlapping (1.02 us per step; matrix pipe busy 35 % of the cycles).  Here
-//   * a stage is 64 k-elements = one 128-byte line per row (32 KiB per operand); the A ring is 3 deep (its rows come from
-//     HBM), the W ring 2 deep (L2-resident): 160 KiB; a DMA instruction covers 8 rows x 128 B;
-//     the 16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7, which keeps ds_read_b128 conflict-free with
-//     128-byte rows;
+// (tools/probes/dma_pattern_probe.hip); (2) both waves of a SIMD leave the barrier together, issue DMA and LDS reads
+// together and queue their MFMAs together, so those times add up instead of overlapping (matrix pipe busy 35 % of the
+// cycles); (3) a constant of ~14 us per 256 x 256 tile (35 % of a K = 1024 tile): every CU finishes its tile at the same
+// moment, 33 MB of outputs then drain to HBM while nothing computes, and the next workgroup starts with an empty ring.
+// Here
+//   * a stage is 64 k-elements = one 128-byte line per row (32 KiB per operand); the A ring is 3 deep, the W ring 2
+//     deep: 160 KiB; a DMA instruction covers 8 rows x 128 B; the 16-byte chunks of a row are XOR-swizzled with
+//     (row >> 1) & 7, which keeps ds_read_b128 conflict-free with 128-byte rows;
 //   * the eight waves form two groups of four (one wave of each group per SIMD) that run half a step apart: while one
-//     group is in its 16-MFMA burst the other one issues its DMA and reads its next 12 fragments from LDS
-//     (MI355X_MICROARCH.md, "Two waves per SIMD"), a barrier after every phase.  With h = half step (32 k-elements):
-//         P0(h): group 0 multiplies h                        | group 1 [h even: DMA W rows of stage h/2 + 1] reads h
-//         P1(h): group 0 [h odd: DMA A rows of stage (h+3)/2] | group 1 multiplies h
-//                reads h + 1
-//     group 0 streams the A rows (HBM latency: issued two half steps ahead), group 1 the W rows (L2-resident: one and
-//     a half); every wave waits for its own part of stage s + 1 (vmcnt(0)) at the end of P0(2 s + 1);
+//     group is in its 16-MFMA burst the other one reads its next 12 fragments from LDS (MI355X_MICROARCH.md, "Two waves
+//     per SIMD"), a barrier after every phase.  With h = half step (32 k-elements), stage st = h / 2:
+//         P0(h): group 0 multiplies h                                  | group 1 reads h
+//         P1(h): group 0 reads h + 1, h even: DMA A rows of stage st + 2 | group 1 multiplies h
+//                                     h odd:  DMA W rows of stage st + 2 |
+//   * wave roles: group 0 issues ALL the DMA and is the only one that waits on vmcnt (stage st + 1 at the end of
+//     P0(2 st + 1); the barrier publishes it); group 1 issues ALL the output stores.  Stores and loads share vmcnt, so
+//     a wave that does both can wait for its loads only by also waiting for its stores; with the roles apart the
+//     stores of tile t drain under the K loop of tile t + 1;
+//   * persistent: one workgroup per CU walks its tiles (same XCD-aware order), so there is no workgroup turnover.
 //   * LDS reads are inline asm with an explicit lgkmcnt wait (complete before the wave passes the barrier that lets
-//     the other group's DMA overwrite the slot).
+//     the DMA overwrite the slot).
 // ------------------------------------------------------------------------------------------------------------
 struct PP64Cfg {
   static constexpr int NW = 8, NT = 512, BM = 256, BN = 256, BK = 64;
   static constexpr int HALF = BM * BK * 2;                      // one operand's stage: 256 rows x 128 B = 32 KiB
-  static constexpr int NA = 3, NB = 2;                          // A ring (HBM latency) 3 deep, W ring (L2-resident) 2 deep
-  static constexpr int PIECES = BN / 8, IT = BM * PIECES / NT;  // epilogue: 32 pieces per row, 16 rows per thread
+  static constexpr int NA = 3, NB = 2;                          // A ring 3 deep, W ring 2 deep
+  static constexpr int NTR = 512;                               // writer threads of the epilogue (256: group 1 only -- measured slower)
+  static constexpr int PIECES = BN / 8, IT = BM * PIECES / NTR; // epilogue: 32 pieces per row, 16 rows per writer thread
   static constexpr int LDS = (NA + NB) * HALF;                  // 160 KiB (the bf16 output tile is staged in the first 128)
 };
 
@@ -459,80 +475,25 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
                              const float* __restrict__ bias, __bf16* __restrict__ C16, int ldc, float* __restrict__ C32, int ldc32,
                              float act_param, const __bf16* __restrict__ aux, int ldaux, uint8_t* __restrict__ mask, int ldmask) {
   using Cfg = PP64Cfg;
-  constexpr int WM = 2, WN = 4, FM = 4, FN = 2, BM = Cfg::BM, BN = Cfg::BN, HALF = Cfg::HALF, NA = Cfg::NA, IT = Cfg::IT,
-                PIECES = Cfg::PIECES;
+  constexpr int WN = 4, FM = 4, FN = 2, BM = Cfg::BM, BN = Cfg::BN, HALF = Cfg::HALF, NA = Cfg::NA, IT = Cfg::IT, PIECES = Cfg::PIECES;
   constexpr uint32_t WBASE = NA * HALF;                         // the W ring sits behind the A ring
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN, grp = wm;           // group 0 = waves 0-3 = tile rows 0-127
-  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  int tile_m, tile_n;
-  {                                                           // XCD-aware order, see linear_bf16_kernel
-    const int b = blockIdx.x, xcd = b & 7, id = b >> 3;
-    const int full = (tiles_m / 8) * 8;
-    const int group = id / tiles_n;
-    if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
-    else { const int r = b - full * tiles_n; tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n; }
-  }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM, tiles = tiles_m * tiles_n;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_smem;
-  // DMA: wave w of group g covers rows [64 w', 64 w' + 64) (w' = w & 3) of operand g (0: A, 1: W) with 8 instructions of
-  // 8 rows x 128 B; lane l -> row l >> 3, position l & 7 holding chunk (l & 7) ^ ((row >> 1) & 7)
-  const char* gsrc[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int row = 64 * (wave & 3) + 8 * q + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    if (grp == 0) {
-      int m = m0 + row; m = m < M ? m : M - 1;
-      gsrc[q] = (const char*)(A + (size_t)m * lda + chunk * 8);
-    } else {
-      int n = n0 + row; n = n < N ? n : N - 1;
-      gsrc[q] = (const char*)(W + (size_t)n * ldw + chunk * 8);
-    }
-  }
-  const uint32_t ldst = lds0 + (uint32_t)(grp * WBASE + 64 * (wave & 3) * 128);        // + slot * HALF + q * 1024
   const int ns = K / 64;                                        // stages
-  auto issue = [&](int st, uint32_t slot_bytes) {               // this wave's 8 KiB of stage st
-    if (st >= ns) return;
-#ifdef MIP360_EXP_NODMA
-    if (st >= 3) return;
-#endif
-#ifdef MIP360_EXP_NODMA_A
-    if (st >= 3 && grp == 0) return;
-#endif
-#ifdef MIP360_EXP_NODMA_W
-    if (st >= 3 && grp == 1) return;
-#endif
-    const uint32_t dst = ldst + slot_bytes;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) glds16_asm(gsrc[q] + (size_t)st * 128, dst + q * 1024);
-  };
-  // ReLU bit mask words of this thread's 16 output rows (see linear_bf16_ring_kernel)
-  const int piece = tid % PIECES, rgroup = tid / PIECES;
-  uint32_t mw[IT / 4];
-  uint8_t* const mask_at = mask + (size_t)((n0 >> 3) + piece) * ldmask + m0 + rgroup * IT;
-#pragma unroll
-  for (int q = 0; q < IT / 4; ++q) mw[q] = 0u;
-  if (ACT == 6) {
-    const uint4 t = *(const uint4*)mask_at;
-    mw[0] = t.x; mw[1] = t.y; mw[2] = t.z; mw[3] = t.w;         // (older than every DMA: loads return in order)
-  }
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // fragment addresses: row R = block row + (lane & 31); chunk c = 4 hh + 2 ks + (lane >> 5) at position c ^ ((R >> 1) & 7)
-  const int frow = lane & 31, fkh = lane >> 5, sw = (frow >> 1) & 7;
+  const int frow = lane & 31, fkh = lane >> 5, hi = fkh, sw = (frow >> 1) & 7;
   uint32_t offA[4], offB[4];
 #pragma unroll
   for (int c2 = 0; c2 < 4; ++c2) {
     offA[c2] = lds0 + (uint32_t)((wm * 128 + frow) * 128 + (((2 * c2 + fkh) ^ sw) << 4));
     offB[c2] = lds0 + WBASE + (uint32_t)((wn * 64 + frow) * 128 + (((2 * c2 + fkh) ^ sw) << 4));
   }
+  // writer threads (group 1): columns [8 piece, 8 piece + 8) of rows [32 rgroup, 32 rgroup + 32) of the tile
+  const int wt = tid & (Cfg::NTR - 1), piece = wt % PIECES, rgroup = wt / PIECES;
   bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+  f32x16 acc[FM][FN];
 #ifdef MIP360_EXP_NOLDS
 #define PP64_READ6(fa, fb, pa, pb) {}
 #else
@@ -543,7 +504,7 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
                : "v"(pa), "v"(pb) : "memory");
 #endif
   // fragments of one half step (A slot / W slot byte offsets sa_ / sb_, half HH): the 12 reads are issued first, then DMA_
-  // (this wave's share of a later stage: its issue time overlaps the reads' latency), then the wait
+  // (its issue time overlaps the reads' latency), then the wait
 #define PP64_LOAD(sa_, sb_, HH, DMA_)                                                                                  \
   {                                                                                                                    \
     PP64_READ6(fa0, fb0, offA[2 * (HH)] + (sa_), offB[2 * (HH)] + (sb_));                                              \
@@ -569,62 +530,222 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
 #define PP64_PHASE_END()                                                                                               \
   __builtin_amdgcn_sched_barrier(0);                                                                                   \
   __builtin_amdgcn_s_barrier();
-  // ring positions as byte offsets (A: 3 slots, W: 2 slots), advanced once per stage
-  uint32_t sa = 0, sb = 0;                                      // slots of the current stage
   auto next_a = [&](uint32_t x) { return x == (NA - 1) * HALF ? 0u : x + HALF; };
-  // one loop per group (straight-line bodies); both execute the same sequence of barriers
-  if (grp == 0) {
-    issue(0, 0);
-    issue(1, HALF);
-    issue(2, 2 * HALF);
-    if (ns > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // stage 0
-    else if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    PP64_LOAD(0u, 0u, 0, (void)0);
-    PP64_PHASE_END();
-    for (int st = 0; st < ns; ++st) {
-      const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;        // slots of stage st + 1
-      PP64_MULTIPLY();                                          // P0(2 st)
-      PP64_PHASE_END();
-      PP64_LOAD(sa, sb, 1, (void)0);                            // P1(2 st)
-      PP64_PHASE_END();
-      PP64_MULTIPLY();                                          // P0(2 st + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      if (st + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   //   own A rows of stage st + 1 (stage st + 2 may be out)
+  auto activate = [&](float v) {
+    if (ACT == 1 || ACT == 5) v = fmaxf(v, 0.f);
+    if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+    if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
+    return v;
+  };
+
+  for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+    int tile_m, tile_n;
+    {                                                           // XCD-aware order, see linear_bf16_kernel (gridDim.x % 8 == 0 or one tile each)
+      const int xcd = vb & 7, id = vb >> 3;
+      const int full = (tiles_m / 8) * 8;
+      const int group = id / tiles_n;
+      if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
+      else { const int r = vb - full * tiles_n; tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n; }
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    uint32_t mw[IT / 4];                                        // ReLU bit mask words of a writer thread's 32 rows
+    uint8_t* const mask_at = mask + (size_t)((n0 >> 3) + piece) * ldmask + m0 + rgroup * IT;
+#pragma unroll
+    for (int q = 0; q < IT / 4; ++q) mw[q] = 0u;
+    if (ACT == 6 && (Cfg::NTR == 512 || grp == 1)) {            // (issued ahead of this tile's DMA: loads return in order)
+#pragma unroll
+      for (int q = 0; q < IT / 16; ++q) {
+        const uint4 t = *(const uint4*)(mask_at + 16 * q);
+        mw[4 * q] = t.x; mw[4 * q + 1] = t.y; mw[4 * q + 2] = t.z; mw[4 * q + 3] = t.w;
+      }
+    }
+    uint32_t sa = 0, sb = 0;                                    // ring positions (byte offsets) of the current stage
+    // one loop per group (straight-line bodies); both execute the same sequence of barriers
+    if (grp == 0) {
+      // DMA: wave w covers rows [64 w, 64 w + 64) of A and of W with 8 instructions of 8 rows x 128 B each per stage;
+      // lane l -> row l >> 3, position l & 7 holding chunk (l & 7) ^ ((row >> 1) & 7).  Whole tiles only (the launcher
+      // sends ragged shapes to the ring kernel), so a row's address is a wave-uniform base (SGPRs: tile origin, wave,
+      // instruction q, stage) plus a per-lane offset that only depends on the parity of q: 4 VGPRs for both operands.
+      uint32_t voffA[2], voffW[2];
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int chunk = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);      // ((8 q + (lane >> 3)) >> 1) & 7 with q & 1 = par
+        voffA[par] = (uint32_t)((lane >> 3) * lda * 2 + chunk * 16);
+        voffW[par] = (uint32_t)((lane >> 3) * ldw * 2 + chunk * 16);
+      }
+      const char* const baseA = (const char*)(A + (size_t)(m0 + 64 * wave) * lda);
+      const char* const baseW = (const char*)(W + (size_t)(n0 + 64 * wave) * ldw);
+      const uint32_t dstA = lds0 + (uint32_t)(64 * wave * 128), dstW = dstA + WBASE;
+      auto issue_a = [&](int st, uint32_t slot_bytes) {
+        if (st >= ns) return;
+#if defined(MIP360_EXP_NODMA)
+        if (st >= 2) return;
+#endif
+#pragma unroll
+        for (int q = 0; q < 8; ++q) glds16_saddr(baseA + (size_t)q * 8 * lda * 2 + (size_t)st * 128, voffA[q & 1], dstA + slot_bytes + q * 1024);
+      };
+      auto issue_w = [&](int st, uint32_t slot_bytes) {
+        if (st >= ns) return;
+#if defined(MIP360_EXP_NODMA)
+        if (st >= 2) return;
+#endif
+#pragma unroll
+        for (int q = 0; q < 8; ++q) glds16_saddr(baseW + (size_t)q * 8 * ldw * 2 + (size_t)st * 128, voffW[q & 1], dstW + slot_bytes + q * 1024);
+      };
+      issue_a(0, 0);
+      issue_w(0, 0);
+      issue_a(1, HALF);
+      issue_w(1, HALF);
+      if (ns > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // stage 0
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      PP64_LOAD(0u, 0u, 0, (void)0);
       PP64_PHASE_END();
-      // P1(2 st + 1): the A slot of stage st is free -> stage st + 3; fragments of (st + 1, half 0) (last stage: a harmless re-read)
-      if (st + 1 < ns) { PP64_LOAD(sa1, sb1, 0, issue(st + 3, sa)); } else { PP64_LOAD(sa, sb, 0, (void)0); }
+      for (int st = 0; st < ns; ++st) {
+        const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;      // slots of stage st + 1
+        PP64_MULTIPLY();                                        // P0(2 st)
+        PP64_PHASE_END();
+        PP64_LOAD(sa, sb, 1, issue_a(st + 2, next_a(sa1)));     // P1(2 st): the A slot of stage st - 1 is free -> stage st + 2
+        PP64_PHASE_END();
+        PP64_MULTIPLY();                                        // P0(2 st + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  //   stage st + 1 (A of stage st + 2 may be out)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP64_PHASE_END();
+        // P1(2 st + 1): the W slot of stage st is free -> stage st + 2; fragments of (st + 1, half 0) (last stage: a harmless re-read)
+        if (st + 1 < ns) { PP64_LOAD(sa1, sb1, 0, issue_w(st + 2, sb)); } else { PP64_LOAD(sa, sb, 0, (void)0); }
+        PP64_PHASE_END();
+        sa = sa1; sb = sb1;
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();
       PP64_PHASE_END();
-      sa = sa1; sb = sb1;
+      for (int st = 0; st < ns; ++st) {
+        const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;
+        PP64_LOAD(sa, sb, 0, (void)0);                          // P0(2 st)
+        PP64_PHASE_END();
+        PP64_MULTIPLY();                                        // P1(2 st)
+        PP64_PHASE_END();
+        PP64_LOAD(sa, sb, 1, (void)0);                          // P0(2 st + 1)
+        PP64_PHASE_END();
+        PP64_MULTIPLY();                                        // P1(2 st + 1)
+        PP64_PHASE_END();
+        sa = sa1; sb = sb1;
+      }
     }
-  } else {
-    issue(0, 0);
-    issue(1, HALF);
-    if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // stage 0
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue of the tile.  Accumulators: lane l & 31 = tile row, register r = column (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    // of a 32 x 32 block.
+    if (C32 != nullptr) {                                       // float32 outputs (rare for wide layers): direct stores by every wave
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * FM * 32 + i * 32 + frow;
+        if (m < M) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int n = n0 + wn * FN * 32 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              if (n >= N) continue;
+              float v = activate(acc[i][j][r] + (bias ? bias[n] : 0.f));
+              if (ACT == 4) v = (float)aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;
+              C32[(size_t)m * ldc32 + n] = v;
+              if (C16) C16[(size_t)m * ldc + n] = (__bf16)v;
+            }
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    // bf16 output: every wave stages its 128 x 64 part in the (idle) ring memory ([256][256] bf16, rows rotated by 16 bytes
+    // per row against bank conflicts; 8-byte writes: a register quad is 4 consecutive columns of one row); group 1 writes
+    // the tile out as 16 bytes per lane = whole 512-byte rows per 32 lanes, applying / emitting the ReLU masks
+    {
+      __bf16* tile = (__bf16*)ring_smem;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = wn * FN * 32 + j * 32 + 8 * q + 4 * hi;        // first of 4 consecutive columns
+          const int n = n0 + nl;
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias) {
+            if (n + 4 <= N) b4 = *(const float4*)(bias + n);
+            else { if (n < N) b4.x = bias[n]; if (n + 1 < N) b4.y = bias[n + 1]; if (n + 2 < N) b4.z = bias[n + 2]; }
+          }
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const int ml = wm * FM * 32 + i * 32 + frow;
+            const f32x2 lo = {activate(acc[i][j][4 * q] + b4.x), activate(acc[i][j][4 * q + 1] + b4.y)};
+            const f32x2 hi2 = {activate(acc[i][j][4 * q + 2] + b4.z), activate(acc[i][j][4 * q + 3] + b4.w)};
+            uint2 pk;
+            pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+            pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi2, bf16x2));
+            *(uint2*)(tile + ml * BN + ((nl + 8 * ml) & (BN - 1))) = pk;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (group 0: the bias loads; group 1: bias, mask words, and the previous tile's stores -- long done)
     __builtin_amdgcn_s_barrier();
-    PP64_PHASE_END();
-    for (int st = 0; st < ns; ++st) {
-      const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;
-      PP64_LOAD(sa, sb, 0, if (st >= 1) issue(st + 1, sb1));    // P0(2 st): the W slot of stage st - 1 is free -> stage st + 1
-      PP64_PHASE_END();
-      PP64_MULTIPLY();                                          // P1(2 st)
-      PP64_PHASE_END();
-      PP64_LOAD(sa, sb, 1, (void)0);                            // P0(2 st + 1)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          //   own W rows of stage st + 1
-      PP64_PHASE_END();
-      PP64_MULTIPLY();                                          // P1(2 st + 1)
-      PP64_PHASE_END();
-      sa = sa1; sb = sb1;
+    if (Cfg::NTR == 512 || grp == 1) {
+      // (whole tiles, ldc / ldaux multiples of 8: the launcher sends everything else to the ring kernel)
+      const __bf16* tile = (const __bf16*)ring_smem;
+      const int n = n0 + piece * 8;
+#pragma unroll
+      for (int q = 0; q < IT / 4; ++q) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int ml = rgroup * IT + 4 * q + b, m = m0 + ml;
+          uint4 v = *(const uint4*)(tile + ml * BN + ((piece * 8 + 8 * ml) & (BN - 1)));
+          if (ACT == 5) {                                              // bit k: bf16 k is > 0 (sign clear, magnitude non-zero)
+            const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+            uint32_t bits = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              bits |= (((vw[k] & 0x8000u) == 0 && (vw[k] & 0x7FFFu) != 0) ? 1u : 0u) << (2 * k);
+              bits |= (((vw[k] & 0x80000000u) == 0 && (vw[k] & 0x7FFF0000u) != 0) ? 1u : 0u) << (2 * k + 1);
+            }
+            mw[q] |= bits << (8 * b);
+          }
+          if (ACT == 6) {
+            const uint32_t bits = mw[q] >> (8 * b);
+            v.x &= ((0u - ((bits >> 0) & 1u)) & 0x0000FFFFu) | ((0u - ((bits >> 1) & 1u)) & 0xFFFF0000u);
+            v.y &= ((0u - ((bits >> 2) & 1u)) & 0x0000FFFFu) | ((0u - ((bits >> 3) & 1u)) & 0xFFFF0000u);
+            v.z &= ((0u - ((bits >> 4) & 1u)) & 0x0000FFFFu) | ((0u - ((bits >> 5) & 1u)) & 0xFFFF0000u);
+            v.w &= ((0u - ((bits >> 6) & 1u)) & 0x0000FFFFu) | ((0u - ((bits >> 7) & 1u)) & 0xFFFF0000u);
+          }
+          if (ACT == 4) {                                              // keep a bf16 where the saved activation is > 0
+            const uint4 a4 = *(const uint4*)(aux + (size_t)m * ldaux + n);
+            auto keep = [](uint32_t aw) {
+              const uint32_t lo = ((aw & 0x8000u) == 0 && (aw & 0x7FFFu) != 0) ? 0x0000FFFFu : 0u;
+              const uint32_t hi16 = ((aw & 0x80000000u) == 0 && (aw & 0x7FFF0000u) != 0) ? 0xFFFF0000u : 0u;
+              return lo | hi16;
+            };
+            v.x &= keep(a4.x); v.y &= keep(a4.y); v.z &= keep(a4.z); v.w &= keep(a4.w);
+          }
+          *(uint4*)(C16 + (size_t)m * ldc + n) = v;
+        }
+      }
+      if (ACT == 5) {
+#pragma unroll
+        for (int q = 0; q < IT / 16; ++q) *(uint4*)(mask_at + 16 * q) = make_uint4(mw[4 * q], mw[4 * q + 1], mw[4 * q + 2], mw[4 * q + 3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tile has left LDS (the stores themselves drain under the next tile)
     }
+    __builtin_amdgcn_s_barrier();                                 // the ring may be refilled
   }
 #undef PP64_READ6
 #undef PP64_LOAD
 #undef PP64_MULTIPLY
 #undef PP64_PHASE_END
-  ring_epilogue<ACT, WM, WN, FM, FN, Cfg>(acc, mw, mask_at, tid, wm, wn, m0, n0, M, N, bias, C16, ldc, C32, ldc32, act_param, aux, ldaux);
 }
 
 }  // namespace mip360
@@ -655,8 +776,15 @@ static void launch_pp64(hipStream_t st, int M, int N, int K, const void* A, int 
     (void)hipFuncSetAttribute((const void*)linear_bf16_pp64_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PP64Cfg::LDS);
     attr_set = true;
   }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    n_cu = n_cu >= 8 ? n_cu / 8 * 8 : 8;                          // a multiple of 8: virtual block id % 8 stays the XCD
+  }
   const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
-  hipLaunchKernelGGL((linear_bf16_pp64_kernel<ACT>), dim3(tiles), dim3(512), PP64Cfg::LDS, st, M, N, K, (const __bf16*)A, lda,
+  hipLaunchKernelGGL((linear_bf16_pp64_kernel<ACT>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), PP64Cfg::LDS, st, M, N, K, (const __bf16*)A, lda,
                      (const __bf16*)W, ldw, bias, (__bf16*)C16, ldc, C32, ldc32, act_param, (const __bf16*)aux, ldaux, (uint8_t*)mask,
                      ldmask);
 }
@@ -674,7 +802,8 @@ static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, 
   if (MASKED || (N >= 192 && M >= 256 && !force_small && !no_ring)) {
 #define MIP360_RING(...) launch_ring<ACT, __VA_ARGS__>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux, mask, ldmask)
     if (ring_kind == 4) MIP360_RING(2, 2, 4, 2, 3);                  // 4 waves, 256 x 128, two workgroups per CU (measured slower)
-    else if (ring_kind == 1 || K % 64 != 0) MIP360_RING(2, 4, 4, 2, 4);
+    else if (ring_kind == 1 || K % 64 != 0 || M % 256 != 0 || N % 256 != 0 || (C16 && ldc % 8 != 0) || (ACT == 4 && ldaux % 8 != 0))
+      MIP360_RING(2, 4, 4, 2, 4);
     else launch_pp64<ACT>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux, mask, ldmask);
 #undef MIP360_RING
   } else if constexpr (!MASKED) {
