@@ -396,7 +396,7 @@ class TrainableMLP(object):
         self.wb = {}                                                                         # backward operands
         for t in range(1, D):
             self.wb[t] = bf(self.in_pad[t], W)
-        self.head_k = (BOTTLENECK + 32) if not cfg['disable_rgb'] else 32
+        self.head_k = (BOTTLENECK + 64) if not cfg['disable_rgb'] else 64        # a multiple of 64: the persistent ping-pong GEMM
         self.wb['heads'] = bf(W, self.head_k)                    # [K_bottleneck | K_density | 0], or [K_density | 0]
         if not cfg['disable_rgb']:
             self.wb[D + 2] = bf(BOTTLENECK + DIR_LD, VIEW_WIDTH)
