@@ -131,10 +131,17 @@ int mip360_linear_masked_bf16(void* stream, int m, int n, int k, const void* a, 
 /* d kernel [n_in, n_out] (flax layout, float32, row stride ldg) = scale * H[m, n_in]^T dZ[m, n_out]: bf16 operands,
  * MFMA with ds_read_b64_tr_b16 transposed fragments, split over `ksplit` row slices into `slabs`
  * (>= ksplit * (n_in * ldg + n_out) floats) that are summed in a fixed order.  grad_bias [n_out] (may be NULL) =
- * scale * column sums of dZ, accumulated from the fragments the first input tile already holds. */
+ * scale * column sums of dZ, accumulated from the fragments the first input tile already holds.
+ * grad_kernel == NULL: only the slabs are produced (grad_bias != NULL still asks for the bias slabs); the caller sums
+ * them later with mip360_grad_weight_reduce, e.g. on another stream under the next layer's GEMMs. */
 int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz,
                             int lddz, int ksplit, float* slabs, float* grad_kernel, int ldg, float scale,
                             float* grad_bias);
+/* The fixed-order sum of the slabs written by mip360_grad_weight_bf16(m, n_in, n_out, ..., ksplit, slabs, ldg): kernel
+ * gradient rows [0, rows) (rows <= n_in: the zero-padded input columns of a layer are dropped here) and, if grad_bias is
+ * not NULL, the bias gradient, in one launch. */
+int mip360_grad_weight_reduce(void* stream, int rows, int n_in, int n_out, int ksplit, const float* slabs,
+                              float* grad_kernel, int ldg, float scale, float* grad_bias);
 /* Output tile edge (256 or 128) the call above will use for these sizes: the caller picks ksplit (1..256) so that
  * ceil(n_in / tile) * ceil(n_out / tile) * ksplit fills the 256 CUs (multiples of 8 keep a row slice on one XCD). */
 int mip360_grad_weight_tile(int m, int n_in, int n_out, int ldh, int lddz);

@@ -26,6 +26,8 @@ void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, in
                           int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux,
                           void* mask, int ldmask);
 bool mip360_grad_weight_is_wide(int M, int I, int O, int ldh, int lddz);
+void mip360_launch_grad_weight_reduce(hipStream_t st, int rows, int I_slab, int O, int ksplit, const float* slabs, float* out, int ldc,
+                                      float scale, float* bias_out);
 void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
                                float* slabs, float* out, int ldc, float scale, float* bias_out);
 void mip360_launch_col_sum(hipStream_t st, int M, int O, const void* dZ, int ld, int nslice, float* partial, float* out,
@@ -180,9 +182,16 @@ int mip360_linear_masked_bf16(void* stream, int m, int n, int k, const void* a, 
 int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz, int lddz,
                             int ksplit, float* slabs, float* grad_kernel, int ldg, float scale, float* grad_bias) {
   REQUIRE(m > 0 && n_in > 0 && n_out > 0 && n_in % 8 == 0 && ksplit >= 1 && ksplit <= 256, "sizes (n_in multiple of 8, 1 <= ksplit <= 256)");
-  REQUIRE(h && dz && slabs && grad_kernel && ldh >= n_in && lddz >= n_out && ldg >= n_out && ldh % 8 == 0 && lddz % 8 == 0, "pointers / leading dimensions");
+  REQUIRE(h && dz && slabs && ldh >= n_in && lddz >= n_out && ldg >= n_out && ldh % 8 == 0 && lddz % 8 == 0, "pointers / leading dimensions");
   mip360_launch_grad_weight((hipStream_t)stream, m, n_in, n_out, h, ldh, dz, lddz, ksplit, slabs, grad_kernel, ldg, scale, grad_bias);
   return check_launch("grad_weight_bf16");
+}
+
+int mip360_grad_weight_reduce(void* stream, int rows, int n_in, int n_out, int ksplit, const float* slabs, float* grad_kernel, int ldg,
+                              float scale, float* grad_bias) {
+  REQUIRE(rows > 0 && rows <= n_in && n_out > 0 && ksplit >= 1 && ksplit <= 256 && slabs && grad_kernel && ldg >= n_out, "arguments");
+  mip360_launch_grad_weight_reduce((hipStream_t)stream, rows, n_in, n_out, ksplit, slabs, grad_kernel, ldg, scale, grad_bias);
+  return check_launch("grad_weight_reduce");
 }
 
 int mip360_grad_weight_tile(int m, int n_in, int n_out, int ldh, int lddz) {

@@ -311,6 +311,50 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(int64_t n, int ksplit, co
   }
 }
 
+// the same for two slab sets in one launch (a layer's kernel and bias gradients): blocks [0, blocks_a) reduce set a
+// (n_a elements of slabs whose stride is stride_a >= n_a), the remaining blocks set b
+__global__ __launch_bounds__(256) void slab_sum2_kernel(int blocks_a, int64_t n_a, int64_t stride_a, const float* __restrict__ slabs_a,
+                                                        float* __restrict__ out_a, int64_t n_b, int64_t stride_b,
+                                                        const float* __restrict__ slabs_b, float* __restrict__ out_b, int ksplit,
+                                                        float scale) {
+  __shared__ float4 part[4][64];
+  const bool second = (int)blockIdx.x >= blocks_a;
+  const int64_t n = second ? n_b : n_a, stride = second ? stride_b : stride_a;
+  const float* slabs = second ? slabs_b : slabs_a;
+  float* out = second ? out_b : out_a;
+  const int blk = second ? blockIdx.x - blocks_a : blockIdx.x;
+  const int t = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t e = ((int64_t)blk * 64 + t) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < n) {
+    if ((n & 3) == 0 && (stride & 3) == 0) {
+      for (int s_ = g; s_ < ksplit; s_ += 4) {
+        const float4 v = *(const float4*)(slabs + (size_t)s_ * stride + e);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    } else {
+      for (int s_ = g; s_ < ksplit; s_ += 4) {
+        const float* p = slabs + (size_t)s_ * stride + e;
+        acc.x += p[0];
+        if (e + 1 < n) acc.y += p[1];
+        if (e + 2 < n) acc.z += p[2];
+        if (e + 3 < n) acc.w += p[3];
+      }
+    }
+  }
+  part[g][t] = acc;
+  __syncthreads();
+  if (g == 0 && e < n) {
+    float4 r = part[0][t];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { r.x += part[k][t].x; r.y += part[k][t].y; r.z += part[k][t].z; r.w += part[k][t].w; }
+    out[e] = r.x * scale;
+    if (e + 1 < n) out[e + 1] = r.y * scale;
+    if (e + 2 < n) out[e + 2] = r.z * scale;
+    if (e + 3 < n) out[e + 3] = r.w * scale;
+  }
+}
+
 // bias gradients: partial[slice][o] = sum over the slice's rows of dZ[m][o]
 __global__ __launch_bounds__(256) void col_sum_kernel(int M, int O, const __bf16* __restrict__ dZ, int ld, int nslice,
                                                       float* __restrict__ partial) {
@@ -404,6 +448,8 @@ bool mip360_grad_weight_is_wide(int M, int I, int O, int ldh, int lddz) {
   static const bool off = getenv("MIP360_DW_NARROW") != nullptr;
   return !off && M % 32 == 0 && M >= 256 && I % 256 == 0 && O % 256 == 0 && ldh % 8 == 0 && lddz % 8 == 0;
 }
+void mip360_launch_grad_weight_reduce(hipStream_t st, int rows, int I_slab, int O, int ksplit, const float* slabs, float* out, int ldc,
+                                      float scale, float* bias_out);
 void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
                                float* slabs, float* out, int ldc, float scale, float* bias_out) {
   const int tiles = ((I + GT - 1) / GT) * ((O + GT - 1) / GT);
@@ -416,10 +462,17 @@ void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* 
   else
   hipLaunchKernelGGL(grad_weight_kernel, dim3(tiles * ksplit), dim3(256), lds, st, M, I, O, (const __bf16*)H, ldh,
                      (const __bf16*)dZ, lddz, ksplit, slabs, ldc, bias_slabs);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ksplit, slabs, scale, out);
-  if (bias_out)
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((O + 255) / 256)), dim3(256), 0, st, (int64_t)O, ksplit, bias_slabs, scale,
-                       bias_out);
+  if (out) mip360_launch_grad_weight_reduce(st, I, I, O, ksplit, slabs, out, ldc, scale, bias_out);
+}
+// kernel gradient = scale * sum of the split-K slabs (first `rows` of the I_slab input rows of every slab), bias gradient
+// likewise from the [ksplit][O] slabs behind them: one launch
+void mip360_launch_grad_weight_reduce(hipStream_t st, int rows, int I_slab, int O, int ksplit, const float* slabs, float* out, int ldc,
+                                      float scale, float* bias_out) {
+  const int64_t stride = (int64_t)I_slab * ldc, n = (int64_t)rows * ldc;
+  const float* bias_slabs = slabs + (size_t)ksplit * stride;
+  const int blocks_a = (int)((n + 255) / 256), blocks_b = bias_out ? (O + 255) / 256 : 0;
+  hipLaunchKernelGGL(slab_sum2_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, st, blocks_a, n, stride, slabs, out, (int64_t)O,
+                     (int64_t)O, bias_slabs, bias_out, ksplit, scale);
 }
 void mip360_launch_col_sum(hipStream_t st, int M, int O, const void* dZ, int ld, int nslice, float* partial, float* out,
                            float scale) {

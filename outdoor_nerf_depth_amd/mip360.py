@@ -44,6 +44,7 @@ SYMBOLS = {
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                           C.c_float, _fp]),
+    'mip360_grad_weight_reduce': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_float, _fp]),
     'mip360_grad_bias_bf16': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_float]),
     'mip360_head_backward': (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'mip360_sum_squares': (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int]),
@@ -378,6 +379,7 @@ class TrainableMLP(object):
             self.kernel(t).copy_(torch.from_numpy(np.asarray(k, np.float32)))
             self.bias(t).copy_(torch.from_numpy(np.asarray(b, np.float32)))
         self.grads = torch.zeros_like(self.flat)
+        self.slabs = {}                                  # per-layer split-K slab buffers of the deferred weight-gradient sums
         self.mu, self.nu = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         D, W = self.depth, self.W
         self.in_pad = []
@@ -434,8 +436,10 @@ class TrainableMLP(object):
         return [(self.kernel(t).clone(), self.bias(t).clone()) for t in range(len(self.shapes))]
 
 
-def _grad_weight(h, dz, n_in, n_out, out, scratch, bias_out=None):
-    """d kernel = H^T dZ into `out` [n_in, n_out]; bias_out [n_out] = column sums of dZ from the same pass."""
+def _grad_weight(h, dz, n_in, n_out, out, scratch, bias_out=None, rows_out=None, side=None, slabs=None):
+    """d kernel = H^T dZ into `out` [rows_out <= n_in, n_out]; bias_out [n_out] = column sums of dZ from the same pass.
+    side = (stream, persistent slab dict, key): the split-K slabs are summed on that stream (under the GEMMs that follow on
+    the current one) out of a buffer that belongs to this layer alone."""
     m = h.shape[0]
     ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
     tile = lib().mip360_grad_weight_tile(m, n_in, n_out, ld(h), ld(dz))
@@ -444,10 +448,32 @@ def _grad_weight(h, dz, n_in, n_out, out, scratch, bias_out=None):
     if ksplit >= 8 or m >= 8 * 256:
         ksplit = max(8, (ksplit // 8) * 8)            # multiples of 8: one or more whole row slices per XCD
     need = ksplit * (n_in * n_out + n_out)
-    if scratch[0] is None or scratch[0].numel() < need:
-        scratch[0] = torch.empty(need, device=h.device)
-    _check(lib().mip360_grad_weight_bf16(_stream(), m, n_in, n_out, _p(h), ld(h), _p(dz), ld(dz), ksplit, _p(scratch[0]), _p(out),
-                                         n_out, 1.0, _p(bias_out)), 'mip360_grad_weight_bf16')
+    rows_out = n_in if rows_out is None else rows_out
+    if side is None:
+        if scratch[0] is None or scratch[0].numel() < need:
+            scratch[0] = torch.empty(need, device=h.device)
+        buf = scratch[0]
+        if rows_out == n_in:
+            _check(lib().mip360_grad_weight_bf16(_stream(), m, n_in, n_out, _p(h), ld(h), _p(dz), ld(dz), ksplit, _p(buf), _p(out),
+                                                 n_out, 1.0, _p(bias_out)), 'mip360_grad_weight_bf16')
+            return
+        _check(lib().mip360_grad_weight_bf16(_stream(), m, n_in, n_out, _p(h), ld(h), _p(dz), ld(dz), ksplit, _p(buf), None,
+                                             n_out, 1.0, _p(bias_out)), 'mip360_grad_weight_bf16')
+        _check(lib().mip360_grad_weight_reduce(_stream(), rows_out, n_in, n_out, ksplit, _p(buf), _p(out), n_out, 1.0,
+                                               _p(bias_out)), 'mip360_grad_weight_reduce')
+        return
+    stream, store, key = side
+    buf = store.get(key)
+    if buf is None or buf.numel() < need:
+        buf = store[key] = torch.empty(need, device=h.device)
+    _check(lib().mip360_grad_weight_bf16(_stream(), m, n_in, n_out, _p(h), ld(h), _p(dz), ld(dz), ksplit, _p(buf), None, n_out, 1.0,
+                                         _p(bias_out)), 'mip360_grad_weight_bf16')
+    ev = torch.cuda.Event()
+    ev.record()
+    stream.wait_event(ev)
+    with torch.cuda.stream(stream):
+        _check(lib().mip360_grad_weight_reduce(_stream(), rows_out, n_in, n_out, ksplit, _p(buf), _p(out), n_out, 1.0,
+                                               _p(bias_out)), 'mip360_grad_weight_reduce')
 
 
 def _grad_bias(dz, n_out, out, scratch):
@@ -495,7 +521,7 @@ def mlp_forward_train(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
     return density[:, 0], rgb, saved
 
 
-def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch):
+def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch, side_stream=None):
     """Parameter gradients of one MLP into tm.grads (oracle: mip360_oracle.mlp_backward).  g_density [rows] f32,
     g_rgb [rows, 3] f32 or None."""
     W, D = tm.W, tm.depth
@@ -503,6 +529,10 @@ def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch):
     G = tm.grads
     bf = lambda c: torch.empty(rows, c, dtype=torch.bfloat16, device=dev)
     nerf = not tm.cfg['disable_rgb']
+    # side_stream: the slab sums of the weight gradients run there (persistent per-layer slab buffers in tm.slabs); the
+    # caller orders whatever consumes tm.grads after that stream.  Measured on the trainer: no gain (-3 %) -- the GEMMs
+    # that follow occupy every CU's LDS and registers, so the short reduction kernels cannot run beside them.
+    side = (lambda key: (side_stream, tm.slabs, key)) if side_stream is not None else (lambda key: None)
     trunk, trunk_k = saved['trunk']
     heads = bf(tm.head_k)                                            # [d bottleneck (256) | d raw | 0] or [d raw | 0]
     raw_col = BOTTLENECK if nerf else 0
@@ -512,27 +542,22 @@ def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch):
                                       _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
     if nerf:
         h, view_in = saved['h'], saved['view_in']
-        _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G))
+        _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G), side=side(D + 3))
         d_hz = bf(VIEW_WIDTH)
         linear(d_pre, tm.wb[D + 3], None, act=4, out_bf16=d_hz, m=rows, n=VIEW_WIDTH, k=32, aux=h)
-        gk = torch.empty(BOTTLENECK + DIR_LD, VIEW_WIDTH, device=dev)
-        _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, gk, scratch, tm.bias(D + 2, G))
-        tm.kernel(D + 2, G).copy_(gk[:BOTTLENECK + DIR_DIM])
+        _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, tm.kernel(D + 2, G), scratch, tm.bias(D + 2, G),
+                     rows_out=BOTTLENECK + DIR_DIM, side=side(D + 2))
         linear(d_hz, tm.wb[D + 2], None, act=0, out_bf16=heads, m=rows, n=BOTTLENECK, k=VIEW_WIDTH)     # -> heads[:, :256]
-        _grad_weight(trunk, heads, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch, tm.bias(D + 1, G))
+        _grad_weight(trunk, heads, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch, tm.bias(D + 1, G), side=side(D + 1))
     d_raw = heads[:, raw_col:]
-    _grad_weight(trunk, d_raw, trunk_k, 1, tm.kernel(D, G), scratch, tm.bias(D, G))
+    _grad_weight(trunk, d_raw, trunk_k, 1, tm.kernel(D, G), scratch, tm.bias(D, G), side=side(D))
     # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
     dz = bf(W)
     linear_masked(heads, tm.wb['heads'], dz, *saved['masks'][D - 1], m=rows, n=W, k=tm.head_k)
     for i in reversed(range(D)):
         x, x_k = saved['inputs'][i]
-        if x_k == tm.shapes[i][0]:
-            _grad_weight(x, dz, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G))
-        else:                                                        # padded input (504 -> 512 encoding columns)
-            gk = torch.empty(x_k, W, device=dev)
-            _grad_weight(x, dz, x_k, W, gk, scratch, tm.bias(i, G))
-            tm.kernel(i, G).copy_(gk[:tm.shapes[i][0]])
+        # (padded input, 504 -> 512 encoding columns: the slab sum drops the padding rows)
+        _grad_weight(x, dz, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G), rows_out=tm.shapes[i][0], side=side(i))
         if i > 0:
             nxt = bf(W)
             linear_masked(dz, tm.wb[i], nxt, *saved['masks'][i - 1], m=rows, n=W, k=W)
