@@ -20,3 +20,10 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/m360 -- python $R/tools/mip36
 python $R/tools/rocpd_stats.py $(ls $O/m360/*/*.db | head -1) > $O/mip360_kernel_stats.md
 python $R/tools/rocpd_timeline.py $(ls $O/m360/*/*.db | head -1) resample_kernel 3 > $O/mip360_timeline.md
 rm -rf $O/m360
+# MipNeRF-360 dense-layer probes: GEMM micro-benchmarks (next to torch / hipBLASLt), time against K and tile count, DMA
+# address-pattern rate, PMC passes over one NerfMLP-shaped layer
+timeout 200 python $R/tools/probes/mip360_gemm_bench.py --check > $O/mip360_gemm_bench.txt 2>&1
+timeout 200 python $R/tools/probes/mip360_gemm_shapes.py > $O/mip360_gemm_shapes.txt 2>&1
+timeout 200 python $R/tools/probes/mip360_dw_bench.py > $O/mip360_dw_bench.txt 2>&1
+[ -x $R/tools/probes/dma_pattern_probe ] && timeout 100 $R/tools/probes/dma_pattern_probe > $O/dma_pattern_probe.txt 2>&1
+RINGS="1 0" bash $R/tools/probes/pmc_gemm_one.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_gemm_one.txt $O/pmc_gemm_one.txt
