@@ -114,7 +114,9 @@ def test_cast_encode_matches_oracle(M):
 
 
 # ---------------------------------------------------------------------------------------------------- dense layers
-@pytest.mark.parametrize('m,n,k', [(300, 70, 96), (128, 128, 32), (1000, 1, 1024), (257, 1024, 1536)])
+# (512, 512, 192) and (768, 256, 1024): whole 256 x 256 tiles and K % 64 == 0 -> the persistent ping-pong kernel (more tiles than
+# one round would need on a small grid is covered by the MLP tests); the others -> the ring / register-staged kernels
+@pytest.mark.parametrize('m,n,k', [(300, 70, 96), (128, 128, 32), (1000, 1, 1024), (257, 1024, 1536), (512, 512, 192), (768, 256, 1024)])
 def test_linear_bf16_against_numpy(M, m, n, k):
     rs = np.random.RandomState(m + n)
     a = round_bf16(rs.randn(m, k).astype(np.float32))
@@ -131,6 +133,9 @@ def test_linear_bf16_against_numpy(M, m, n, k):
         np.testing.assert_allclose(N(o32), fn(ref), rtol=2e-5, atol=2e-5)
         if n > 1:
             np.testing.assert_allclose(N(o16[:, :n]), fn(ref), rtol=2 ** -7, atol=1e-3)
+            o16b = torch.empty(m, n + 8, dtype=torch.bfloat16, device=dev())      # bf16 output alone: the LDS-staged epilogue
+            M.linear(ta, tw, T(b), act=act, act_param={2: -1.0, 3: 0.001}.get(act, 0.0), out_bf16=o16b[:, :n])
+            np.testing.assert_allclose(N(o16b[:, :n]), fn(ref), rtol=2 ** -7, atol=1e-3)
     # strided A (a column window of a wider buffer), as the skip / view layers use it
     wide = torch.zeros(m, k + 64, dtype=torch.bfloat16, device=dev())
     wide[:, 64:] = ta
@@ -160,7 +165,7 @@ def test_linear_relu_bit_mask_equals_the_saved_activation_path(M, m, n, k):
     want = np.packbits(want.reshape(-1, 8, m), axis=1, bitorder='little')[:, 0]
     np.testing.assert_array_equal(bits, want)
     # dX step: dz [m, kk] times a [n, kk] transposed kernel, masked by this layer's pattern
-    kk = 96
+    kk = 128 if m % 256 == 0 else 96                                       # 128: act 4 and the bit-mask dX both on the ping-pong kernel
     dz = T(round_bf16(rs.randn(m, kk).astype(np.float32))).to(torch.bfloat16)
     wb = T(round_bf16(rs.randn(n, kk).astype(np.float32))).to(torch.bfloat16)
     want16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev())
