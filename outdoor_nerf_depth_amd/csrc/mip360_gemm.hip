@@ -567,72 +567,81 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
     }
     uint32_t sa = 0, sb = 0;                                    // ring positions (byte offsets) of the current stage
     // one loop per group (straight-line bodies); both execute the same sequence of barriers
+    // DMA: a stage of one operand is 32 instructions of 8 rows x 128 B; wave w issues instructions [4 w, 4 w + 4) of BOTH
+    // operands, i.e. rows [32 w, 32 w + 32): four instructions in each of its load phases, so that every load phase of
+    // every wave carries the same issue work (eight in one phase made that phase 1.6x as long as the MFMA burst beside it).
+    // lane l -> row l >> 3, position l & 7 holding chunk (l & 7) ^ ((row >> 1) & 7).  Whole tiles only (the launcher sends
+    // ragged shapes to the ring kernel), so a row's address is a wave-uniform base (SGPRs: tile origin, wave, instruction
+    // q, stage) plus a per-lane offset that only depends on the parity of q: 4 VGPRs for both operands.
+    uint32_t voffA[2], voffW[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int chunk = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);        // ((8 q + (lane >> 3)) >> 1) & 7 with q & 1 = par
+      voffA[par] = (uint32_t)((lane >> 3) * lda * 2 + chunk * 16);
+      voffW[par] = (uint32_t)((lane >> 3) * ldw * 2 + chunk * 16);
+    }
+    const char* const baseA = (const char*)(A + (size_t)(m0 + 32 * wave) * lda);
+    const char* const baseW = (const char*)(W + (size_t)(n0 + 32 * wave) * ldw);
+    const uint32_t dstA = lds0 + (uint32_t)(32 * wave * 128), dstW = dstA + WBASE;
+    auto issue_a = [&](int st, uint32_t slot_bytes) {
+      if (st >= ns) return;
+#if defined(MIP360_EXP_NODMA)
+      if (st >= 2) return;
+#endif
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16_saddr(baseA + (size_t)q * 8 * lda * 2 + (size_t)st * 128, voffA[q & 1], dstA + slot_bytes + q * 1024);
+    };
+    auto issue_w = [&](int st, uint32_t slot_bytes) {
+      if (st >= ns) return;
+#if defined(MIP360_EXP_NODMA)
+      if (st >= 2) return;
+#endif
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16_saddr(baseW + (size_t)q * 8 * ldw * 2 + (size_t)st * 128, voffW[q & 1], dstW + slot_bytes + q * 1024);
+    };
+    // every wave: its rows of stages 0 and 1, then stage 0 must have landed (stage 1: 8 instructions may be out)
+    issue_a(0, 0);
+    issue_w(0, 0);
+    issue_a(1, HALF);
+    issue_w(1, HALF);
+    if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // DMA schedule (slots: the A ring is 3 deep, the W ring 2 deep; a stage's slots are free once group 1 has read its second
+    // half, i.e. after P0(2 st + 1)):
+    //     group 0, P1(2 st):     A rows of stage st + 2      group 1, P0(2 st):     W rows of stage st + 1 (st >= 1)
+    //     group 0, P1(2 st + 1): W rows of stage st + 2      group 1, P0(2 st + 1): A rows of stage st + 2
+    // every wave waits for its own rows of stage st + 1 at the end of P0(2 st + 1): only its A rows of stage st + 2 may be out.
     if (grp == 0) {
-      // DMA: wave w covers rows [64 w, 64 w + 64) of A and of W with 8 instructions of 8 rows x 128 B each per stage;
-      // lane l -> row l >> 3, position l & 7 holding chunk (l & 7) ^ ((row >> 1) & 7).  Whole tiles only (the launcher
-      // sends ragged shapes to the ring kernel), so a row's address is a wave-uniform base (SGPRs: tile origin, wave,
-      // instruction q, stage) plus a per-lane offset that only depends on the parity of q: 4 VGPRs for both operands.
-      uint32_t voffA[2], voffW[2];
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int chunk = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);      // ((8 q + (lane >> 3)) >> 1) & 7 with q & 1 = par
-        voffA[par] = (uint32_t)((lane >> 3) * lda * 2 + chunk * 16);
-        voffW[par] = (uint32_t)((lane >> 3) * ldw * 2 + chunk * 16);
-      }
-      const char* const baseA = (const char*)(A + (size_t)(m0 + 64 * wave) * lda);
-      const char* const baseW = (const char*)(W + (size_t)(n0 + 64 * wave) * ldw);
-      const uint32_t dstA = lds0 + (uint32_t)(64 * wave * 128), dstW = dstA + WBASE;
-      auto issue_a = [&](int st, uint32_t slot_bytes) {
-        if (st >= ns) return;
-#if defined(MIP360_EXP_NODMA)
-        if (st >= 2) return;
-#endif
-#pragma unroll
-        for (int q = 0; q < 8; ++q) glds16_saddr(baseA + (size_t)q * 8 * lda * 2 + (size_t)st * 128, voffA[q & 1], dstA + slot_bytes + q * 1024);
-      };
-      auto issue_w = [&](int st, uint32_t slot_bytes) {
-        if (st >= ns) return;
-#if defined(MIP360_EXP_NODMA)
-        if (st >= 2) return;
-#endif
-#pragma unroll
-        for (int q = 0; q < 8; ++q) glds16_saddr(baseW + (size_t)q * 8 * ldw * 2 + (size_t)st * 128, voffW[q & 1], dstW + slot_bytes + q * 1024);
-      };
-      issue_a(0, 0);
-      issue_w(0, 0);
-      issue_a(1, HALF);
-      issue_w(1, HALF);
-      if (ns > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // stage 0
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
       PP64_LOAD(0u, 0u, 0, (void)0);
       PP64_PHASE_END();
       for (int st = 0; st < ns; ++st) {
         const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;      // slots of stage st + 1
         PP64_MULTIPLY();                                        // P0(2 st)
         PP64_PHASE_END();
-        PP64_LOAD(sa, sb, 1, issue_a(st + 2, next_a(sa1)));     // P1(2 st): the A slot of stage st - 1 is free -> stage st + 2
+        PP64_LOAD(sa, sb, 1, issue_a(st + 2, next_a(sa1)));     // P1(2 st)
         PP64_PHASE_END();
         PP64_MULTIPLY();                                        // P0(2 st + 1)
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  //   stage st + 1 (A of stage st + 2 may be out)
+        if (st + 2 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP64_PHASE_END();
-        // P1(2 st + 1): the W slot of stage st is free -> stage st + 2; fragments of (st + 1, half 0) (last stage: a harmless re-read)
+        // P1(2 st + 1): fragments of (st + 1, half 0) (last stage: a harmless re-read)
         if (st + 1 < ns) { PP64_LOAD(sa1, sb1, 0, issue_w(st + 2, sb)); } else { PP64_LOAD(sa, sb, 0, (void)0); }
         PP64_PHASE_END();
         sa = sa1; sb = sb1;
       }
     } else {
-      __builtin_amdgcn_s_barrier();
       PP64_PHASE_END();
       for (int st = 0; st < ns; ++st) {
         const uint32_t sa1 = next_a(sa), sb1 = sb ^ HALF;
-        PP64_LOAD(sa, sb, 0, (void)0);                          // P0(2 st)
+        PP64_LOAD(sa, sb, 0, if (st >= 1) issue_w(st + 1, sb1));          // P0(2 st): the W slot of stage st - 1
         PP64_PHASE_END();
         PP64_MULTIPLY();                                        // P1(2 st)
         PP64_PHASE_END();
-        PP64_LOAD(sa, sb, 1, (void)0);                          // P0(2 st + 1)
+        PP64_LOAD(sa, sb, 1, issue_a(st + 2, next_a(sa1)));     // P0(2 st + 1): the A slot of stage st - 1
+        if (st + 2 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP64_PHASE_END();
         PP64_MULTIPLY();                                        // P1(2 st + 1)
         PP64_PHASE_END();
