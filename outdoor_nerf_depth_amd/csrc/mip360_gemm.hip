@@ -759,6 +759,38 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
 
 }  // namespace mip360
 
+namespace mip360 {
+// One output column (the density head, models.py:497: raw_density = Dense(1)(x)): a GEMM tile would spend 128 columns of
+// MFMA work on it; this is a row dot product that streams x once (HBM-bound: 268 MB at the NerfMLP shape).  16 lanes per
+// row, 16 bytes per lane and step, float32 accumulation, xor-shuffle reduction; four rows per wave and pass.
+template <int ACT>
+__global__ __launch_bounds__(256) void rowdot_bf16_kernel(int M, int K, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ w,
+                                                          const float* __restrict__ bias, float act_param, float* __restrict__ out,
+                                                          int ldo) {
+  const int sub = threadIdx.x & 15, rq = threadIdx.x >> 4;            // 16 row slots per block and pass
+  const float b = bias ? bias[0] : 0.f;
+  for (int m = blockIdx.x * 16 + rq; m < M; m += gridDim.x * 16) {
+    const __bf16* row = A + (size_t)m * lda;
+    float acc = 0.f;
+    for (int k = sub * 8; k < K; k += 128) {
+      const bf16x8 x = *(const bf16x8*)(row + k);
+      const bf16x8 ww = *(const bf16x8*)(w + k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += (float)x[e] * (float)ww[e];
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 16);
+    if (sub == 0) {
+      float v = acc + b;
+      if (ACT == 1) v = fmaxf(v, 0.f);
+      if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+      if (ACT == 3) v = (1.f / (1.f + expf(-v))) * (1.f + 2.f * act_param) - act_param;
+      out[(size_t)m * ldo] = v;
+    }
+  }
+}
+}  // namespace mip360
+
 template <int ACT, int WM, int WN, int FM, int FN, int NBUF>
 static void launch_ring(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                         float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux, void* mask, int ldmask) {
@@ -834,6 +866,19 @@ void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, in
                           void* mask, int ldmask) {
   static const bool exp_nomask = getenv("MIP360_EXP_NOMASK") != nullptr;       // timing experiment: dX without its ReLU mask
   if (exp_nomask && (act == 4 || act == 6)) act = 0;
+  static const bool no_rowdot = getenv("MIP360_NO_ROWDOT") != nullptr;
+  if (N == 1 && C32 && !C16 && act >= 0 && act <= 3 && K % 8 == 0 && !no_rowdot) {        // single column: row dot product
+    using namespace mip360;
+    const int blocks = M / 16 < 4096 ? (M + 15) / 16 : 4096;
+#define MIP360_ROWDOT(ACT_) hipLaunchKernelGGL((rowdot_bf16_kernel<ACT_>), dim3(blocks), dim3(256), 0, st, M, K, (const __bf16*)A, lda, \
+                                               (const __bf16*)W, bias, act_param, C32, ldc32)
+    if (act == 1) MIP360_ROWDOT(1);
+    else if (act == 2) MIP360_ROWDOT(2);
+    else if (act == 3) MIP360_ROWDOT(3);
+    else MIP360_ROWDOT(0);
+#undef MIP360_ROWDOT
+    return;
+  }
 #define MIP360_LINEAR_CASE(ACT_) \
   launch_linear_t<ACT_>(st, M, N, K, A, lda, W, ldw, bias, act_param, C16, ldc, C32, ldc32, aux, ldaux, mask, ldmask)
   if (act == 1) MIP360_LINEAR_CASE(1);
