@@ -312,25 +312,42 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(int64_t n, int ksplit, co
 }
 
 // One output column (the density head's kernel gradient, d kernel[i] = sum_m H[m][i] dz[m]): a column dot product that
-// streams H once instead of an MFMA tile with 127 idle columns.  Block = (row slice, group of 64 input columns); a thread
-// owns 8 columns (one 16-byte load per row: a row of the block is one 128-byte line) of every 32nd row of the slice;
-// float32 accumulation, the 32 row-threads of a column are combined through LDS in a fixed order.  Slabs as the MFMA
-// kernels write them: slabs[slice][i], bias slabs [slice] = sum_m dz[m].
+// streams H once instead of an MFMA tile with 127 idle columns.  Block = (row slice, group of 256 input columns); a thread
+// owns 8 columns (16 bytes) of every 8th row of the slice, so a row of the block is 512 contiguous bytes (64-column
+// groups, one cache line per row, ran at half the rate: 82 us); four rows in flight per thread; float32 accumulation, the 8
+// row-threads of a column are combined through LDS in a fixed order.  Slabs as the MFMA kernels write them:
+// slabs[slice][i], bias slabs [slice] = sum_m dz[m].
 __global__ __launch_bounds__(256) void grad_weight_col_kernel(int M, int I, const __bf16* __restrict__ H, int ldh,
                                                               const __bf16* __restrict__ dZ, int lddz, int ksplit,
                                                               float* __restrict__ slabs, int ldc, float* __restrict__ bias_slabs) {
-  __shared__ float part[32][65];
-  __shared__ float bpart[32];
-  const int cgroups = (I + 63) / 64;
+  __shared__ float part[8][257];
+  __shared__ float bpart[8];
+  const int cgroups = (I + 255) / 256;
   const int slice = blockIdx.x / cgroups, cg = blockIdx.x - slice * cgroups;
-  const int sub = threadIdx.x & 7, rt = threadIdx.x >> 3;             // 8 threads x 8 columns per row, 32 rows per pass
+  const int sub = threadIdx.x & 31, rt = threadIdx.x >> 5;            // 32 threads x 8 columns per row, 8 rows per pass
   const int64_t per = ((int64_t)M + ksplit - 1) / ksplit;
   const int64_t r_begin = (int64_t)slice * per, r_end = r_begin + per < M ? r_begin + per : M;
-  const int col = cg * 64 + sub * 8;
+  const int col = cg * 256 + sub * 8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   if (col < I) {
-    for (int64_t m = r_begin + rt; m < r_end; m += 32) {
+    int64_t m = r_begin + rt;
+    for (; m + 24 < r_end; m += 32) {
+      bf16x8 h[4];
+      float z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        h[u] = *(const bf16x8*)(H + (size_t)(m + 8 * u) * ldh + col);
+        z[u] = (float)dZ[(size_t)(m + 8 * u) * lddz];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)h[u][e] * z[u];
+        bsum += z[u];
+      }
+    }
+    for (; m < r_end; m += 8) {
       const float z = (float)dZ[(size_t)m * lddz];
       const bf16x8 h = *(const bf16x8*)(H + (size_t)m * ldh + col);
 #pragma unroll
@@ -342,15 +359,15 @@ __global__ __launch_bounds__(256) void grad_weight_col_kernel(int M, int I, cons
   for (int e = 0; e < 8; ++e) part[rt][sub * 8 + e] = acc[e];
   if (sub == 0) bpart[rt] = bsum;
   __syncthreads();
-  if (threadIdx.x < 64) {
+  {
     float t = 0.f;
-    for (int r = 0; r < 32; ++r) t += part[r][threadIdx.x];
-    const int i = cg * 64 + threadIdx.x;
+    for (int r = 0; r < 8; ++r) t += part[r][threadIdx.x];
+    const int i = cg * 256 + threadIdx.x;
     if (i < I) slabs[(size_t)slice * I * ldc + (size_t)i * ldc] = t;
   }
-  if (bias_slabs && cg == 0 && threadIdx.x == 64) {
+  if (bias_slabs && cg == 0 && threadIdx.x == 0) {
     float t = 0.f;
-    for (int r = 0; r < 32; ++r) t += bpart[r];
+    for (int r = 0; r < 8; ++r) t += bpart[r];
     bias_slabs[slice] = t;
   }
 }
@@ -502,7 +519,7 @@ void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* 
   float* bias_slabs = bias_out ? slabs + (size_t)ksplit * n : nullptr;            // [ksplit][O] after the kernel slabs
   static const bool no_col = getenv("MIP360_NO_COLDOT") != nullptr;
   if (O == 1 && I % 8 == 0 && !no_col)
-    hipLaunchKernelGGL(grad_weight_col_kernel, dim3(((I + 63) / 64) * ksplit), dim3(256), 0, st, M, I, (const __bf16*)H, ldh,
+    hipLaunchKernelGGL(grad_weight_col_kernel, dim3(((I + 255) / 256) * ksplit), dim3(256), 0, st, M, I, (const __bf16*)H, ldh,
                        (const __bf16*)dZ, lddz, ksplit, slabs, ldc, bias_slabs);
   else if (mip360_grad_weight_is_wide(M, I, O, ldh, lddz))
     hipLaunchKernelGGL(grad_weight_wide_kernel, dim3((I / 256) * (O / 256) * ksplit), dim3(512), WNBUF * 2 * WOPER, st, M, I, O,

@@ -447,6 +447,8 @@ def _grad_weight(h, dz, n_in, n_out, out, scratch, bias_out=None, rows_out=None,
     ksplit = int(max(1, min(256 if tile == 256 else 64, (256 + tiles - 1) // tiles, (m + 31) // 32)))
     if ksplit >= 8 or m >= 8 * 256:
         ksplit = max(8, (ksplit // 8) * 8)            # multiples of 8: one or more whole row slices per XCD
+    if n_out == 1 and n_in % 8 == 0 and m >= 256 * 64:
+        ksplit = 256                                  # the column-dot kernel: (n_in / 256) x 256 blocks of whole 512-byte row pieces
     need = ksplit * (n_in * n_out + n_out)
     rows_out = n_in if rows_out is None else rows_out
     if side is None:
