@@ -49,7 +49,7 @@ DW_BYTES_PER_ROW = (4960 + 5024) * 2
 # HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16, from the rocprofv3 --pmc passes committed under
 # profiles/ (FETCH_SIZE x2 gfx950 wide-stream correction + WRITE_SIZE; cannot be collected inside this process)
 PMC_TRAFFIC = {
-    'source': 'profiles/r02_g_kernel_stats_timeline_hbm.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; identical in r02_f)',
+    'source': 'profiles/r02_h_kernel_stats_timeline_hbm.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; identical in r02_f / r02_g)',
     'dw_L1': (2 * 1.5 * (917.6e6 + 356.3e6)) + 1.5 * (64.7e6 + 23.1e6),
     'mlp_fwd_L1': 1.5 * (2 * (10.63e6 + 14.72e6) + 620.6e6 + 641.4e6),
     'mlp_bwd_L1': 1.5 * (2 * (29.09e6 + 29.38e6) + 583.4e6 + 583.7e6),
