@@ -285,6 +285,12 @@ def main():
         res['bf16'] = run_mode(args, L.PREC_BF16, rank, world, device, batches)
     if args.precision in ('both', 'split'):
         res['split'] = run_mode(args, L.PREC_SPLIT_BF16, rank, world, device, batches)
+    m360 = None
+    if world > 1 and args.mip360_rays > 0:
+        # BASELINE configs[4] is an 8-GPU configuration: the MipNeRF-360 step data-parallel over the same ranks
+        # (per-rank rays, gradients averaged over RCCL); every rank takes part, rank 0 reports
+        from outdoor_nerf_depth_amd import mip360
+        m360 = mip360.benchmark_step(device, args.mip360_rays, steps=5, warmup=2, seed=rank, world_size=world)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -341,6 +347,8 @@ def main():
         # BASELINE configs[4], labelled extra: the MipNeRF-360 step on its own library (libmip360_hip.so)
         from outdoor_nerf_depth_amd import mip360
         out['config5_mip360'] = mip360.benchmark_step(device, args.mip360_rays, steps=5, warmup=2)
+    elif m360 is not None:
+        out['config5_mip360'] = m360
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

@@ -702,15 +702,19 @@ def mlp_shapes(cfg):
     return out
 
 
-def benchmark_step(device, n_rays=4096, steps=10, warmup=3, forward_only=False, seed=0):
+def benchmark_step(device, n_rays=4096, steps=10, warmup=3, forward_only=False, seed=0, world_size=1):
     """configs/360.gin shape on synthetic rays (2 x 64 proposal samples through the 4 x 256 PropMLP, 32 samples through the
     8 x 1024 NerfMLP, he_uniform weights): whole training steps (forward, losses, backward, clip, Adam, re-pack) or
-    forwards only.  Dense-layer FLOP per ray (forward) = 2 * (2 * 64 * prop MACs + 32 * nerf MACs); training = 3x."""
+    forwards only.  Dense-layer FLOP per ray (forward) = 2 * (2 * 64 * prop MACs + 32 * nerf MACs); training = 3x.
+    world_size > 1 (torch.distributed initialised by the caller): every rank runs n_rays rays of its own (seed = its
+    rank), gradients are averaged over ranks (train_utils.py:340-342), the timed region is bracketed by barriers and the
+    slowest rank's time counts; value = world_size * n_rays / that time."""
     import time
-    rs = np.random.RandomState(seed)
-    he = lambda shapes: [(rs.uniform(-np.sqrt(6.0 / i), np.sqrt(6.0 / i), (i, o)).astype(np.float32), np.zeros(o, np.float32))
+    rs_p = np.random.RandomState(0)                                   # identical parameters on every rank
+    he = lambda shapes: [(rs_p.uniform(-np.sqrt(6.0 / i), np.sqrt(6.0 / i), (i, o)).astype(np.float32), np.zeros(o, np.float32))
                          for i, o in shapes]
     prop, nerf = he(mlp_shapes(PROP_CFG)), he(mlp_shapes(NERF_CFG))
+    rs = np.random.RandomState(seed)
     n = n_rays
     d = rs.randn(n, 3).astype(np.float32)
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
@@ -720,21 +724,31 @@ def benchmark_step(device, n_rays=4096, steps=10, warmup=3, forward_only=False, 
                 far=T(np.full((n, 1), 1e6, np.float32)))
     gt = T(rs.rand(n, 3).astype(np.float32))
     sup = T(np.where(rs.rand(n) < .5, rs.uniform(1, 6, n), 0).astype(np.float32))
-    tr = Mip360Trainer(prop, nerf, device)
+    tr = Mip360Trainer(prop, nerf, device, world_size=world_size)
     macs = lambda sh: sum(i * o for i, o in sh)
     fwd_flop = 2.0 * (2 * 64 * macs(mlp_shapes(PROP_CFG)) + 32 * macs(mlp_shapes(NERF_CFG)))
     step = (lambda: tr.forward(rays, 0.5, None)) if forward_only else (lambda: tr.train_step(rays, gt, sup))
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(device)
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize(device)
+    if world_size > 1:
+        dist.barrier()
     dt = (time.perf_counter() - t0) / steps
+    if world_size > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n = n_rays * world_size
     flop = fwd_flop * (1 if forward_only else 3) * n
     return {'workload': 'MipNeRF-360 configs/360.gin shape, %d rays/step, %s, depth_loss_type=mse on distance_mean, synthetic rays'
-                        % (n, 'forward' if forward_only else 'train step'),
-            'value': n / dt, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt, 'steps': steps, 'dense_tflops': flop / dt / 1e12,
-            'frac_of_bf16_mfma_peak': flop / dt / 2.5e15, 'fwd_gflop_per_ray': fwd_flop / 1e9,
+                        % (n_rays, 'forward' if forward_only else 'train step'),
+            'n_gpus': world_size, 'rays_per_gpu': n_rays, 'value': n / dt, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt, 'steps': steps, 'dense_tflops': flop / dt / 1e12,
+            'frac_of_bf16_mfma_peak': flop / dt / 2.5e15 / world_size, 'fwd_gflop_per_ray': fwd_flop / 1e9,
             'dtype': 'bf16 MFMA operands, f32 accumulate / f32 master weights'}
