@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(int64_t n, int ksplit, co
 // One output column (the density head's kernel gradient, d kernel[i] = sum_m H[m][i] dz[m]): a column dot product that
 // streams H once instead of an MFMA tile with 127 idle columns.  Block = (row slice, group of 256 input columns); a thread
 // owns 8 columns (16 bytes) of every 8th row of the slice, so a row of the block is 512 contiguous bytes (64-column
-// groups, one cache line per row, ran at half the rate: 82 us); four rows in flight per thread; float32 accumulation, the 8
+// groups: one cache line per row); sixteen rows in flight per thread (with four the kernel was latency-bound: 78 us for either shape); float32 accumulation, the 8
 // row-threads of a column are combined through LDS in a fixed order.  Slabs as the MFMA kernels write them:
 // slabs[slice][i], bias slabs [slice] = sum_m dz[m].
 __global__ __launch_bounds__(256) void grad_weight_col_kernel(int M, int I, const __bf16* __restrict__ H, int ldh,
@@ -332,16 +332,17 @@ __global__ __launch_bounds__(256) void grad_weight_col_kernel(int M, int I, cons
   float bsum = 0.f;
   if (col < I) {
     int64_t m = r_begin + rt;
-    for (; m + 24 < r_end; m += 32) {
-      bf16x8 h[4];
-      float z[4];
+    constexpr int U = 16;                          // rows in flight per thread: a block per CU must cover ~2 us of HBM latency by itself
+    for (; m + 8 * (U - 1) < r_end; m += 8 * U) {
+      bf16x8 h[U];
+      float z[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         h[u] = *(const bf16x8*)(H + (size_t)(m + 8 * u) * ldh + col);
         z[u] = (float)dZ[(size_t)(m + 8 * u) * lddz];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += (float)h[u][e] * z[u];
         bsum += z[u];
