@@ -151,14 +151,21 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(int n, int M, int S_new
     if (lane == 0) {
       double acc = 0.0;
       for (int k = 0; k < M; ++k) acc += (double)wq[k];
-      const float wsum = (float)acc;
-      acc = 0.0;
-      cdf[0] = 0.f;
-      for (int k = 0; k < M; ++k) {
-        const float pdf = wq[k] / wsum;
-        acc += (double)pdf;
-        cdf[k + 1] = (float)acc;
-      }
+      cdf[0] = (float)acc;                          // wsum, handed to the other lanes through LDS
+    }
+  }
+  __syncthreads();
+  if (active) {                                     // the M divisions in parallel (they were a dependent chain on lane 0) ...
+    const float wsum = cdf[0];
+    for (int k = lane; k < M; k += 64) wq[k] = wq[k] / wsum;
+  }
+  __syncthreads();
+  if (active && lane == 0) {                        // ... the running sum stays sequential float64 (= torch's CPU cumsum order)
+    double acc = 0.0;
+    cdf[0] = 0.f;
+    for (int k = 0; k < M; ++k) {
+      acc += (double)wq[k];
+      cdf[k + 1] = (float)acc;
     }
   }
   __syncthreads();
@@ -166,8 +173,15 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(int n, int M, int S_new
     for (int j = lane; j < S_new; j += 64) {
       const float u = args.rng.enabled ? philox_uniform(args.rng, 2u + blockIdx.y, (uint64_t)ray * S_new + j)
                       : u_in ? u_in[(size_t)ray * S_new + j] : torch_linspace01(j, S_new);
-      int above = 0;
-      for (int k = 0; k < M; ++k) above += (u >= cdf[k]) ? 1 : 0;
+      // above = #{k < M : u >= cdf[k]}; the cdf is non-decreasing (a running sum of non-negative terms, rounded monotonically),
+      // so the count is the position of the first entry above u: binary search instead of M comparisons
+      int above = 0, hi_ = M;
+      while (above < hi_) {
+        const int mid = (above + hi_) >> 1;
+        const bool ge = u >= cdf[mid];
+        above = ge ? mid + 1 : above;
+        hi_ = ge ? hi_ : mid;
+      }
       const int below = above - 1 > 0 ? above - 1 : 0;
       const float cdf_lo = cdf[below], cdf_hi = cdf[above];
       const float bin_lo = bins[below], bin_hi = bins[above];
