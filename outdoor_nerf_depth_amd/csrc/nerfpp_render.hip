@@ -198,6 +198,25 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(int n, int M, int S_new
   __syncthreads();
   if (active && merged_out) {
     const int S_tot = S_old + S_new;
+    if (S_tot <= 192) {
+      // up to three elements per lane ranked in ONE pass over the list (a third of the LDS reads of the per-element loop
+      // below, three independent compare chains); same comparison, same result
+      const int e0 = lane, e1 = lane + 64, e2 = lane + 128;
+      const float v0 = e0 < S_tot ? zs[e0] : 0.f, v1 = e1 < S_tot ? zs[e1] : 0.f, v2 = e2 < S_tot ? zs[e2] : 0.f;
+      int r0 = 0, r1 = 0, r2 = 0;
+#pragma unroll 4
+      for (int k = 0; k < S_tot; ++k) {
+        const float o = zs[k];
+        r0 += (o < v0 || (o == v0 && k < e0)) ? 1 : 0;
+        r1 += (o < v1 || (o == v1 && k < e1)) ? 1 : 0;
+        r2 += (o < v2 || (o == v2 && k < e2)) ? 1 : 0;
+      }
+      float* mo = merged_out + (size_t)ray * S_tot;
+      if (e0 < S_tot) mo[r0] = v0;
+      if (e1 < S_tot) mo[r1] = v1;
+      if (e2 < S_tot) mo[r2] = v2;
+      return;
+    }
     for (int e = lane; e < S_tot; e += 64) {          // rank sort: values only, stable
       const float v = zs[e];
       int rank = 0;
