@@ -46,14 +46,55 @@ SURVEY_ALGO_BYTES_PER_RAY = 18.8e3   # inputs + outputs + amortised
 # algorithmic bytes per sample row read by the weight-gradient GEMMs (every operand once per job):
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
 DW_BYTES_PER_ROW = (4960 + 5024) * 2
-# HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16, from the rocprofv3 --pmc passes committed under
-# profiles/ (FETCH_SIZE x2 gfx950 wide-stream correction + WRITE_SIZE; cannot be collected inside this process)
-PMC_TRAFFIC = {
-    'source': 'profiles/r02_h_kernel_stats_timeline_hbm.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; identical in r02_f / r02_g)',
-    'dw_L1': (2 * 1.5 * (917.6e6 + 356.3e6)) + 1.5 * (64.7e6 + 23.1e6),
-    'mlp_fwd_L1': 1.5 * (2 * (10.63e6 + 14.72e6) + 620.6e6 + 641.4e6),
-    'mlp_bwd_L1': 1.5 * (2 * (29.09e6 + 29.38e6) + 583.4e6 + 583.7e6),
+FLOP_PER_RAY_RENDER = 0.613e9    # forward only, both levels
+# HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16: PARSED at start-up from the rocprofv3 --pmc passes committed
+# under profiles/ (they cannot be collected inside this process: separate --pmc runs, MI355X_MICROARCH.md "HBM").  The
+# field is named `traffic_from_profile`-style in the output (`traffic_source`), it is not a live measurement.
+PMC_PROFILE = os.path.join('profiles', 'r03_final_kernel_stats_timeline_hbm.md')
+PMC_PROFILE_FALLBACK = os.path.join('profiles', 'r02_h_kernel_stats_timeline_hbm.md')
+PMC_GROUPS = {            # launch group -> kernel-name prefix of its bf16 training instantiations (both nets / both launches)
+    'dw_L1': 'dw_kernel<1,',
+    'mlp_fwd_L1': 'mlp_fwd_kernel<',
+    'mlp_bwd_L1': 'mlp_bwd_kernel<',
 }
+
+
+def load_pmc_traffic():
+    """{'source': file, group: bytes per level-1 launch group} from the `## kernel (dispatches: n)` / `FETCH_SIZE avg x`
+    blocks (KB) that tools/rocpd_pmc.py wrote into the round's profile.  Per dispatch: 2 x FETCH_SIZE (gfx950 counts 64 B
+    per 128-B request of a wide stream) + WRITE_SIZE; the file averages level-0 and level-1 dispatches (rows 1 : 3), so a
+    level-1 launch is 1.5 x the average.  Returns None when no profile is there (then `traffic` is null)."""
+    import re
+    for rel in (PMC_PROFILE, PMC_PROFILE_FALLBACK):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        per = {}
+        name = None
+        for line in open(path):
+            m = re.match(r'^## (.+?)\s+\(dispatches: \d+\)', line)
+            if m:
+                name = m.group(1)
+                continue
+            m = re.match(r'^\s+(FETCH_SIZE|WRITE_SIZE)\s+avg\s+([0-9.eE+-]+)', line)
+            if m and name:
+                per.setdefault(name, {})[m.group(1)] = float(m.group(2)) * 1e3
+        out = {'source': rel + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, parsed at start-up)', 'kernels': {}}
+        for grp, prefix in PMC_GROUPS.items():
+            if grp == 'dw_L1':                    # dw_kernel<1, true> (256 x 256 jobs) + dw_kernel<1, false> (narrow jobs)
+                ks = [k for k in per if k.startswith(prefix)]
+            else:                                 # <net, P = 1, 8 waves[, TRAIN = true]>: the bf16 training instantiations
+                ks = [k for k in per if k.startswith(prefix) and ', 1, 8' in k and not k.endswith('false>')]
+            ks = [k for k in ks if 'FETCH_SIZE' in per[k] and 'WRITE_SIZE' in per[k]]
+            if not ks:
+                return None
+            out[grp] = 1.5 * sum(2.0 * per[k]['FETCH_SIZE'] + per[k]['WRITE_SIZE'] for k in ks)
+            out['kernels'][grp] = sorted(ks)
+        return out
+    return None
+
+
+PMC_TRAFFIC = load_pmc_traffic()
 
 
 def parse():
@@ -71,8 +112,9 @@ def parse():
     p.add_argument('--depth_loss_type', default='mse', choices=['mse', 'l1', 'kl'])
     p.add_argument('--lambda_depth', type=float, default=0.1)
     p.add_argument('--cpu_rays', type=int, default=1024, help='N_rand of the CPU baseline (SURVEY 8d: 1024)')
-    p.add_argument('--cpu_budget_s', type=float, default=100.0,
-                   help='stop adding timed CPU steps once this much wall time is spent (>= 2 timed steps always run)')
+    p.add_argument('--render_frames', type=int, default=1,
+                   help='375x1242 frames rendered per precision by the inference leg (`render`; 0 = skip)')
+    p.add_argument('--render_chunk', type=int, default=8192, help='rays per render chunk (ddp_train_nerf.py --chunk_size)')
     return p.parse_args()
 
 
@@ -99,9 +141,29 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
-        raise SystemExit('bench.py --gpus %d: rank exit codes %r' % (n, rcs))
+    # poll: as soon as one rank exits non-zero the others are terminated (a dead rank would otherwise leave the rest
+    # blocked in an RCCL collective until its timeout, and the bench would hang instead of failing loudly)
+    rcs = [None] * n
+    deadline = time.time() + float(os.environ.get('NERFPP_BENCH_TIMEOUT_S', '1800'))
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        failed = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed or time.time() > deadline:
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            raise SystemExit('bench.py --gpus %d: %s; rank exit codes %r' %
+                             (n, 'rank(s) %r failed' % failed if failed else 'timed out', rcs))
+        time.sleep(0.2)
 
 
 def run_mode(args, precision, rank, world, device, batches):
@@ -171,10 +233,15 @@ def run_mode(args, precision, rank, world, device, batches):
             k['gbs'] = k['bytes'] / (k['ms'] * 1e-3) / 1e9
     # share of a step: every group also runs once at level 0 on a third of the rows
     share = {k: v['ms'] * (1 + 64.0 / 192) for k, v in kernels.items()}
-    dominant = max(share, key=share.get)
+    # deterministic choice: groups within 2 % of the largest share count as tied and the tie goes to a fixed order
+    # (forward, dX chain, weight gradients), so the reported kernel does not flip on timing noise; all tied groups are named
+    order = ('mlp_fwd_L1', 'mlp_bwd_L1', 'dw_L1')
+    top = max(share.values())
+    tied = [k for k in order if share[k] >= 0.98 * top]
+    dominant = tied[0]
     return dict(elapsed=elapsed, ms_per_step=1e3 * elapsed / K, value=n * K * world / elapsed, loss=loss,
-                value_per_gpu=n * K / elapsed, kernels=kernels, dominant=dominant, share_ms=share,
-                pmc_ok=(n == 1024 and precision == 1))
+                value_per_gpu=n * K / elapsed, kernels=kernels, dominant=dominant, co_dominant=tied, share_ms=share,
+                pmc_ok=(n == 1024 and precision == 1 and PMC_TRAFFIC is not None))
 
 
 def roofline(r):
@@ -191,9 +258,16 @@ def roofline(r):
     traffic = PMC_TRAFFIC.get(r['dominant']) if r['pmc_ok'] else None
     dw = r['kernels']['dw_L1']
     step_traffic = sum(PMC_TRAFFIC[k] for k in ('dw_L1', 'mlp_fwd_L1', 'mlp_bwd_L1')) * (1 + 64.0 / 192) if r['pmc_ok'] else None
-    return {'bound': 'mfma', 'kernel': r['dominant'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': traffic, 'launch_ms': dom['ms'],
-            'traffic_source': PMC_TRAFFIC['source'] if traffic else None,
+    # the MLP kernels are priced against the dense bf16 MFMA peak; when the weight-gradient GEMMs are the (strictly)
+    # dominant group the bound that applies to THEM is HBM (every operand streamed once), and that view is reported
+    if r['dominant'] == 'dw_L1':
+        head = {'bound': 'hbm', 'achieved': dw['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': dw['gbs'] / PEAK_HBM_GBS}
+    else:
+        head = {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': dom['tflops'] / PEAK_BF16_TFLOPS}
+    head.update({'kernel': r['dominant'], 'co_dominant_within_2pct': r['co_dominant'], 'traffic': traffic,
+                 'launch_ms': dom['ms'], 'traffic_source': PMC_TRAFFIC['source'] if traffic else None})
+    return {**head,
             'whole_step': {'tflops': tfl, 'frac_of_bf16_mfma_peak': tfl / PEAK_BF16_TFLOPS,
                            'hbm_traffic_bytes_per_step': step_traffic,
                            'traffic_over_survey_algorithmic_bytes':
@@ -217,23 +291,74 @@ def cpu_baseline(args):
                             lambda_depth=args.lambda_depth)
     scene = SyntheticKitti(depth_sup_type=args.depth_sup_type)
     rng = np.random.RandomState(777)
-    times, t_start = [], time.perf_counter()
-    n_warm, n_timed = 2, 5
+    times = []
+    n_warm, n_timed = 2, 5                        # median of >= 5 steps after 2 warm-ups -- always run in full
     for step in range(n_warm + n_timed):
         b = scene.random_batch(n, rng)
         uni = O.step_uniforms(777, step + 1, n, 64, 128)
         t0 = time.perf_counter()
         tc.train_step(b, uni)
         times.append(time.perf_counter() - t0)
-        if step >= n_warm + 1 and time.perf_counter() - t_start > args.cpu_budget_s:
-            break
-    timed = times[n_warm:] if len(times) > n_warm else times[-1:]
+    timed = times[n_warm:]
     t = float(np.median(timed))
-    return dict(value=n / t, unit='rays/s', cores=torch.get_num_threads(), kind='port',
-                host_logical_cpus=os.cpu_count(), s_per_step=t,
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    print('cpu_baseline: %s, nproc=%d, torch threads=%d, s/step %s' %
+          (model, os.cpu_count(), torch.get_num_threads(), ['%.2f' % x for x in times]), file=sys.stderr, flush=True)
+    return dict(value=n / t, unit='rays/s', cores=torch.get_num_threads(), kind='port', cpu_model=model,
+                host_logical_cpus=os.cpu_count(), s_per_step=t, s_per_step_all=[round(x, 3) for x in timed],
                 sample='N_rand=%d rays/step, %d warm-up + %d timed steps (median), both levels fwd+bwd+Adam, float32 '
                        'PyTorch-CPU restatement (oracle/nerfpp_torch_cpu.py), torch threads = %d'
-                       % (n, min(n_warm, len(times) - len(timed)), len(timed), torch.get_num_threads()))
+                       % (n, n_warm, len(timed), torch.get_num_threads()))
+
+
+def render_leg(args, device, precision, label):
+    """SURVEY 8 f-2, the inference half of the metric: `render_single_image` (ddp_train_nerf.py:133-249) on one
+    375x1242 frame -- deterministic sampling, both cascade levels (64 + 128 samples), fg + bg nets, chunked -- timed as the
+    reference runs it (host loop, H2D of the frame's rays, D2H of every output map included), plus the time inside the MLP
+    kernels alone from HIP events the library records around them on the launch stream (north_star's ">= 40 % bf16-MFMA
+    utilisation in the MLP kernel" is THIS number: the same kernels as training without the saved-tensor stores)."""
+    import torch
+    from outdoor_nerf_depth_amd.data_loader_split import synthetic_ray_samplers
+    from outdoor_nerf_depth_amd.ddp_train_nerf import render_single_image
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer, ALGO_MACS
+    sampler = synthetic_ray_samplers('test', 1, 'gt', 20, 375, 1242)[0]
+    tr = NerfppTrainer(device, precision=precision, use_depth=False)
+    render_single_image(0, 1, tr, sampler, args.render_chunk, keep_dists=False)      # warm-up
+    torch.cuda.synchronize()
+    taps = []
+    t0 = time.perf_counter()
+    for _ in range(args.render_frames):
+        out = render_single_image(0, 1, tr, sampler, args.render_chunk, keep_dists=False, mlp_events=taps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.render_frames
+    assert bool(torch.isfinite(out[-1]['rgb']).all()), 'non-finite rendered frame'
+    n = sampler.H * sampler.W
+    macs = ALGO_MACS['fwd'][0] + ALGO_MACS['fwd'][1]
+    lv = {}
+    for m in (0, 1):
+        ms = sum(b.elapsed_time(e) for (mm, _, b, e) in taps if mm == m) / args.render_frames
+        rows = sum(r for (mm, r, _, _) in taps if mm == m) / args.render_frames
+        tf = 2.0 * macs * rows / (ms * 1e-3) / 1e12
+        lv['mlp_fwd_infer_L%d' % m] = {'ms_per_frame': round(ms, 3), 'rows': int(rows), 'tflops': round(tf, 1),
+                                       'frac_of_bf16_mfma_peak': round(tf / PEAK_BF16_TFLOPS, 4)}
+    mlp_ms = sum(v['ms_per_frame'] for v in lv.values())
+    mlp_tf = n * FLOP_PER_RAY_RENDER / (mlp_ms * 1e-3) / 1e12
+    tf = n * FLOP_PER_RAY_RENDER / dt / 1e12
+    return {'dtype': label, 'frame': '%dx%d' % (sampler.H, sampler.W), 'chunk': args.render_chunk,
+            'frames_timed': args.render_frames, 's_per_frame': dt, 'rays_per_s': n / dt, 'algorithmic_tflops': tf,
+            'frac_of_bf16_mfma_peak': tf / PEAK_BF16_TFLOPS,
+            'mlp_kernels': {'ms_per_frame': round(mlp_ms, 3), 'tflops': round(mlp_tf, 1),
+                            'frac_of_bf16_mfma_peak': round(mlp_tf / PEAK_BF16_TFLOPS, 4), **lv},
+            'note': 's_per_frame is the whole render_single_image call (host loop, H2D of rays, D2H of 7 output maps per '
+                    'level); mlp_kernels is HIP-event time inside the MLP launches only (executed MFMA work is 3x the '
+                    'algorithmic figure in split-bf16)'}
 
 
 def main():
@@ -349,6 +474,12 @@ def main():
         out['config5_mip360'] = mip360.benchmark_step(device, args.mip360_rays, steps=5, warmup=2)
     elif m360 is not None:
         out['config5_mip360'] = m360
+    if world == 1 and args.render_frames > 0:
+        out['render'] = {'metric': 'render rays/sec, one 375x1242 frame, 64+128 samples/ray, deterministic sampling '
+                                   '(render_single_image, ddp_train_nerf.py:133-249)',
+                         'bf16': render_leg(args, device, L.PREC_BF16, 'bf16 MFMA operands, f32 accumulate')}
+        if args.precision == 'both':
+            out['render']['split_bf16'] = render_leg(args, device, L.PREC_SPLIT_BF16, 'split-bf16 (hi+lo, 3 MFMA passes): 1e-4 parity mode')
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

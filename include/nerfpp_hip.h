@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERFPP_ABI_VERSION 3
+#define NERFPP_ABI_VERSION 4
 
 #define NERFPP_OK 0
 #define NERFPP_ERR_ARG 1          /* bad argument (null pointer, size out of range) */
@@ -227,10 +227,14 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* args);
  * after the backward call (stream order or an event) and before anything that overwrites `workspace`. */
 int nerfpp_level_reduce_grads(void* stream, const nerfpp_backward_args* args);
 
-/* torch.optim.Adam single step (ddp_train_nerf.py:324,498); step is the 1-based step count */
+/* torch.optim.Adam single step (ddp_train_nerf.py:324,498); step is the 1-based step count.
+ * skip_if_nonzero: NULL, or a device float; when it is != 0 at execution time the call changes nothing.  The
+ * reference raises BEFORE the optimiser step when a camera lies outside the unit sphere (:62-63); a caller that
+ * reads the bad-camera count later (asynchronously) passes it here -- summed over the ranks with the gradient
+ * all-reduce -- so that a poisoned gradient never reaches the parameters or the Adam moments. */
 int nerfpp_adam_step(void* stream, float* params, const float* grads, float* exp_avg,
                      float* exp_avg_sq, int64_t n, int step, double lr, double beta1, double beta2,
-                     double eps);
+                     double eps, const float* skip_if_nonzero);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hip.so')   # override: diagnostic builds
 
 OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2
 PREC_SPLIT_FWD = 3        # host-side combination: split-bf16 forward, bf16 backward (ops.LevelEngine)
 LOSS_RGB_ONLY, LOSS_MSE, LOSS_L1, LOSS_KL = 0, 1, 2, 3
@@ -70,7 +70,7 @@ SYMBOLS = {
     'nerfpp_level_backward': (C.c_int, [_fp, C.POINTER(BackwardArgs)]),
     'nerfpp_level_reduce_grads': (C.c_int, [_fp, C.POINTER(BackwardArgs)]),
     'nerfpp_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_double, C.c_double,
-                                   C.c_double, C.c_double]),
+                                   C.c_double, C.c_double, _fp]),
 }
 
 _lib = None

@@ -11,6 +11,7 @@
 // so an MFMA fragment is one 16-byte LDS read per lane (row l & 31, k offset 8 * (l >> 5)); LDS rows are padded to
 // 80 bytes.  The next K tile is fetched into registers while the current one is multiplied (one __syncthreads per K
 // step).
+#include "probe_env.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -835,9 +836,9 @@ static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, 
                             float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux, void* mask,
                             int ldmask) {
   using namespace mip360;
-  static const bool force_small = getenv("MIP360_GEMM_SMALL") != nullptr;
-  static const bool no_ring = getenv("MIP360_GEMM_NORING") != nullptr;
-  static const char* ring_env = getenv("MIP360_GEMM_RING");     // probes: 1 = lock-step ring kernel everywhere, 4 = 4-wave 256 x 128
+  static const bool force_small = PROBE_GETENV("MIP360_GEMM_SMALL") != nullptr;
+  static const bool no_ring = PROBE_GETENV("MIP360_GEMM_NORING") != nullptr;
+  static const char* ring_env = PROBE_GETENV("MIP360_GEMM_RING");     // probes: 1 = lock-step ring kernel everywhere, 4 = 4-wave 256 x 128
   static const int ring_kind = ring_env ? atoi(ring_env) : 0;
   constexpr bool MASKED = ACT == 5 || ACT == 6;                 // bit-mask variants exist in the ring kernels only
   if (MASKED || (N >= 192 && M >= 256 && !force_small && !no_ring)) {
@@ -864,9 +865,9 @@ static void launch_linear_t(hipStream_t st, int M, int N, int K, const void* A, 
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                           int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux,
                           void* mask, int ldmask) {
-  static const bool exp_nomask = getenv("MIP360_EXP_NOMASK") != nullptr;       // timing experiment: dX without its ReLU mask
+  static const bool exp_nomask = PROBE_GETENV("MIP360_EXP_NOMASK") != nullptr;       // timing experiment: dX without its ReLU mask
   if (exp_nomask && (act == 4 || act == 6)) act = 0;
-  static const bool no_rowdot = getenv("MIP360_NO_ROWDOT") != nullptr;
+  static const bool no_rowdot = PROBE_GETENV("MIP360_NO_ROWDOT") != nullptr;
   if (N == 1 && C32 && !C16 && act >= 0 && act <= 3 && K % 8 == 0 && !no_rowdot) {        // single column: row dot product
     using namespace mip360;
     const int blocks = M / 16 < 4096 ? (M + 15) / 16 : 4096;

@@ -9,6 +9,7 @@
 //     ds_read_b64_tr_b16 transposed reads of row-major [32 rows][128 cols] LDS tiles, as in the NeRF++ dw_kernel.
 //     Split-K: blockIdx = (tile_i, tile_o, slice); every slice writes its own f32 slab and a second kernel sums the
 //     slabs in a fixed order (deterministic, no atomics).
+#include "probe_env.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -515,7 +516,7 @@ using namespace mip360;
 
 // the 256 x 256-tile kernel needs whole tiles, whole 32-row chunks and 16-byte aligned rows
 bool mip360_grad_weight_is_wide(int M, int I, int O, int ldh, int lddz) {
-  static const bool off = getenv("MIP360_DW_NARROW") != nullptr;
+  static const bool off = PROBE_GETENV("MIP360_DW_NARROW") != nullptr;
   return !off && M % 32 == 0 && M >= 256 && I % 256 == 0 && O % 256 == 0 && ldh % 8 == 0 && lddz % 8 == 0;
 }
 void mip360_launch_grad_weight_reduce(hipStream_t st, int rows, int I_slab, int O, int ksplit, const float* slabs, float* out, int ldc,
@@ -526,7 +527,7 @@ void mip360_launch_grad_weight(hipStream_t st, int M, int I, int O, const void* 
   const size_t lds = 4 * GK * GROWB;
   const int64_t n = (int64_t)I * ldc;
   float* bias_slabs = bias_out ? slabs + (size_t)ksplit * n : nullptr;            // [ksplit][O] after the kernel slabs
-  static const bool no_col = getenv("MIP360_NO_COLDOT") != nullptr;
+  static const bool no_col = PROBE_GETENV("MIP360_NO_COLDOT") != nullptr;
   if (O == 1 && I % 8 == 0 && !no_col)
     hipLaunchKernelGGL(grad_weight_col_kernel, dim3(((I + 255) / 256) * ksplit), dim3(256), 0, st, M, I, (const __bf16*)H, ldh,
                        (const __bf16*)dZ, lddz, ksplit, slabs, ldc, bias_slabs);

@@ -1,4 +1,5 @@
 // extern "C" entry points of libnerfpp_hip.so (declared in include/nerfpp_hip.h).
+#include "probe_env.h"
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -117,7 +118,7 @@ bool prec_ok(int P) { return P == NERFPP_PREC_BF16 || P == NERFPP_PREC_SPLIT_BF1
 // stream with events, so its workgroups fill CUs as the foreground's tail frees them.
 struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
 SideStream* side_stream() {
-  static const bool enabled = getenv("NERFPP_OVERLAP_NETS") ? atoi(getenv("NERFPP_OVERLAP_NETS")) != 0 : false;
+  static const bool enabled = PROBE_GETENV("NERFPP_OVERLAP_NETS") ? atoi(PROBE_GETENV("NERFPP_OVERLAP_NETS")) != 0 : false;
   if (!enabled) return nullptr;
   static SideStream table[16];
   int dev = 0;
@@ -359,7 +360,7 @@ static void weight_grads(hipStream_t st, const nerfpp_backward_args* a, const Ws
 }
 // experiment (NERFPP_DEFER_DW=1): with defer_reduce the weight-gradient GEMMs move to the deferred half as well
 static bool defer_dw() {
-  static const bool on = getenv("NERFPP_DEFER_DW") != nullptr;
+  static const bool on = PROBE_GETENV("NERFPP_DEFER_DW") != nullptr;
   return on;
 }
 
@@ -436,9 +437,10 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
 }
 
 int nerfpp_adam_step(void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                     int64_t n, int step, double lr, double beta1, double beta2, double eps) {
+                     int64_t n, int step, double lr, double beta1, double beta2, double eps,
+                     const float* skip_if_nonzero) {
   REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "non-null pointers, step >= 1");
-  launch_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps);
+  launch_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, skip_if_nonzero);
   return check_launch("adam_step");
 }
 

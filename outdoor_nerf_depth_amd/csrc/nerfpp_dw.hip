@@ -24,6 +24,7 @@
 //   * bias gradients: VALU column sums of the A fragments, split over the waves that share them.
 // Rows beyond `rows` up to the next multiple of 32 are zero in every saved tensor (the MLP kernels
 // zero-fill their tile tails), so no masking is needed.
+#include "probe_env.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -399,7 +400,7 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   dim3 gfull(sf.wg_end[sf.njobs - 1]), gnarrow(sn.wg_end[sn.njobs - 1]);
   dim3 block(512);
   const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;
-  static const int dbg = getenv("NERFPP_DW_DEBUG") ? atoi(getenv("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
+  static const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
   if (P == 1) {
     hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);
     hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg, (uint32_t)lds);

@@ -86,4 +86,4 @@ void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_
                          float* grads_lvl);
 void launch_remap_fixup(hipStream_t st, float* grads_lvl, const float* params_lvl, const float* m0, const float* m1);
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
-                 double beta1, double beta2, double eps);
+                 double beta1, double beta2, double eps, const float* skip);

@@ -82,9 +82,12 @@ __global__ void unpack_grads_kernel(UnpackArgs a, float scale, float* __restrict
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
-                            float step_size, float sqrt_bias2, float eps) {
+                            float step_size, float sqrt_bias2, float eps, const float* __restrict__ skip) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // device-side predicate (nerfpp_adam_step: skip_if_nonzero): the reference raises BEFORE the step when a camera is
+  // outside the unit sphere (ddp_train_nerf.py:62-63); here that count is read later, so the update must not happen
+  if (skip != nullptr && *skip != 0.f) return;
   const float gi = g[i];
   float mi = m[i], vi = v[i];
   mi = mi + (gi - mi) * one_minus_b1;                   // exp_avg.lerp_(grad, 1 - beta1)
@@ -185,11 +188,11 @@ void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_
   hipLaunchKernelGGL(unpack_grads_kernel, dim3((LEVEL_PARAMS + 255) / 256), dim3(256), 0, st, a, scale, grads_lvl);
 }
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
-                 double beta1, double beta2, double eps) {
+                 double beta1, double beta2, double eps, const float* skip) {
   const double bias1 = 1.0 - pow(beta1, step), bias2 = 1.0 - pow(beta2, step);
   const float step_size = (float)(lr / bias1);
   const float sqrt_bias2 = (float)sqrt(bias2);
   // 1 - beta is formed in double like Python does, then rounded once (1.f - 0.9f != (float)0.1)
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
-                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, sqrt_bias2, (float)eps);
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, sqrt_bias2, (float)eps, skip);
 }

@@ -165,11 +165,13 @@ def validate_args(args):
 
 
 # ------------------------------------------------------------------------------------------------
-def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size, keep_dists=True):
+def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size, keep_dists=True, mlp_events=None):
     """ddp_train_nerf.py:133-249: deterministic sampling, no perturbation, chunked, sharded over ranks
     (ragged last shard instead of raising when H*W % world_size != 0).  Returns, per level, every key of
     `ret` except the two weight tensors, in the reference's order (:210-218) -- including `fg_dists`
-    [H, W, S] (0.36 GB per 375x1242 frame at S = 192; keep_dists=False drops it for timing runs)."""
+    [H, W, S] (0.36 GB per 375x1242 frame at S = 192; keep_dists=False drops it for timing runs).
+    mlp_events: optional list; (level, rows, begin, end) HIP-event taps around the MLP kernels (fg + bg) of every
+    chunk are appended to it (bench.py's inference leg reads them after a synchronise)."""
     import torch
     from . import ops
     from .dist_utils import shard_sizes, gather_ragged
@@ -193,7 +195,12 @@ def render_single_image(rank, world_size, trainer, ray_sampler, chunk_size, keep
         for m, eng in enumerate(trainer.engines):
             if m > 0:
                 fg_z, bg_z = ops.sample_fine_pair(fg_z, ret['fg_weights'], bg_z, ret['bg_weights'], S1, det=True)
-            ret = eng.forward(o, d, far, fg_z, bg_z, training=False)
+            ev = None
+            if mlp_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(); ev[1].record()            # materialise the hipEvent_t handles
+                mlp_events.append((m, int(o.shape[0]) * int(fg_z.shape[1]), ev[0], ev[1]))
+            ret = eng.forward(o, d, far, fg_z, bg_z, training=False, events=ev)
             for k in keys:
                 out[m][k].append(ret[k])
     merged = []
@@ -212,6 +219,7 @@ def save_checkpoint(path, trainer, global_step):
     import torch
     from .model import state_dict_from_flat, adam_state_dict
     trainer.flush()
+    trainer.check_cameras()                       # never write (and later auto-reload) a checkpoint of a poisoned run
     to_save = OrderedDict()
     for m, eng in enumerate(trainer.engines):
         to_save['net_%d' % m] = OrderedDict((k, v.clone().cpu()) for k, v in
@@ -379,6 +387,9 @@ def ddp_train_nerf(rank, args):
             scalars_to_log = OrderedDict([('resolution', ray_samplers[0].resolution_level)])
             for m, sc in enumerate(scalars):
                 sc = sc.cpu().numpy()
+                if not np.isfinite(sc[:2]).all():
+                    raise FloatingPointError('non-finite loss at step %d, level %d: loss=%r rgb_loss=%r (check the '
+                                             'scene normalisation / input data)' % (global_step, m, sc[0], sc[1]))
                 if args.use_depth:
                     scalars_to_log['level_{}/loss_depth'.format(m)] = float(sc[2])
                 if trainer.last_autoexpo[m] is not None:
@@ -402,6 +413,7 @@ def ddp_train_nerf(rank, args):
             if rank == 0:
                 os.makedirs(out_dir, exist_ok=True)
             psnrs, rmses, abs_rels = [], [], []
+            trainer.check_cameras()
             for idx, sampler in enumerate(val_ray_samplers):
                 ret = render_single_image(rank, world, trainer, sampler, args.chunk_size, keep_dists=False)   # fg_dists is never read below
                 if rank != 0:

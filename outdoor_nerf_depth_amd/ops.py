@@ -326,7 +326,10 @@ def loss_and_grads(ret, rgb_gt, depth_sup=None, loss_type='rgbonly', lambda_dept
     return scalars, g_rgb, g_depth, g_w
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8):
-    """torch.optim.Adam(lr) single step on flat tensors, in place (ddp_train_nerf.py:324,498)."""
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, skip=None):
+    """torch.optim.Adam(lr) single step on flat tensors, in place (ddp_train_nerf.py:324,498).
+    skip: optional float32 device tensor [1]; the update is dropped on the device when it is non-zero."""
+    if skip is not None and (skip.dtype != torch.float32 or not skip.is_cuda):
+        raise L.NerfppError('adam_step: skip must be a float32 device tensor')
     L.check(L.lib().nerfpp_adam_step(_stream(), _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq),
-                                     params.numel(), int(step), lr, beta1, beta2, eps), 'nerfpp_adam_step')
+                                     params.numel(), int(step), lr, beta1, beta2, eps, _p(skip)), 'nerfpp_adam_step')

@@ -43,10 +43,17 @@ def trajectory(n_frames=295, length_m=250.0):
 
 def normalize_poses(c2w, target_radius=1.0):
     """colmap_runner/normalize_cam_dict.py:8-30: centre on the mean camera position and scale
-    with scale = target_radius / (1.5 * max camera distance)."""
+    with scale = target_radius / (1.5 * max camera distance).
+
+    A single camera (BASELINE config 1: one frame) has max distance 0, for which the reference's
+    `target_radius / radius` (:23-27) is a division by zero.  That case is defined here as the same
+    formula applied to a unit distance (1 m): the camera sits at the origin and
+    scale = target_radius / 1.5 (finite; metres * scale stays the depth-prior convention)."""
     centres = c2w[:, :3, 3]
     centre = centres.mean(0)
     dist = np.linalg.norm(centres - centre, axis=-1).max()
+    if not dist > 1e-9:
+        dist = 1.0
     scale = target_radius / (dist * 1.5)
     out = c2w.copy()
     out[:, :3, 3] = (centres - centre) * scale

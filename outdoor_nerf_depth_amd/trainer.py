@@ -42,7 +42,10 @@ class NerfppTrainer(object):
         self.engines = [ops.LevelEngine(p.to(self.device), precision) for p in level_params]
         self.exp_avg = [torch.zeros_like(e.params) for e in self.engines]
         self.exp_avg_sq = [torch.zeros_like(e.params) for e in self.engines]
-        self.grads = [torch.empty_like(e.params) for e in self.engines]
+        # [LEVEL_PARAMS gradient | bad-camera flag | pad]: the flag rides the gradient all-reduce (a SUM over ranks) and is
+        # the device-side predicate of the Adam step, so that NO rank applies an update computed from rays that left the
+        # unit sphere (the reference raises before the step, ddp_train_nerf.py:62-63; here the count is read later)
+        self.grads = [torch.zeros(L.LEVEL_PARAMS + 4, device=self.device) for _ in self.engines]
         self.step_count = 0
         self.seed, self.torch_rng = int(seed), bool(torch_rng)
         self.rng_step = 0                 # counter of the in-kernel RNG (not reset by checkpoint reloads of step_count)
@@ -74,6 +77,8 @@ class NerfppTrainer(object):
         1/world_size in the reduction, so a SUM all-reduce yields the mean, ddp_train_nerf.py:323), Adam, re-pack."""
         eng = self.engines[m]
         eng.reduce_grads()
+        flag = self.grads[m][L.LEVEL_PARAMS:L.LEVEL_PARAMS + 1]
+        flag.copy_(self.bad_cameras)                      # int32 count -> float, cumulative since the last check_cameras()
         if self.world_size > 1:
             import torch.distributed as dist
             if self.autoexpo is not None:
@@ -84,7 +89,8 @@ class NerfppTrainer(object):
                     self._ae_grad[m] = torch.zeros(len(self.autoexpo[m].names), 3, device=self.device)
                 dist.all_reduce(self._ae_grad[m])
             dist.all_reduce(self.grads[m])
-        ops.adam_step(eng.params, self.grads[m], self.exp_avg[m], self.exp_avg_sq[m], step, lr=self.lrate)
+        ops.adam_step(eng.params, self.grads[m][:L.LEVEL_PARAMS], self.exp_avg[m], self.exp_avg_sq[m], step, lr=self.lrate,
+                      skip=flag)
         eng.repack()
         if self._ae_grad[m] is not None:
             self.autoexpo[m].apply(self._ae_grad[m][:, :2], self._ae_grad[m][:, 2] > 0)
@@ -118,10 +124,19 @@ class NerfppTrainer(object):
 
     def check_cameras(self):
         """Raise the reference's exception (ddp_train_nerf.py:62-63) if any ray of any step since the last
-        call left the unit sphere.  Synchronises (one 4-byte D2H): call it where the loop syncs anyway --
-        the log line, checkpoints, evaluation, the end of training."""
-        if int(self.bad_cameras.item()) != 0:
+        call left the unit sphere -- on ANY rank: the count rides the gradient all-reduce, so every rank raises
+        together instead of one raising and the others blocking in the next collective.  From the first bad step
+        until this call the Adam updates are dropped on the device (adam_step(skip=...)), i.e. the parameters are
+        what they were when the reference would have raised.  Synchronises (a few bytes D2H): call it where the loop
+        syncs anyway -- the log line, checkpoints, evaluation, the end of training."""
+        bad = int(self.bad_cameras.item())
+        if self.world_size > 1 and self.step_count > 0:
+            self.flush()
+            bad += int(sum(float(g[L.LEVEL_PARAMS].item()) for g in self.grads))
+        if bad != 0:
             self.bad_cameras.zero_()
+            for g in self.grads:
+                g[L.LEVEL_PARAMS:].zero_()
             raise Exception(ops.CAMERA_ERROR)
 
     # -- one optimisation step ----------------------------------------------------------------------
@@ -178,7 +193,7 @@ class NerfppTrainer(object):
                 rows[ae_idx, 2] = 1.0
                 self._ae_grad[m] = rows
                 self.last_autoexpo[m] = ae.scale_shift(ae_idx)
-            eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m],
+            eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS],
                          events=ev['bwd'] if ev else None, defer_reduce=True)
             scalars.append(sc)
             self._update_begin(m)

@@ -11,6 +11,25 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    _forbid_nan_equal()
+
+
+def _forbid_nan_equal():
+    """np.testing.assert_allclose treats NaN == NaN as a match by default, which let a test on NaN inputs pass
+    vacuously.  Suite-wide: NaN never compares equal unless a test asks for it explicitly
+    (the empty-mask quirks are asserted with np.isnan)."""
+    import functools
+    import numpy as np
+    orig = np.testing.assert_allclose
+    if getattr(orig, '_nan_strict', False):
+        return
+
+    @functools.wraps(orig)
+    def strict(actual, desired, *args, **kw):
+        kw.setdefault('equal_nan', False)
+        return orig(actual, desired, *args, **kw)
+    strict._nan_strict = True
+    np.testing.assert_allclose = strict
 
 
 @pytest.fixture(scope='session')

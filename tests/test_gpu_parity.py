@@ -29,7 +29,7 @@ def N(t):
 
 
 def close(a, b, rtol=1e-4, atol=1e-6):
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=False)
 
 
 @pytest.fixture(scope='module')

@@ -204,10 +204,15 @@ def test_config1_rgbonly_32_coarse_samples_steps_match_oracle(ops):
     np.random.seed(3)
     for step in range(1, 4):
         b = sampler.random_sample(n)
+        for k, v in b.items():                        # the one-frame scene used to normalise to NaN poses
+            if isinstance(v, np.ndarray) and v.dtype.kind == 'f':
+                assert np.isfinite(v).all(), 'non-finite %s in the config-1 batch' % k
         bd = {k: T(np.asarray(v, np.float32)) for k, v in b.items() if isinstance(v, np.ndarray)}
         sc = tr.train_step(bd)
         uni = O.step_uniforms(seed, step, n, 32, 64)
         logs, rets = O.train_step(lv, opt, step, b, uni, cascade_samples=(32, 64), use_depth=False)
+        for m in range(2):
+            assert np.isfinite(logs[m]['loss']) and np.isfinite(N(sc[m])[:2]).all(), (step, m, logs[m], N(sc[m]))
         close(N(sc[0])[0], logs[0]['loss'], 1e-4, 0)
         close(N(sc[1])[0], logs[1]['loss'], 2e-3, 0)
         assert N(sc[0])[2] == 0 and rets[0][0]['fg_weights'].shape == (n, 32) and rets[1][0]['fg_weights'].shape == (n, 96)
@@ -215,6 +220,7 @@ def test_config1_rgbonly_32_coarse_samples_steps_match_oracle(ops):
     for m in range(2):
         now = unflat(N(tr.engines[m].params))
         for k in O.param_order():
+            assert np.isfinite(now[k]).all() and np.isfinite(lv[m][k]).all(), (m, k)
             bad = np.abs(now[k] - lv[m][k]) > 2.5e-4
             assert bad.mean() < 0.10, (m, k, bad.mean())
 
@@ -231,6 +237,12 @@ def test_config1_cli_runs(tmp_path):
     C.ddp_train_nerf(0, args)
     ck = torch.load(tmp_path / 'c1' / 'model_000002.pth', map_location='cpu', weights_only=False)
     assert ck['net_0']['module.nerf_net.fg_net.base_layers.0.0.weight'].shape == (256, 63)
+    for net in ('net_0', 'net_1'):                    # a NaN scene used to train (and checkpoint) NaN weights silently
+        for k, v in ck[net].items():
+            assert bool(torch.isfinite(v).all()), (net, k)
+    for opt in ('optim_0', 'optim_1'):
+        for st in ck[opt]['state'].values():
+            assert bool(torch.isfinite(st['exp_avg']).all()) and bool(torch.isfinite(st['exp_avg_sq']).all())
 
 
 # ------------------------------------------------------------------------------------------- error behaviour
@@ -243,9 +255,38 @@ def test_training_loop_raises_the_unit_sphere_exception(ops):
     b = SyntheticKitti().random_batch(64, np.random.RandomState(0))
     tr.train_step({k: T(v) for k, v in b.items() if isinstance(v, np.ndarray)})
     tr.check_cameras()                                              # fine
+    tr.flush()
+    before = [N(e.params).copy() for e in tr.engines]
+    mom = [N(m).copy() for m in tr.exp_avg]
     b['ray_o'][5] = np.array([3.0, 0.0, 0.0], np.float32)          # far outside, pointing away
     b['ray_d'][5] = np.array([0.0, 1.0, 0.0], np.float32)
     tr.train_step({k: T(v) for k, v in b.items() if isinstance(v, np.ndarray)})
+    good = SyntheticKitti().random_batch(64, np.random.RandomState(1))
+    tr.train_step({k: T(v) for k, v in good.items() if isinstance(v, np.ndarray)})   # a later, clean step before the check
+    tr.flush()
+    # the reference raises BEFORE the step, so neither the poisoned update nor any later one may reach the
+    # parameters or the Adam moments until the deferred check has raised (device-side predicate of the Adam kernel)
+    for m in range(2):
+        np.testing.assert_array_equal(N(tr.engines[m].params), before[m])
+        np.testing.assert_array_equal(N(tr.exp_avg[m]), mom[m])
+        assert np.isfinite(N(tr.engines[m].params)).all()
     with pytest.raises(Exception, match='bounded by the unit sphere'):
         tr.check_cameras()
     tr.check_cameras()                                              # the counter was reset
+    tr.train_step({k: T(v) for k, v in good.items() if isinstance(v, np.ndarray)})
+    tr.flush()
+    assert not np.array_equal(N(tr.engines[0].params), before[0])   # updates resume after the check
+
+
+def test_checkpoint_of_a_poisoned_run_is_refused(tmp_path):
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
+    from outdoor_nerf_depth_amd.ddp_train_nerf import save_checkpoint
+    tr = NerfppTrainer(dev(), precision=1, use_depth=False)
+    b = SyntheticKitti().random_batch(64, np.random.RandomState(0))
+    b['ray_o'][0] = np.array([0.0, 2.5, 0.0], np.float32)
+    b['ray_d'][0] = np.array([1.0, 0.0, 0.0], np.float32)
+    tr.train_step({k: T(v) for k, v in b.items() if isinstance(v, np.ndarray)})
+    with pytest.raises(Exception, match='bounded by the unit sphere'):
+        save_checkpoint(str(tmp_path / 'model_000001.pth'), tr, 1)
+    assert not (tmp_path / 'model_000001.pth').exists()
