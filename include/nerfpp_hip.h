@@ -217,6 +217,18 @@ typedef struct {
   int32_t defer_reduce;            /* != 0: stop after the weight-gradient GEMMs (their split-K slabs stay in
                                       `workspace`); the caller finishes with nerfpp_level_reduce_grads, e.g. on
                                       another stream so that it runs under the next level's forward */
+  /* Fused loss head (ABI 4).  fused_loss != 0: dL/d rgb, dL/d depth and (KL) dL/d fg_weights are formed INSIDE the
+   * compositing backward from the fields below -- the arithmetic of nerfpp_loss (ddp_train_nerf.py:481-493), so the
+   * loss launch leaves the critical path between forward and backward; g_rgb / g_depth / g_fg_weights are ignored and
+   * may be NULL.  nerfpp_loss stays the source of the logged scalars (any stream, any time after the forward). */
+  int32_t fused_loss;
+  int32_t loss_type;               /* NERFPP_LOSS_* */
+  float lambda_depth;
+  float kl_sigma;
+  const float* rgb;                /* [n,3] forward output */
+  const float* depth;              /* [n]   forward output */
+  const float* rgb_gt;             /* [n,3] */
+  const float* depth_sup;          /* [n]; NULL for NERFPP_LOSS_RGB_ONLY */
 } nerfpp_backward_args;
 
 /* loss.backward() for one level (autograd in the reference)         ddp_train_nerf.py:497 */

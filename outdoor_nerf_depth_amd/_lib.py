@@ -39,7 +39,9 @@ class BackwardArgs(C.Structure):
                                    'g_rgb', 'g_depth', 'g_fg_weights')] + \
                [('grad_scale', C.c_float), ('grads', _fp)] + \
                [(k, _fp) for k in ('ev_bwd_begin', 'ev_bwd_end', 'ev_dw_begin', 'ev_dw_end', 'params')] + \
-               [('defer_reduce', C.c_int32)]
+               [('defer_reduce', C.c_int32), ('fused_loss', C.c_int32), ('loss_type', C.c_int32),
+                ('lambda_depth', C.c_float), ('kl_sigma', C.c_float)] + \
+               [(k, _fp) for k in ('rgb', 'depth', 'rgb_gt', 'depth_sup')]
 
 
 # every symbol include/nerfpp_hip.h declares: name -> (restype, argtypes)

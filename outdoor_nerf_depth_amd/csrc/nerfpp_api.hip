@@ -402,7 +402,18 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");
   REQUIRE(prec_ok(a->precision), "precision must be 1 or 2");
   REQUIRE(a->ray_d && a->fg_far && a->fg_z && a->bg_z && a->packed && a->workspace && a->tables, "inputs");
-  REQUIRE(a->g_rgb && a->g_depth && a->grads && a->params, "gradients / params");
+  REQUIRE(a->grads && a->params, "gradients / params");
+  LossFuse lf{};
+  if (a->fused_loss) {
+    REQUIRE(a->loss_type >= NERFPP_LOSS_RGB_ONLY && a->loss_type <= NERFPP_LOSS_KL, "loss_type in 0..3");
+    REQUIRE(a->rgb && a->rgb_gt, "fused loss head needs rgb and rgb_gt");
+    if (a->loss_type != NERFPP_LOSS_RGB_ONLY) REQUIRE(a->depth && a->depth_sup, "fused depth loss needs depth and depth_sup");
+    if (a->loss_type == NERFPP_LOSS_KL) REQUIRE(a->kl_sigma > 0.f, "kl_sigma > 0");
+    lf.type = a->loss_type; lf.lambda_depth = a->lambda_depth; lf.kl_sigma = a->kl_sigma;
+    lf.rgb = a->rgb; lf.depth = a->depth; lf.rgb_gt = a->rgb_gt; lf.depth_sup = a->depth_sup;
+  } else {
+    REQUIRE(a->g_rgb && a->g_depth, "dL/d rgb and dL/d depth (or fused_loss)");
+  }
   hipStream_t st = (hipStream_t)stream;
   const int P = a->precision;
   const int WP = a->workspace_precision ? a->workspace_precision : P;     // precision of the forward's saves
@@ -415,7 +426,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   launch_composite_bwd(st, a->n_rays, a->n_samples, (const float*)(ws + L.out_raw[0]),
                        (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
                        a->fg_z, a->bg_z, a->g_rgb, a->g_depth, a->g_fg_weights, (float*)(ws + L.d_out[0]),
-                       (float*)(ws + L.d_out[1]));
+                       (float*)(ws + L.d_out[1]), a->fused_loss ? &lf : nullptr);
   SideStream* side = side_stream();
   for (int net = 0; net < N_NET; ++net) {
     MlpBwdArgs m{};

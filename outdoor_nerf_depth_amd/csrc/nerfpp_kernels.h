@@ -36,6 +36,15 @@ struct MlpBwdArgs {
   const uint4* masks;
 };
 
+struct LossFuse {                // loss head folded into the compositing backward (nerfpp_backward_args::fused_loss)
+  int type;                      // NERFPP_LOSS_*
+  float lambda_depth, kl_sigma;
+  const float* rgb;              // [n,3] forward output
+  const float* depth;            // [n]   forward output
+  const float* rgb_gt;           // [n,3]
+  const float* depth_sup;        // [n] (NULL for rgb-only)
+};
+
 struct DwArgs {
   NetWs ws[N_NET];
   int64_t rows, rows_padded;
@@ -65,7 +74,7 @@ void launch_composite_fwd(hipStream_t st, int n, int S, const float* raw_fg, con
 void launch_composite_bwd(hipStream_t st, int n, int S, const float* raw_fg, const float* raw_bg,
                           const float* depth_real_bg, const float* ray_d, const float* fg_far,
                           const float* fg_z, const float* bg_z, const float* g_rgb, const float* g_depth,
-                          const float* g_fg_weights, float* dout_fg, float* dout_bg);
+                          const float* g_fg_weights, float* dout_fg, float* dout_bg, const nerfpp::LossFuse* lf);
 void launch_loss(hipStream_t st, int n, int S, int type, float lambda_depth, float kl_sigma, const float* rgb,
                  const float* rgb_gt, const float* depth, const float* depth_sup, const float* fg_weights,
                  const float* fg_z, const float* fg_dists, const float* fg_far, float* scalars, float* g_rgb,

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "nerfpp_common.h"
+#include "nerfpp_kernels.h"
 
 namespace nerfpp {
 
@@ -104,6 +105,11 @@ __global__ void perturb_kernel(int n, int S, const float* __restrict__ z, const 
 // Arithmetic order = oracle: wsum and cdf by sequential float64 accumulation rounded to float32.
 // ------------------------------------------------------------------------------------------------
 constexpr int SP_MAX = 512;     // max S_old + S_new and max M+1
+// LDS hand-off between the lanes of ONE wave (its LDS operations retire in order; the compiler must not reorder across)
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // blockIdx.y selects one of up to two independent problems (the foreground and background volumes of
 // a cascade level are re-sampled in one launch: with one wave per ray a single volume of 1024 rays
@@ -198,6 +204,56 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(int n, int M, int S_new
   __syncthreads();
   if (active && merged_out) {
     const int S_tot = S_old + S_new;
+    // sort(cat(z_old, samples)) (ddp_train_nerf.py:457,465) as a MERGE: z_old is ascending in every caller of the
+    // reference (stratified depths, or the previous level's sorted depths), so only the S_new new depths need sorting --
+    // a bitonic network in LDS (28 compare-exchange passes for 128 values instead of ranking all 192 against all 192) --
+    // and every element's place in the output is its own index plus a binary-search count in the other list
+    // (old before new on ties, like the stable sort of the concatenation; the output is values only, so any correct
+    // order of equal values is bit-identical).  A z_old that is not ascending falls through to the rank sort below.
+    bool sorted_old = true;
+    for (int i = lane; i + 1 < S_old; i += 64) sorted_old = sorted_old && zs[i] <= zs[i + 1];
+    if (__all(sorted_old) && S_new <= SP_MAX) {
+      int P2 = 1;
+      while (P2 < S_new) P2 <<= 1;
+      float* nb = wq;                                   // the pdf is no longer needed: its array takes the new depths
+      for (int i = lane; i < P2; i += 64) nb[i] = i < S_new ? zs[S_old + i] : __builtin_inff();
+      lds_wave_sync();
+      for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = lane; t < (P2 >> 1); t += 64) {
+            const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi_i = lo | j;
+            const bool up = (lo & k) == 0;
+            const float x = nb[lo], y = nb[hi_i];
+            if ((x > y) == up) { nb[lo] = y; nb[hi_i] = x; }
+          }
+          lds_wave_sync();
+        }
+      }
+      float* mo = merged_out + (size_t)ray * S_tot;
+      for (int i = lane; i < S_old; i += 64) {          // old depth i: + #{new < it}
+        const float v = zs[i];
+        int lo = 0, hi_i = S_new;
+        while (lo < hi_i) {
+          const int mid = (lo + hi_i) >> 1;
+          const bool lt = nb[mid] < v;
+          lo = lt ? mid + 1 : lo;
+          hi_i = lt ? hi_i : mid;
+        }
+        mo[i + lo] = v;
+      }
+      for (int p = lane; p < S_new; p += 64) {          // p-th smallest new depth: + #{old <= it}
+        const float v = nb[p];
+        int lo = 0, hi_i = S_old;
+        while (lo < hi_i) {
+          const int mid = (lo + hi_i) >> 1;
+          const bool le = zs[mid] <= v;
+          lo = le ? mid + 1 : lo;
+          hi_i = le ? hi_i : mid;
+        }
+        mo[p + lo] = v;
+      }
+      return;
+    }
     if (S_tot <= 192) {
       // up to three elements per lane ranked in ONE pass over the list (a third of the LDS reads of the per-element loop
       // below, three independent compare chains); same comparison, same result
@@ -368,11 +424,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 // Backward of the compositing: given dL/d rgb [n,3], dL/d depth [n] and
 // (KL only) dL/d fg_weights [n,S], writes per sample (d rgb_pre-sigmoid[3], d sigma_raw) for the
 // fg and bg MLPs, natural sample order.
+// KL term formed in place (fused loss head): dL/d fg_weights of depth_kl, the arithmetic of kl_terms_kernel
+struct KlFuse { bool on; float gt, inv2s, lambda_depth; };
 template <bool BG>
 __device__ __forceinline__ void volume_backward(const RaySamples& v, int S, int cpl, int lane, size_t row0,
                                                 const float gC[3], float gD, float g_lam_lam,
                                                 const float* __restrict__ g_w_extra,
-                                                float4* __restrict__ dout) {
+                                                float4* __restrict__ dout, const KlFuse kl = KlFuse{false, 0.f, 0.f, 0.f}) {
   float gw[CPL_MAX], term = 0.f;
 #pragma unroll
   for (int k = 0; k < CPL_MAX; ++k) {
@@ -380,6 +438,12 @@ __device__ __forceinline__ void volume_backward(const RaySamples& v, int S, int 
     const bool ok = k < cpl && i < S;
     float g = gC[0] * v.c[k][0] + gC[1] * v.c[k][1] + gC[2] * v.c[k][2] + gD * v.zval[k];
     if (ok && g_w_extra) g += g_w_extra[row0 + i];
+    if (!BG && ok && kl.on) {
+      const float dz = v.zval[k] - kl.gt;
+      const float w = v.w[k] + 1e-5f;
+      const float e = expf(-(dz * dz) * kl.inv2s);
+      g += -kl.lambda_depth * e * v.dist[k] / (w * (float)S);
+    }
     gw[k] = ok ? g : 0.f;
     term += gw[k] * v.w[k];
   }
@@ -403,21 +467,58 @@ __device__ __forceinline__ void volume_backward(const RaySamples& v, int S, int 
   }
 }
 
+// LF (fused loss head, nerfpp_backward_args::fused_loss): dL/d rgb, dL/d depth and (KL) dL/d fg_weights are formed here
+// with the arithmetic of loss_kernel / kl_terms_kernel instead of being read back from a loss launch that sits between
+// the compositing forward and this kernel on the critical path.  The mse / l1 normaliser (#rays with a prior) depends
+// on the batch only: every workgroup recounts it from depth_sup (n floats, L2-resident; exact in float up to 2^24).
+template <bool LF>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(
     int n, int S, const float4* __restrict__ raw_fg, const float4* __restrict__ raw_bg,
     const float* __restrict__ depth_real_bg, const float* __restrict__ ray_d,
     const float* __restrict__ fg_far, const float* __restrict__ fg_z, const float* __restrict__ bg_z,
     const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
-    const float* __restrict__ g_fg_weights, float4* __restrict__ dout_fg, float4* __restrict__ dout_bg) {
+    const float* __restrict__ g_fg_weights, float4* __restrict__ dout_fg, float4* __restrict__ dout_bg, LossFuse lf) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + wave;
+  float cnt = 0.f;
+  if (LF && (lf.type == 1 || lf.type == 2)) {
+    __shared__ float s_cnt[4];
+    float c = 0.f;
+    for (int r = threadIdx.x; r < n; r += 256) c += lf.depth_sup[r] > 0.f ? 1.f : 0.f;
+    c = wave_sum(c);
+    if (lane == 0) s_cnt[wave] = c;
+    __syncthreads();
+    cnt = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+  }
   if (ray >= n) return;
   const int cpl = (S + 63) / 64;
   const size_t row0 = (size_t)ray * S;
   const float dx = ray_d[ray * 3], dy = ray_d[ray * 3 + 1], dz = ray_d[ray * 3 + 2];
   const float dnorm = sqrtf(sum3(dx * dx, dy * dy, dz * dz));
-  const float gC[3] = {g_rgb[ray * 3], g_rgb[ray * 3 + 1], g_rgb[ray * 3 + 2]};
-  const float gD = g_depth[ray];
+  float gC[3], gD;
+  KlFuse kl{false, 0.f, 0.f, 0.f};
+  if (LF) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gC[c] = 2.f * (lf.rgb[ray * 3 + c] - lf.rgb_gt[ray * 3 + c]) / (float)(3 * n);
+    gD = 0.f;
+    if (lf.type == 1 || lf.type == 2) {
+      const float gt = lf.depth_sup[ray];
+      if (gt > 0.f && cnt > 0.f) {
+        const float d = lf.depth[ray] - gt;
+        gD = lf.type == 1 ? lf.lambda_depth * 2.f * d / cnt
+                          : lf.lambda_depth * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / cnt;
+      }
+    } else if (lf.type == 3) {
+      const float gt = lf.depth_sup[ray];
+      kl.on = gt > 0.f && gt < fg_far[ray];
+      kl.gt = gt;
+      kl.inv2s = 1.f / (2.f * lf.kl_sigma);
+      kl.lambda_depth = lf.lambda_depth;
+    }
+  } else {
+    gC[0] = g_rgb[ray * 3]; gC[1] = g_rgb[ray * 3 + 1]; gC[2] = g_rgb[ray * 3 + 2];
+    gD = g_depth[ray];
+  }
   RaySamples vb;
   load_volume<true>(vb, S, cpl, lane, row0, raw_bg, bg_z + row0, depth_real_bg, dnorm, 0.f);
   float a0 = 0, a1 = 0, a2 = 0, ad = 0;
@@ -430,7 +531,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
   RaySamples vf;
   load_volume<false>(vf, S, cpl, lane, row0, raw_fg, fg_z + row0, nullptr, dnorm, fg_far[ray]);
   const float lam = vf.lambda;
-  volume_backward<false>(vf, S, cpl, lane, row0, gC, gD, g_lam * lam, g_fg_weights, dout_fg);
+  volume_backward<false>(vf, S, cpl, lane, row0, gC, gD, g_lam * lam, LF ? nullptr : g_fg_weights, dout_fg, kl);
   const float gCb[3] = {lam * gC[0], lam * gC[1], lam * gC[2]};
   volume_backward<true>(vb, S, cpl, lane, row0, gCb, lam * gD, 0.f, nullptr, dout_bg);
 }
@@ -596,10 +697,15 @@ void launch_composite_fwd(hipStream_t st, int n, int S, const float* raw_fg, con
 void launch_composite_bwd(hipStream_t st, int n, int S, const float* raw_fg, const float* raw_bg,
                           const float* depth_real_bg, const float* ray_d, const float* fg_far,
                           const float* fg_z, const float* bg_z, const float* g_rgb, const float* g_depth,
-                          const float* g_fg_weights, float* dout_fg, float* dout_bg) {
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, S, (const float4*)raw_fg,
-                     (const float4*)raw_bg, depth_real_bg, ray_d, fg_far, fg_z, bg_z, g_rgb, g_depth,
-                     g_fg_weights, (float4*)dout_fg, (float4*)dout_bg);
+                          const float* g_fg_weights, float* dout_fg, float* dout_bg, const nerfpp::LossFuse* lf) {
+  if (lf)
+    hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, n, S, (const float4*)raw_fg,
+                       (const float4*)raw_bg, depth_real_bg, ray_d, fg_far, fg_z, bg_z, g_rgb, g_depth,
+                       g_fg_weights, (float4*)dout_fg, (float4*)dout_bg, *lf);
+  else
+    hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, n, S, (const float4*)raw_fg,
+                       (const float4*)raw_bg, depth_real_bg, ray_d, fg_far, fg_z, bg_z, g_rgb, g_depth,
+                       g_fg_weights, (float4*)dout_fg, (float4*)dout_bg, nerfpp::LossFuse{});
 }
 void launch_loss(hipStream_t st, int n, int S, int type, float lambda_depth, float kl_sigma, const float* rgb,
                  const float* rgb_gt, const float* depth, const float* depth_sup, const float* fg_weights,

@@ -264,23 +264,41 @@ class LevelEngine(object):
             self._fwd = (n, S, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
         return out
 
-    def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None, events=None, defer_reduce=False):
+    def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None, events=None, defer_reduce=False,
+                 fused_loss=None):
         """Gradient of the loss w.r.t. the flat parameters given dL/d rgb, dL/d depth and (KL)
         dL/d fg_weights, for the last training-mode forward.  defer_reduce: stop after the weight-gradient
-        GEMMs; `reduce_grads()` (on any stream ordered after this call) then fills the returned tensor."""
+        GEMMs; `reduce_grads()` (on any stream ordered after this call) then fills the returned tensor.
+        fused_loss: instead of g_* (pass None), dict(loss_type, lambda_depth, kl_sigma, ret, rgb_gt, depth_sup): the
+        loss head of ddp_train_nerf.py:481-493 is differentiated inside the compositing backward (same arithmetic as
+        loss_and_grads, which then only serves the logged scalars and can run off the critical path)."""
         if self._fwd is None:
             raise L.NerfppError('backward() needs a preceding forward(training=True)')
         n, S, ray_d, fg_far, fg_z, bg_z = self._fwd
-        g_rgb, g_depth = _f32(g_rgb, (n, 3)), _f32(g_depth, (n,))
-        g_fg_weights = _f32(g_fg_weights, (n, S)) if g_fg_weights is not None else None
+        keep = None
+        if fused_loss is None:
+            g_rgb, g_depth = _f32(g_rgb, (n, 3)), _f32(g_depth, (n,))
+            g_fg_weights = _f32(g_fg_weights, (n, S)) if g_fg_weights is not None else None
+        else:
+            g_rgb = g_depth = g_fg_weights = None
+            f = fused_loss
+            t = L.LOSS_TYPES[f['loss_type']]
+            keep = (_f32(f['ret']['rgb'], (n, 3)), _f32(f['ret']['depth'], (n,)), _f32(f['rgb_gt'], (n, 3)),
+                    _f32(f['depth_sup'], (n,)) if t != L.LOSS_RGB_ONLY else None)
         grads = out if out is not None else torch.empty(L.LEVEL_PARAMS, device=self.device)
         a = L.BackwardArgs()
         a.n_rays, a.n_samples, a.precision = n, S, self.bwd_precision
         a.workspace_precision = self.precision
         a.ray_d, a.fg_far, a.fg_z, a.bg_z = [t.data_ptr() for t in (ray_d, fg_far, fg_z, bg_z)]
         a.packed, a.workspace, a.tables = self.packed_bwd.data_ptr(), self.workspace.data_ptr(), self.tables.data_ptr()
-        a.g_rgb, a.g_depth = g_rgb.data_ptr(), g_depth.data_ptr()
-        a.g_fg_weights = g_fg_weights.data_ptr() if g_fg_weights is not None else None
+        if fused_loss is None:
+            a.g_rgb, a.g_depth = g_rgb.data_ptr(), g_depth.data_ptr()
+            a.g_fg_weights = g_fg_weights.data_ptr() if g_fg_weights is not None else None
+        else:
+            a.fused_loss, a.loss_type = 1, t
+            a.lambda_depth, a.kl_sigma = float(fused_loss.get('lambda_depth', 1.0)), float(fused_loss.get('kl_sigma', 0.01))
+            a.rgb, a.depth, a.rgb_gt = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+            a.depth_sup = keep[3].data_ptr() if keep[3] is not None else None
         a.grad_scale = float(grad_scale)
         a.grads = grads.data_ptr()
         a.params = self.params.data_ptr()

@@ -86,7 +86,15 @@ class SyntheticKitti(object):
                  seed=DATA_SEED):
         self.H, self.W = H, W
         self.K = kitti_intrinsics(H, W)
-        c2w, self.depth_scale = normalize_poses(trajectory(n_frames))
+        if n_frames < 2:
+            # BASELINE config 1 ("1 KITTI-seq00 frame"): ONE frame of a sequence that was normalised as a whole.  A lone
+            # camera normalised by itself sits exactly at the origin, where the reference's inverted-sphere
+            # parametrisation is 0/0 (ddp_model.py:27-28: rot_axis = cross(ray_o, p_sphere) / |.|) -- NaN in the
+            # reference itself -- so the frame is taken from the normalised 295-frame trajectory instead.
+            c2w, self.depth_scale = normalize_poses(trajectory(295))
+            c2w = c2w[:n_frames]
+        else:
+            c2w, self.depth_scale = normalize_poses(trajectory(n_frames))
         idx = np.arange(n_frames)
         is_test = (idx % 10) == 9                                # colmap2nerfpp.py:111
         self.train_c2w = c2w[~is_test][::trainskip]

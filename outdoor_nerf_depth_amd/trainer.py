@@ -22,7 +22,7 @@ class NerfppTrainer(object):
     def __init__(self, device, precision=L.PREC_SPLIT_BF16, cascade_samples=(64, 128), lrate=5e-4,
                  use_depth=True, depth_loss_type='mse', lambda_depth=0.1, depth_sigma=0.01, depth_scale=1.0,
                  world_size=1, level_params=None, overlap_allreduce=True, optim_autoexpo=False, img_names=None,
-                 lambda_autoexpo=1.0, seed=777, torch_rng=False):
+                 lambda_autoexpo=1.0, seed=777, torch_rng=False, fuse_loss=True):
         """seed: key of the in-kernel sampling RNG (the CLI passes (rank+1)*777 like ddp_train_nerf.py:406-408);
         torch_rng=True draws the four uniform tensors with torch.rand in the reference's call order instead
         (4 extra launches per step)."""
@@ -48,6 +48,7 @@ class NerfppTrainer(object):
         self.grads = [torch.zeros(L.LEVEL_PARAMS + 4, device=self.device) for _ in self.engines]
         self.step_count = 0
         self.seed, self.torch_rng = int(seed), bool(torch_rng)
+        self.fuse_loss = bool(fuse_loss)      # loss-head gradient inside the compositing backward (not with auto-exposure)
         self.rng_step = 0                 # counter of the in-kernel RNG (not reset by checkpoint reloads of step_count)
         # rays whose closest point to the origin lies outside the unit sphere, summed over all steps since
         # the last check_cameras() (the reference raises on the spot, ddp_train_nerf.py:62-63; here the
@@ -183,6 +184,32 @@ class NerfppTrainer(object):
             ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True,
                               events=ev['fwd'] if ev else None)
             ae = self.autoexpo[m] if ae_idx is not None else None
+            if ae is None and self.fuse_loss:
+                # The loss head's gradient is formed inside the compositing backward (nerfpp_backward_args.fused_loss);
+                # the loss launch itself only yields the logged scalars, so it runs on the side stream next to the
+                # backward kernels instead of between forward and backward on the critical path.
+                loss_done = None
+                if self.update_stream is not None:
+                    fwd_done = torch.cuda.Event()
+                    fwd_done.record()
+                    self.update_stream.wait_event(fwd_done)
+                    with torch.cuda.stream(self.update_stream):
+                        sc = ops.loss_and_grads(ret, batch['rgb'], depth_sup, self.loss_type, self.lambda_depth,
+                                                self.kl_sigma, fg_z, far)[0]
+                        loss_done = torch.cuda.Event()
+                        loss_done.record()
+                eng.backward(None, None, None, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS],
+                             events=ev['bwd'] if ev else None, defer_reduce=True,
+                             fused_loss=dict(loss_type=self.loss_type, lambda_depth=self.lambda_depth, kl_sigma=self.kl_sigma,
+                                             ret=ret, rgb_gt=batch['rgb'], depth_sup=depth_sup))
+                if loss_done is not None:
+                    torch.cuda.current_stream().wait_event(loss_done)     # long finished: orders readers of `sc` / frees of `ret`
+                else:
+                    sc = ops.loss_and_grads(ret, batch['rgb'], depth_sup, self.loss_type, self.lambda_depth,
+                                            self.kl_sigma, fg_z, far)[0]
+                scalars.append(sc)
+                self._update_begin(m)
+                continue
             rgb_gt = ae.target(ae_idx, batch['rgb']) if ae is not None else batch['rgb']
             sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, rgb_gt, depth_sup, self.loss_type,
                                                          self.lambda_depth, self.kl_sigma, fg_z, far)

@@ -1,0 +1,165 @@
+"""GPU tests added in round 3 (through the C ABI, against the numpy oracle):
+
+* the loss head folded into the compositing backward (nerfpp_backward_args.fused_loss) gives the gradients of the
+  loss_and_grads + backward pair bit for bit, for rgb-only / mse / l1 / kl incl. the empty-mask cases;
+* the merge of `sample_fine` (bitonic sort of the new depths + binary-search ranks) against the oracle's
+  sort(cat(...)): ties, duplicated depths, a z_old that is NOT ascending (rank-sort fallback), sizes up to 512;
+* the trainer with and without the fused loss head takes identical steps.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import nerfpp_oracle as O                                   # noqa: E402
+from tests.test_gpu_parity import T, N, flat, dev                       # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ops():
+    dev()
+    from outdoor_nerf_depth_amd import ops as _ops
+    return _ops
+
+
+def _batch(n, seed=0, sup='gt'):
+    from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
+    return SyntheticKitti(depth_sup_type=sup).random_batch(n, np.random.RandomState(seed))
+
+
+@pytest.mark.parametrize('loss_type', ['rgbonly', 'mse', 'l1', 'kl'])
+@pytest.mark.parametrize('precision', [1, 2])
+def test_fused_loss_head_matches_the_two_call_path_bit_for_bit(ops, loss_type, precision):
+    n, S = 96, 64
+    b = _batch(n, 3, 'mono_crop' if loss_type == 'kl' else 'gt')
+    if loss_type in ('mse', 'l1'):
+        b['depth_sup'][::3] = 0.02 + 0.001 * np.arange(len(b['depth_sup'][::3]), dtype=np.float32)   # enough valid rays
+    level = O.init_params_like_reference(1)[0]
+    eng = ops.LevelEngine(T(flat(level)), precision=precision)
+    ray_o, ray_d = T(b['ray_o']), T(b['ray_d'])
+    far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, T(b['min_depth']), S, rng=(5, 1))
+    ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True)
+    sup = T(b['depth_sup']) if loss_type != 'rgbonly' else None
+    sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, T(b['rgb']), sup, loss_type, 0.1, 0.01 * 0.0053, fg_z, far)
+    want = eng.backward(g_rgb, g_depth, g_w).clone()
+    ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True)
+    got = eng.backward(None, None, None, fused_loss=dict(loss_type=loss_type, lambda_depth=0.1, kl_sigma=0.01 * 0.0053,
+                                                         ret=ret, rgb_gt=T(b['rgb']), depth_sup=sup))
+    assert np.isfinite(N(want)).all() and np.abs(N(want)).max() > 0
+    if loss_type != 'rgbonly':
+        assert float(sc[3]) > 0                                          # the depth term is live in this batch
+    np.testing.assert_array_equal(N(got), N(want))
+
+
+@pytest.mark.parametrize('loss_type', ['mse', 'kl'])
+def test_fused_loss_head_empty_mask(ops, loss_type):
+    """no ray carries a depth prior: mse / l1 contribute a zero gradient (their NaN loss value is the scalar's business,
+    depth_loss.py:9-18), kl contributes nothing (depth_loss.py:38-44) -- same as the two-call path."""
+    n, S = 32, 64
+    b = _batch(n, 4)
+    level = O.init_params_like_reference(1)[0]
+    eng = ops.LevelEngine(T(flat(level)), precision=2)
+    ray_o, ray_d = T(b['ray_o']), T(b['ray_d'])
+    far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, T(b['min_depth']), S, rng=(5, 2))
+    zero = torch.zeros(n, device=dev())
+    ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True)
+    sc, g_rgb, g_depth, g_w = ops.loss_and_grads(ret, T(b['rgb']), zero, loss_type, 0.1, 1e-4, fg_z, far)
+    want = eng.backward(g_rgb, g_depth, g_w).clone()
+    ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True)
+    got = eng.backward(None, None, None, fused_loss=dict(loss_type=loss_type, lambda_depth=0.1, kl_sigma=1e-4, ret=ret,
+                                                         rgb_gt=T(b['rgb']), depth_sup=zero))
+    assert np.isfinite(N(got)).all()
+    np.testing.assert_array_equal(N(got), N(want))
+
+
+def test_trainer_steps_identical_with_and_without_the_fused_loss_head(ops):
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    from outdoor_nerf_depth_amd.model import init_level_params
+    outs = []
+    for fuse in (True, False):
+        tr = NerfppTrainer(dev(), precision=1, use_depth=True, depth_loss_type='mse', lambda_depth=0.1,
+                           level_params=init_level_params(2), seed=777, fuse_loss=fuse)
+        scs = []
+        for step in range(3):
+            b = _batch(128, 10 + step)
+            b['depth_sup'][::2] = 0.03
+            scs.append(tr.train_step({k: T(v) for k, v in b.items() if isinstance(v, np.ndarray)}))
+        tr.flush()
+        torch.cuda.synchronize()
+        outs.append(([N(e.params).copy() for e in tr.engines], [[N(s).copy() for s in sc] for sc in scs]))
+    for m in range(2):
+        np.testing.assert_array_equal(outs[0][0][m], outs[1][0][m])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+            assert np.isfinite(x[:3]).all()
+
+
+# ------------------------------------------------------------------------------------------------ merge of sample_fine
+@pytest.mark.parametrize('n_rays,S_old,n_new', [(6, 64, 128), (3, 64, 448), (5, 3, 1), (4, 200, 300), (7, 65, 63), (2, 130, 2)])
+def test_sample_fine_merge_sizes_bit_exact(ops, n_rays, S_old, n_new):
+    rs = np.random.RandomState(S_old * 7 + n_new)
+    z = np.sort(rs.rand(n_rays, S_old).astype(np.float32) * 2 + 0.05, axis=-1)
+    w = rs.rand(n_rays, S_old).astype(np.float32) ** 3
+    u = rs.rand(n_rays, n_new).astype(np.float32)
+    m_o, s_o, a_o = O.fine_depths(z, w, u)
+    merged, samples, above = ops.sample_fine(T(z), T(w), n_new, u=T(u), return_all=True)
+    np.testing.assert_array_equal(N(samples), s_o)
+    np.testing.assert_array_equal(N(merged), m_o)
+    assert (np.diff(N(merged), axis=-1) >= 0).all()
+
+
+def test_sample_fine_merge_ties_and_duplicates(ops):
+    """equal depths inside z_old, new depths landing exactly on old ones (a one-bin pdf with u = 0 returns the bin edge)
+    and repeated uniforms: the merged list is the sorted multiset, bit for bit."""
+    n, S_old, n_new = 8, 64, 128
+    rs = np.random.RandomState(1)
+    z = np.sort(rs.rand(n, S_old).astype(np.float32), axis=-1)
+    z[:, 10:14] = z[:, 10:11]                                            # a run of equal old depths
+    z = np.sort(z, axis=-1)
+    w = np.zeros((n, S_old), np.float32)
+    w[:, 20] = 1.0                                                       # all the mass in one bin
+    u = rs.rand(n, n_new).astype(np.float32)
+    u[:, :16] = 0.0                                                      # -> samples exactly on a bin edge, 16 duplicates
+    u[:, 16:32] = u[:, 16:17]
+    m_o, s_o, _ = O.fine_depths(z, w, u)
+    merged, samples, _ = ops.sample_fine(T(z), T(w), n_new, u=T(u), return_all=True)
+    np.testing.assert_array_equal(N(samples), s_o)
+    np.testing.assert_array_equal(N(merged), m_o)
+
+
+def test_sample_fine_unsorted_old_depths_fall_back_to_the_rank_sort(ops):
+    """the reference sorts cat(z_old, samples) whatever the order of z_old; the merge path needs an ascending z_old and
+    otherwise the kernel uses its all-pairs rank sort: same result as the oracle's sort."""
+    n, S_old, n_new = 5, 64, 128
+    rs = np.random.RandomState(2)
+    z = rs.rand(n, S_old).astype(np.float32) + 0.1                       # NOT sorted
+    z[0] = np.sort(z[0])                                                 # one ray takes the merge path in the same launch
+    w = rs.rand(n, S_old).astype(np.float32)
+    u = rs.rand(n, n_new).astype(np.float32)
+    m_o, s_o, _ = O.fine_depths(z, w, u)
+    merged, samples, _ = ops.sample_fine(T(z), T(w), n_new, u=T(u), return_all=True)
+    np.testing.assert_array_equal(N(samples), s_o)
+    np.testing.assert_array_equal(N(merged), m_o)
+
+
+def test_sample_fine_pair_rng_and_det_at_bench_size(ops):
+    """1024 rays, 64 + 128 (the bench shape): in-kernel Philox uniforms == the explicit-uniform call; det == oracle."""
+    n, S_old, n_new = 1024, 64, 128
+    b = _batch(n, 5)
+    ray_o, ray_d = T(b['ray_o']), T(b['ray_d'])
+    far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, T(b['min_depth']), S_old, rng=(9, 1))
+    rs = np.random.RandomState(3)
+    wf, wb = T(rs.rand(n, S_old).astype(np.float32) ** 6), T(rs.rand(n, S_old).astype(np.float32) ** 6)
+    a, c = ops.sample_fine_pair(fg_z, wf, bg_z, wb, n_new, rng=(9, 1))
+    u_fg = ops.rng_uniform(9, 1, 2, (n, n_new), dev())
+    u_bg = ops.rng_uniform(9, 1, 3, (n, n_new), dev())
+    a2, c2 = ops.sample_fine_pair(fg_z, wf, bg_z, wb, n_new, u_fg=u_fg, u_bg=u_bg)
+    np.testing.assert_array_equal(N(a), N(a2))
+    np.testing.assert_array_equal(N(c), N(c2))
+    np.testing.assert_array_equal(N(a), O.fine_depths(N(fg_z), N(wf), N(u_fg))[0])
+    np.testing.assert_array_equal(N(c), O.fine_depths(N(bg_z), N(wb), N(u_bg))[0])
+    d, _ = ops.sample_fine_pair(fg_z, wf, bg_z, wb, n_new, det=True)
+    u_det = np.broadcast_to(O.torch_linspace(0.0, 1.0, n_new), (n, n_new))
+    np.testing.assert_array_equal(N(d), O.fine_depths(N(fg_z), N(wf), u_det)[0])
