@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MIP360_ABI_VERSION 3
+#define MIP360_ABI_VERSION 4
 #define MIP360_OK 0
 #define MIP360_ERR_ARG 1
 #define MIP360_ERR_HIP 2
@@ -29,6 +29,11 @@ extern "C" {
 #define MIP360_IPE_LD 512          /* row stride of the encoded-sample tensor (zero padded) */
 #define MIP360_MAX_BINS 128        /* bins of a step function handed to mip360_resample */
 #define MIP360_MAX_SAMPLES 64      /* samples per ray per level */
+#define MIP360_DEPTH_NONE 0
+#define MIP360_DEPTH_MSE 1
+#define MIP360_DEPTH_L1 2
+#define MIP360_DEPTH_KL 3          /* ds_nerf_depth_loss            internal/depth_loss.py:5-29 */
+#define MIP360_DEPTH_URF 4         /* urban_radiance_field_depth_loss                     :31-65 */
 
 const char* mip360_last_error(void);
 int mip360_abi_version(void);
@@ -97,6 +102,24 @@ int mip360_losses(void* stream, int n_rays, int s_nerf, int s_prop, int n_prop, 
                   float distortion_mult, float* scalars, float* g_rgb, float* g_distance_mean,
                   float* g_w_nerf, float* const* g_w_prop, float* workspace, float prop_depth_weight,
                   const float* const* dm_prop, float* const* g_dm_prop);
+
+/* depth_loss.depth_loss(weights, tdist, termination_depth, predicted_depth, sigma, dirs, type) for type 'kl' / 'urf' of ONE
+ * sampling level (internal/depth_loss.py:67-102, called per level at train_utils.py:121-128), value and gradients:
+ *   steps = 0.5 (tdist[:-1] + tdist[1:]); kl: lengths = (tdist[1:] - tdist[:-1]) * |directions|,
+ *   loss = -log(w + 1e-7) * exp(-(steps - gt)^2 / (2 sigma)) * lengths (:24); urf: expected-depth + line-of-sight terms
+ *   with N(0, sigma / 3) (:44-60).
+ * Upstream reduces with loss.sum(-2) -- over the RAY axis of [n_rays, n_samples] -- and multiplies the [n_samples]
+ * result by the [n_rays] mask (:25-27, :57-64): that broadcasts only for n_rays == n_samples or n_rays == 1.  This entry
+ * point reproduces exactly that (column s meets the mask / expected term of ray s, or of ray 0) and returns
+ * MIP360_ERR_ARG with the broadcasting message for any other shape, like JAX raises.
+ * weights [n,S], tdist [n,S+1], depth_sup [n], distance_mean [n] (urf, else NULL), directions [n,3] (kl, else NULL).
+ * loss_out[0] = the value.  g_weights [n,S] / g_distance_mean [n] (NULL to skip) are ACCUMULATED: += scale * d value / d x
+ * (scale = the term's weight in the total: lambda_depth for a proposal level, (data_loss_mult + 1) * lambda_depth for the
+ * NeRF level, train_utils.py:136-143).  total_accum (NULL or float[2]): [0] += scale * value, [1] += value. */
+int mip360_depth_loss_klurf(void* stream, int depth_loss_type, int n_rays, int n_samples, const float* weights,
+                            const float* tdist, const float* depth_sup, const float* distance_mean,
+                            const float* directions, float sigma, float scale, float* loss_out, float* g_weights,
+                            float* g_distance_mean, float* total_accum);
 
 /* One dense layer on the matrix cores: C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]), bf16 operands (row-major, K
  * contiguous, leading dimensions lda / ldw in elements, multiples of 8), float32 accumulation

@@ -499,14 +499,18 @@ def init_mlp_params(cfg, rng):
     return ps
 
 
-def mlp_forward(params, cfg, means, covs, viewdirs, basis, cache=None):
+def mlp_forward(params, cfg, means, covs, viewdirs, basis, cache=None, q=None):
     """models.py:436-606 for the 360.gin configuration (warp_fn = contract, disable_density_normals).
     means [..., n, 3], covs [..., n, 3, 3], viewdirs [..., 3].  Returns dict(density [..., n], rgb [..., n, 3]).
-    cache: optional dict that receives what mlp_backward needs."""
+    cache: optional dict that receives what mlp_backward needs.
+    q: optional rounding of every GEMM operand (weights, layer inputs) -- identity upstream; the GPU tests pass a
+    round-to-bfloat16 to model where a bf16-MFMA implementation rounds (test infrastructure, not upstream behaviour)."""
     c = dict(MLP_DEFAULTS, **cfg)
+    q = (lambda a: a) if q is None else q
+    params = [(q(W), b) for W, b in params]
     m, cv = track_linearize_contract(means, covs)
     lm, lv = lift_and_diagonalize(m, cv, basis)
-    x = integrated_pos_enc(lm, lv, c['min_deg_point'], c['max_deg_point'])
+    x = q(integrated_pos_enc(lm, lv, c['min_deg_point'], c['max_deg_point']))
     inputs = x
     k = 0
     acts_in, pre = [], []
@@ -515,7 +519,7 @@ def mlp_forward(params, cfg, means, covs, viewdirs, basis, cache=None):
         acts_in.append(x)
         z = x @ W + b
         pre.append(z)
-        x = np.maximum(z, 0)
+        x = q(np.maximum(z, 0))
         if i % c['skip_layer'] == 0 and i > 0:
             x = np.concatenate([x, inputs], -1)
     W, b = params[k]; k += 1
@@ -526,13 +530,13 @@ def mlp_forward(params, cfg, means, covs, viewdirs, basis, cache=None):
     if c['disable_rgb']:
         return dict(density=density, rgb=np.zeros_like(means))
     W, b = params[k]; k += 1
-    bott = x @ W + b
-    de = pos_enc(viewdirs, 0, c['deg_view'], append_identity=True)
+    bott = q(x @ W + b)
+    de = q(pos_enc(viewdirs, 0, c['deg_view'], append_identity=True))
     de = np.broadcast_to(de[..., None, :], bott.shape[:-1] + (de.shape[-1],))
     view_in = np.concatenate([bott, de], -1)
     W, b = params[k]; k += 1
     hz = view_in @ W + b
-    h = np.maximum(hz, 0)
+    h = q(np.maximum(hz, 0))
     W, b = params[k]; k += 1
     s = 1 / (1 + np.exp(-(h @ W + b)))
     rgb = s * (1 + 2 * c['rgb_padding']) - c['rgb_padding']
@@ -541,31 +545,33 @@ def mlp_forward(params, cfg, means, covs, viewdirs, basis, cache=None):
     return dict(density=density, rgb=rgb)
 
 
-def mlp_backward(params, cache, g_density, g_rgb=None):
+def mlp_backward(params, cache, g_density, g_rgb=None, q=None):
     """Closed-form backward of mlp_forward w.r.t. the parameters (upstream: jax.grad; positions get no gradient --
     models.py:203-204 stop_level_grad and the inputs are not learned).  g_density [..., n], g_rgb [..., n, 3].
-    Returns a list of (d kernel, d bias) in the parameter order."""
+    Returns a list of (d kernel, d bias) in the parameter order.  q: see mlp_forward (rounds the dZ operands too)."""
     c = cache['cfg']
     D = c['net_depth']
+    q = (lambda a: a) if q is None else q
+    params = [(q(W), b) for W, b in params]
     flat = lambda a, w: np.reshape(a, (-1, w))
     grads = [None] * len(params)
     x = flat(cache['trunk_out'], cache['trunk_out'].shape[-1])
     sig = 1 / (1 + np.exp(-(cache['raw_density'] + c['density_bias'])))          # softplus'
-    d_raw = np.reshape(g_density * sig, (-1, 1))
+    d_raw = q(np.reshape(g_density * sig, (-1, 1)))
     W_d, _ = params[D]
     grads[D] = (x.T @ d_raw, d_raw.sum(0))
     d_x = d_raw @ W_d.T
     if not c['disable_rgb']:
         s = flat(cache['sig'], 3)
-        d_pre = flat(g_rgb, 3) * (1 + 2 * c['rgb_padding']) * s * (1 - s)
+        d_pre = q(flat(g_rgb, 3) * (1 + 2 * c['rgb_padding']) * s * (1 - s))
         h = flat(cache['h'], cache['h'].shape[-1])
         W3, _ = params[D + 3]
         grads[D + 3] = (h.T @ d_pre, d_pre.sum(0))
-        d_hz = (d_pre @ W3.T) * (flat(cache['hz'], h.shape[-1]) > 0)
+        d_hz = q((d_pre @ W3.T) * (flat(cache['hz'], h.shape[-1]) > 0))
         vin = flat(cache['view_in'], cache['view_in'].shape[-1])
         W2, _ = params[D + 2]
         grads[D + 2] = (vin.T @ d_hz, d_hz.sum(0))
-        d_bott = (d_hz @ W2.T)[:, :c['bottleneck_width']]
+        d_bott = q((d_hz @ W2.T)[:, :c['bottleneck_width']])
         W1, _ = params[D + 1]
         grads[D + 1] = (x.T @ d_bott, d_bott.sum(0))
         d_x = d_x + d_bott @ W1.T
@@ -573,7 +579,7 @@ def mlp_backward(params, cache, g_density, g_rgb=None):
         if i % c['skip_layer'] == 0 and i > 0:
             d_x = d_x[:, :c['net_width']]                                        # the encoding part needs no gradient
         z = flat(cache['pre'][i], c['net_width'])
-        d_z = d_x * (z > 0)
+        d_z = q(d_x * (z > 0))
         a_in = flat(cache['acts_in'][i], cache['acts_in'][i].shape[-1])
         grads[i] = (a_in.T @ d_z, d_z.sum(0))
         if i > 0:
@@ -584,7 +590,7 @@ def mlp_backward(params, cache, g_density, g_rgb=None):
 def model_forward(prop_params, nerf_params, rays, train_frac=1.0, jitter01=None, basis=None, num_prop_samples=64,
                   num_nerf_samples=32, num_levels=3, anneal_slope=10., dilation_multiplier=0.5, dilation_bias=0.0025,
                   raydist_fn='reciprocal', opaque_background=True, single_jitter=True, resample_padding=0.0,
-                  bg_rgb=1.0):
+                  bg_rgb=1.0, caches=None, q=None):
     """Model.__call__ (models.py:76-303) for configs/360.gin: 2 proposal levels + 1 NeRF level.
     rays: dict origins, directions, viewdirs [N,3], radii, near, far [N,1].  jitter01: None (deterministic) or a
     list of num_levels arrays [N,1] in [0,1) replacing the per-level jax.random.uniform of stepfun.sample.
@@ -611,8 +617,12 @@ def model_forward(prop_params, nerf_params, rays, train_frac=1.0, jitter01=None,
                                  domain=(s_near, s_far))
         tdist = s_to_t(sdist)
         means, covs = cast_rays(tdist, rays['origins'], rays['directions'], rays['radii'], 'cone', diag=False)
+        cache = None
+        if caches is not None:                       # train_step: one cache per level for mlp_backward
+            cache = {}
+            caches.append(cache)
         res = mlp_forward(prop_params if is_prop else nerf_params, PROP_CFG if is_prop else NERF_CFG, means, covs,
-                          rays['viewdirs'], basis)
+                          rays['viewdirs'], basis, cache=cache, q=q)
         weights = compute_alpha_weights(res['density'], tdist, rays['directions'], opaque_background)[0]
         renderings.append(volumetric_rendering(res['rgb'], weights, tdist, bg_rgb, rays['far']))
         res.update(sdist=sdist, tdist=tdist, weights=weights)
@@ -702,3 +712,171 @@ def interlevel_loss(ray_history, interlevel_loss_mult=1.0):
 def distortion_loss(ray_history, distortion_loss_mult=0.01):
     """train_utils.py:163-169."""
     return distortion_loss_mult * np.mean(lossfun_distortion(ray_history[-1]['sdist'], ray_history[-1]['weights']))
+
+
+# ======================================================================================== train_utils.create_train_step
+def volumetric_rendering_backward(rgbs, weights, tdist, bg_rgbs, g_rgb=None, g_distance_mean=None):
+    """Closed-form gradient of volumetric_rendering's `rgb` and `distance_mean` (render.py:161-216; upstream: autograd)
+    w.r.t. the weights and the per-sample colours.  rgb = sum w c + max(0, 1 - acc) bg;
+    distance_mean = clip(exp(sum w log t_mid / max(eps, acc)), t_0, t_N) (zero gradient where the clip is active)."""
+    eps = np.finfo(np.float32).eps
+    acc = weights.sum(-1)
+    g_w = np.zeros_like(weights)
+    g_rgbs = None
+    if g_rgb is not None:
+        bg_on = ((1 - acc) > 0)[..., None]
+        g_w = g_w + (rgbs * g_rgb[..., None, :]).sum(-1) - bg_on * np.sum(bg_rgbs * g_rgb, -1, keepdims=True)
+        g_rgbs = weights[..., None] * g_rgb[..., None, :]
+    if g_distance_mean is not None:
+        logt = np.log(0.5 * (tdist[..., :-1] + tdist[..., 1:]))
+        A = (weights * logt).sum(-1)
+        B = np.maximum(eps, acc)
+        e = np.exp(A / B)
+        inside = (e > tdist[..., 0]) & (e < tdist[..., -1])
+        dB = (acc > eps)
+        g_w = g_w + (g_distance_mean * inside * e)[..., None] * (logt / B[..., None] - (A / B ** 2 * dB)[..., None])
+    return g_w, g_rgbs
+
+
+def tree_norm(grads):
+    """train_utils.py:45-57 over one MLP's (kernel, bias) list."""
+    return np.sqrt(sum(float(np.sum(np.square(k.astype(np.float64))) + np.sum(np.square(b.astype(np.float64)))) for k, b in grads))
+
+
+def new_train_state(prop_params, nerf_params):
+    """TrainState.create with optax.adam (train_utils.py:371-395): parameters + zero first / second moments + count."""
+    zeros = lambda ps: [(np.zeros_like(k), np.zeros_like(b)) for k, b in ps]
+    return dict(count=0, prop=[(k.copy(), b.copy()) for k, b in prop_params], nerf=[(k.copy(), b.copy()) for k, b in nerf_params],
+                mu=dict(prop=zeros(prop_params), nerf=zeros(nerf_params)), nu=dict(prop=zeros(prop_params), nerf=zeros(nerf_params)))
+
+
+def apply_gradients(state, grads, max_steps=250000, lr_init=2e-3, lr_final=2e-5, lr_delay_steps=512, lr_delay_mult=0.01,
+                    grad_max_norm=0.001, adam_b1=0.9, adam_b2=0.999, adam_eps=1e-6):
+    """train_utils.py:344-347: clip_gradients (per MLP, by global norm, :215-236) -> nan_to_num -> optax.adam with the
+    learning-rate schedule evaluated at the PRE-increment count (optax scale_by_schedule) and bias correction at the
+    post-increment count (optax.scale_by_adam).  grads: dict(prop=[(dk, db)], nerf=[...]).  Returns the clip multipliers."""
+    lr = learning_rate_decay(state['count'], lr_init, lr_final, max_steps, lr_delay_steps, lr_delay_mult)
+    t = state['count'] + 1
+    mults = {}
+    for name in ('prop', 'nerf'):
+        g = grads[name]
+        mult = 1.0
+        if grad_max_norm > 0:
+            ratio = grad_max_norm / (EPS32 + tree_norm(g))
+            mult = ratio if np.isnan(ratio) else min(1.0, ratio)              # jnp.minimum propagates NaN
+        mults[name] = mult
+        new_p, new_mu, new_nu = [], [], []
+        for (p_k, p_b), (g_k, g_b), (m_k, m_b), (v_k, v_b) in zip(state[name], g, state['mu'][name], state['nu'][name]):
+            out = []
+            for p_, g_, m_, v_ in ((p_k, g_k, m_k, v_k), (p_b, g_b, m_b, v_b)):
+                with np.errstate(invalid='ignore', over='ignore'):
+                    gg = np.nan_to_num((mult * g_).astype(p_.dtype))           # jnp.nan_to_num: nan -> 0, inf -> finfo.max
+                m2 = adam_b1 * m_ + (1 - adam_b1) * gg
+                v2 = adam_b2 * v_ + (1 - adam_b2) * gg * gg
+                m_hat = m2 / (1 - adam_b1 ** t)
+                v_hat = v2 / (1 - adam_b2 ** t)
+                out.append((p_ - lr * m_hat / (np.sqrt(v_hat) + adam_eps), m2, v2))
+            new_p.append((out[0][0], out[1][0]))
+            new_mu.append((out[0][1], out[1][1]))
+            new_nu.append((out[0][2], out[1][2]))
+        state[name], state['mu'][name], state['nu'][name] = new_p, new_mu, new_nu
+    state['count'] = t
+    return mults
+
+
+def loss_and_grads(prop_params, nerf_params, rays, rgb_gt, disps_sup, train_frac=1.0, jitter01=None, basis=None,
+                   data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, depth_loss_type='mse', lambda_depth=0.1,
+                   depth_sigma=0.01, depth_scale=1.0, interlevel_loss_mult=1.0, distortion_loss_mult=0.01, bg_rgb=1.0, q=None,
+                   **model_kw):
+    """loss_fn + jax.value_and_grad of train_utils.py:258-333 for configs/360.gin (data_coarse_loss_mult = 0,
+    compute_disp_metrics = True): the total of :297 = data (incl. data_loss_mult * lambda * depth[-1], :136-139) +
+    stats['loss_disp_mse'] (lambda * sum of ALL levels' depth terms, :143, :268-269) + interlevel + distortion, and its
+    gradient w.r.t. both MLPs by the closed forms of this module (sample positions carry no gradient: models.py:203-204).
+    Returns (stats dict, grads dict(prop=[(dk, db)], nerf=[...]))."""
+    caches = []
+    renderings, history = model_forward(prop_params, nerf_params, rays, train_frac, jitter01, basis, bg_rgb=bg_rgb,
+                                        caches=caches, q=q, **model_kw)
+    n = rgb_gt.shape[0]
+    data, st = compute_data_loss(rgb_gt, disps_sup, renderings, history, rays['directions'], data_loss_type=data_loss_type,
+                                 charb_padding=charb_padding, data_loss_mult=data_loss_mult, depth_loss_type=depth_loss_type,
+                                 lambda_depth=lambda_depth, depth_sigma=depth_sigma, depth_scale=depth_scale)
+    dep = st['depth_losses']
+    disp = lambda_depth * dep.sum()
+    inter = interlevel_loss(history, interlevel_loss_mult)
+    dist = distortion_loss(history, distortion_loss_mult)
+    stats = dict(loss=data + disp + inter + dist, data=data, loss_disp_mse=disp, interlevel=inter, distortion=dist,
+                 depth_losses=dep, mses=st['mses'])
+    L = len(history)
+    # ---- d total / d (rgb, distance_mean, weights) per level
+    g_w = [np.zeros_like(h['weights']) for h in history]
+    g_dm = [np.zeros(n, h['weights'].dtype) for h in history]
+    resid = renderings[-1]['rgb'] - rgb_gt
+    if data_loss_type == 'charb':
+        g_rgb = data_loss_mult * resid / np.sqrt(resid ** 2 + charb_padding ** 2) / (3 * n)
+    else:
+        g_rgb = data_loss_mult * 2 * resid / (3 * n)
+    m = (disps_sup > 0).astype(g_rgb.dtype)
+    sigma = depth_sigma * depth_scale
+    for i in range(L):
+        k = lambda_depth * (1.0 + (data_loss_mult if i == L - 1 else 0.0))            # :136-143
+        if depth_loss_type in ('mse', 'l1'):
+            diff = m * renderings[i]['distance_mean'] - m * disps_sup
+            g_dm[i] = k * (2 * diff if depth_loss_type == 'mse' else np.sign(diff)) * m / n
+        elif depth_loss_type in ('kl', 'urf'):
+            gw, gd = depth_loss_grads(history[i]['weights'], history[i]['tdist'], disps_sup, renderings[i]['distance_mean'],
+                                      sigma, rays['directions'], depth_loss_type)
+            g_w[i] = g_w[i] + k * gw
+            g_dm[i] = g_dm[i] + k * gd
+    c, w = history[-1]['sdist'], history[-1]['weights']
+    g_w[-1] = g_w[-1] + distortion_loss_mult * lossfun_distortion_grad_w(c, w) / n
+    for i in range(L - 1):
+        g_w[i] = g_w[i] + interlevel_loss_mult * lossfun_outer_grad_w_env(c, w, history[i]['sdist'], history[i]['weights']) / \
+            (n * w.shape[-1])
+    # ---- back through the compositing and the MLPs
+    grads = dict(prop=None, nerf=None)
+    for i in range(L):
+        is_nerf = i == L - 1
+        h = history[i]
+        gw_r, g_rgbs = volumetric_rendering_backward(h['rgb'], h['weights'], h['tdist'], bg_rgb, g_rgb if is_nerf else None, g_dm[i])
+        g_density = alpha_weights_backward(h['density'], h['tdist'], rays['directions'], g_w[i] + gw_r, True)
+        gl = mlp_backward(nerf_params if is_nerf else prop_params, caches[i], g_density, g_rgbs if is_nerf else None, q=q)
+        key = 'nerf' if is_nerf else 'prop'
+        grads[key] = gl if grads[key] is None else [(a + c_, b + d_) for (a, b), (c_, d_) in zip(grads[key], gl)]
+    return stats, grads
+
+
+def depth_loss_grads(weights, tdist, termination_depth, predicted_depth, sigma, dirs, depth_loss_type):
+    """Closed-form gradient of depth_loss() w.r.t. (weights, predicted_depth) with upstream's `.sum(-2)` / mask broadcast
+    (n == S: column s meets the mask and expected term of ray s; n == 1: of ray 0)."""
+    n, S = weights.shape
+    if n != S and n != 1:
+        raise ValueError('operands could not be broadcast together with shapes (%d,) (%d,)' % (S, n))
+    steps = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
+    mask = (termination_depth > 0).astype(weights.dtype)
+    mcol = np.broadcast_to(mask, (S,))                                            # [S]: mask met by column s
+    td = termination_depth[:, None]
+    g_dm = np.zeros(n, weights.dtype)
+    if depth_loss_type == 'kl':
+        lengths = (tdist[..., 1:] - tdist[..., :-1]) * np.linalg.norm(dirs[..., None, :], axis=-1)
+        g_w = -np.exp(-((steps - td) ** 2) / (2 * sigma)) * lengths / (weights + 1e-7) * mcol[None, :] / S
+    else:
+        scale = sigma / URF_SIGMA_SCALE_FACTOR
+        pdf = np.exp(-((steps - td) ** 2) / (2 * scale ** 2) - np.log(scale) - np.log(np.sqrt(2 * np.pi)))
+        near = np.logical_and(steps <= td + sigma, steps >= td - sigma)
+        empty = steps < td - sigma
+        g_w = (near * 2 * (weights - pdf) + empty * 2 * weights) * mcol[None, :] / S
+        e = -2 * (termination_depth - predicted_depth) * mask                     # d expected / d pred, masked by the own ray
+        g_dm = e / S if n == S else e * 1.0                                        # n == 1: S columns x 1/S
+    return g_w, g_dm
+
+
+def train_step(state, rays, rgb_gt, disps_sup, train_frac=None, jitter01=None, max_steps=250000, grad_max_norm=0.001,
+               adam_eps=1e-6, **loss_kw):
+    """train_utils.create_train_step's train_step (:259-364) on one device: loss_fn, gradients, [pmean is the identity],
+    clip, nan_to_num, Adam update of both MLPs.  train_frac defaults to count / (max_steps - 1) like train.py feeds it.
+    Mutates `state`; returns (stats, grads before clipping, clip multipliers)."""
+    if train_frac is None:
+        train_frac = float(np.clip(state['count'] / (max_steps - 1), 0, 1))
+    stats, grads = loss_and_grads(state['prop'], state['nerf'], rays, rgb_gt, disps_sup, train_frac, jitter01, **loss_kw)
+    mults = apply_gradients(state, grads, max_steps=max_steps, grad_max_norm=grad_max_norm, adam_eps=adam_eps)
+    return stats, grads, mults

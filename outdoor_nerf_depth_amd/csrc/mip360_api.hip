@@ -22,6 +22,9 @@ void mip360_launch_losses(hipStream_t st, int n, int s_nerf, int s_prop, int n_p
                           float dist_mult, float* scalars, float* g_rgb, float* g_dm, float* g_w_nerf,
                           float* const* g_w_prop, float* ws, float prop_depth_weight, const float* const* dm_prop,
                           float* const* g_dm_prop);
+void mip360_launch_depth_klurf(hipStream_t st, int type, int n, int S, const float* w, const float* td, const float* sup,
+                               const float* dm, const float* dirs, float sigma, float scale, float* out, float* g_w,
+                               float* g_dm, float* accum);
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                           int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux,
                           void* mask, int ldmask);
@@ -125,6 +128,25 @@ int mip360_losses(void* stream, int n_rays, int s_nerf, int s_prop, int n_prop, 
                        depth_weight, interlevel_mult, distortion_mult, scalars, g_rgb, g_distance_mean, g_w_nerf, g_w_prop,
                        workspace, prop_depth_weight, dm_prop, g_dm_prop);
   return check_launch("losses");
+}
+
+int mip360_depth_loss_klurf(void* stream, int depth_loss_type, int n_rays, int n_samples, const float* weights,
+                            const float* tdist, const float* depth_sup, const float* distance_mean, const float* directions,
+                            float sigma, float scale, float* loss_out, float* g_weights, float* g_distance_mean,
+                            float* total_accum) {
+  REQUIRE(depth_loss_type == MIP360_DEPTH_KL || depth_loss_type == MIP360_DEPTH_URF, "depth_loss_type must be 3 (kl) or 4 (urf)");
+  REQUIRE(n_rays > 0 && n_samples >= 1 && n_samples <= MIP360_MAX_SAMPLES, "1 <= n_samples <= 64");
+  REQUIRE(weights && tdist && depth_sup && loss_out && sigma > 0.f, "non-null pointers, sigma > 0");
+  if (depth_loss_type == MIP360_DEPTH_KL) REQUIRE(directions, "kl needs the ray directions");
+  if (depth_loss_type == MIP360_DEPTH_URF) REQUIRE(distance_mean, "urf needs distance_mean");
+  if (n_rays != n_samples && n_rays != 1)
+    return fail(MIP360_ERR_ARG,
+                "mip360_depth_loss_klurf: operands could not be broadcast together with shapes (%d,) (%d,) -- upstream's "
+                "loss.sum(-2) * depth_mask (internal/depth_loss.py:27,64) needs n_rays == n_samples or n_rays == 1",
+                n_samples, n_rays);
+  mip360_launch_depth_klurf((hipStream_t)stream, depth_loss_type, n_rays, n_samples, weights, tdist, depth_sup, distance_mean,
+                            directions, sigma, scale, loss_out, g_weights, g_distance_mean, total_accum);
+  return check_launch("depth_loss_klurf");
 }
 
 int mip360_dir_encode(void* stream, int n_rays, int n_samples, const float* viewdirs, void* out_bf16, int ld, int col0,

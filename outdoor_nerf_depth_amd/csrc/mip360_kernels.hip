@@ -507,7 +507,9 @@ __global__ __launch_bounds__(256) void losses_ray_kernel(LossArgs a) {
       const float sup = a.sup[ray];
       const float m = sup > 0.f ? 1.f : 0.f;
       const float diff = m * a.dm[ray] - m * sup;
-      const float k = a.data_mult * a.lambda_depth * a.depth_weight / (float)n;
+      // train_utils.py:139-143 + :268-269: data_loss_mult * lambda * dep[-1] (inside `data`) + lambda * dep[-1] (inside
+      // stats['loss_disp_mse'], NOT scaled by data_loss_mult): depth_weight counts the two appearances, data_mult scales one
+      const float k = (a.data_mult + (a.depth_weight - 1.f)) * a.lambda_depth / (float)n;
       if (a.depth_type == 1) { dep = diff * diff; g = k * 2.f * diff * m; }
       else { dep = fabsf(diff); g = k * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * m; }
     }
@@ -612,7 +614,8 @@ __global__ __launch_bounds__(1024) void losses_reduce_kernel(int n, int s_nerf, 
     const float inter = inter_mult * (float)(sh[2][0] / ((double)n * s_nerf));
     const float dist = dist_mult * (float)(sh[3][0] / n);
     const float dep_prop = depth_type ? (float)(sh[4][0] / n) : 0.f;
-    scalars[0] = data_mult * (data + lambda_depth * depth_weight * dep) + lambda_depth * prop_depth_weight * dep_prop + inter + dist;
+    scalars[0] = data_mult * (data + lambda_depth * dep) + lambda_depth * (depth_weight - 1.f) * dep +
+                 lambda_depth * prop_depth_weight * dep_prop + inter + dist;
     scalars[1] = data; scalars[2] = dep; scalars[3] = inter; scalars[4] = dist; scalars[5] = dep_prop;
   }
 }
@@ -635,6 +638,73 @@ __global__ void dir_encode_kernel(int n, int S, const float* __restrict__ viewdi
     v = sinf(half ? sx + 1.5707963267948966f : sx);
   }
   out[(size_t)row * ld + col0 + c] = (__bf16)v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// depth_loss.depth_loss for 'kl' / 'urf' of ONE level (internal/depth_loss.py:5-102), value + gradients.
+//   steps = mid-points of tdist, lengths = interval widths * |dirs|;
+//   kl : l[r,s] = -log(w + 1e-7) * exp(-(steps - gt[r])^2 / (2 sigma)) * lengths
+//   urf: near[r,s] = [gt - sigma <= steps <= gt + sigma] * (w - N(steps - gt; 0, sigma / 3))^2,
+//        empty[r,s] = [steps < gt - sigma] * w^2, expected[r] = (gt - pred)^2
+// Upstream reduces with `.sum(-2)` -- over the RAY axis -- and multiplies the [S] result by the [n] mask, which only
+// broadcasts for n == S (column s meets ray s's mask / expected term) or n == 1 (every column meets ray 0's); the C ABI
+// rejects other shapes like JAX does.  value = mean over the S columns.  One workgroup: thread -> column(s), a sequential
+// float32 sum over the rays of a column (deterministic).  g_w [n,S] and g_dm [n] are ACCUMULATED (+= scale * gradient).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_klurf_kernel(int type, int n, int S, const float* __restrict__ w,
+                                                          const float* __restrict__ td, const float* __restrict__ sup,
+                                                          const float* __restrict__ dm, const float* __restrict__ dirs,
+                                                          float sigma, float scale, float* __restrict__ out,
+                                                          float* __restrict__ g_w, float* __restrict__ g_dm,
+                                                          float* __restrict__ accum) {
+  __shared__ double sh[256];
+  double part = 0.0;
+  const float inv_S = 1.f / (float)S;
+  const float usig = sigma / 3.f;                                    // URF_SIGMA_SCALE_FACTOR
+  const float log_norm = logf(usig) + logf(sqrtf(2.f * 3.14159265358979323846f));
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const int ri = n == 1 ? 0 : s;                                   // the ray whose mask / expected term meets column s
+    const float mk = sup[ri] > 0.f ? 1.f : 0.f;
+    float col = 0.f;
+    for (int r = 0; r < n; ++r) {
+      const float t0 = td[(size_t)r * (S + 1) + s], t1 = td[(size_t)r * (S + 1) + s + 1];
+      const float step = 0.5f * (t0 + t1), gt = sup[r], wi = w[(size_t)r * S + s];
+      float g = 0.f;
+      if (type == 3) {
+        const float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+        const float len = (t1 - t0) * sqrtf(dx * dx + dy * dy + dz * dz);
+        const float d = step - gt;
+        const float e = expf(-(d * d) / (2.f * sigma)) * len;
+        col += -logf(wi + 1e-7f) * e;
+        g = -e / (wi + 1e-7f);
+      } else {
+        const float d = step - gt;
+        const bool near = step <= gt + sigma && step >= gt - sigma, empty = step < gt - sigma;
+        const float pdf = expf(-(d * d) / (2.f * usig * usig) - log_norm);
+        if (near) { col += (wi - pdf) * (wi - pdf); g += 2.f * (wi - pdf); }
+        if (empty) { col += wi * wi; g += 2.f * wi; }
+      }
+      if (g_w) g_w[(size_t)r * S + s] += scale * inv_S * mk * g;
+    }
+    if (type == 4) {
+      const float diff = sup[ri] - dm[ri];
+      col += diff * diff;
+      if (g_dm && n != 1) g_dm[ri] += scale * inv_S * mk * (-2.f * diff);
+    }
+    part += (double)(col * mk);
+  }
+  sh[threadIdx.x] = part;
+  __syncthreads();
+  for (int d = blockDim.x >> 1; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float value = (float)(sh[0] / (double)S);
+    out[0] = value;
+    if (type == 4 && n == 1 && g_dm) g_dm[0] += scale * (sup[0] > 0.f ? 1.f : 0.f) * (-2.f * (sup[0] - dm[0]));   // S columns x 1/S
+    if (accum) { accum[0] += scale * value; accum[1] += value; }
+  }
 }
 
 }  // namespace mip360
@@ -696,4 +766,10 @@ void mip360_launch_losses(hipStream_t st, int n, int s_nerf, int s_prop, int n_p
   hipLaunchKernelGGL(losses_ray_kernel, dim3((n + RPB - 1) / RPB), dim3(256), 0, st, a);
   hipLaunchKernelGGL(losses_reduce_kernel, dim3(1), dim3(1024), 0, st, n, s_nerf, ws, data_mult, depth_type, lambda_depth,
                      depth_weight, inter_mult, dist_mult, n_dm, prop_depth_weight, scalars);
+}
+void mip360_launch_depth_klurf(hipStream_t st, int type, int n, int S, const float* w, const float* td, const float* sup,
+                               const float* dm, const float* dirs, float sigma, float scale, float* out, float* g_w,
+                               float* g_dm, float* accum) {
+  hipLaunchKernelGGL(depth_klurf_kernel, dim3(1), dim3(256), 0, st, type, n, S, w, td, sup, dm, dirs, sigma, scale, out, g_w,
+                     g_dm, accum);
 }

@@ -482,7 +482,9 @@ __global__ void clip_mult_kernel(int n_partial, const float* __restrict__ partia
   double acc = 0;
   for (int i = 0; i < n_partial; ++i) acc += (double)partial[i];
   const float norm = (float)sqrt(acc);
-  out[0] = max_norm > 0.f ? fminf(1.f, max_norm / (1.1920928955078125e-07f + norm)) : 1.f;
+  // jnp.minimum(1, max_norm / (eps + norm)) (train_utils.py:228-229) PROPAGATES a NaN norm (fminf would return 1)
+  const float ratio = max_norm / (1.1920928955078125e-07f + norm);
+  out[0] = max_norm > 0.f ? (ratio != ratio ? ratio : fminf(1.f, ratio)) : 1.f;
   out[1] = norm;
 }
 // optax.adam (scale_by_adam + scale(-lr)): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; update = -lr m_hat / (sqrt(v_hat) + eps)
@@ -491,7 +493,12 @@ __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __res
                             float bc1, float bc2) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float gi = g[i] * (gmult ? gmult[0] : 1.f);
+  float gi = g[i] * (gmult ? gmult[0] : 1.f);
+  // grad = tree_map(jnp.nan_to_num, grad) after the clipping (train_utils.py:345): NaN -> 0, +-inf -> +-FLT_MAX, so one
+  // non-finite gradient (then norm = inf / NaN, multiplier 0 / NaN) costs one step instead of poisoning mu, nu, params
+  if (gi != gi) gi = 0.f;
+  else if (gi > 3.4028234663852886e38f) gi = 3.4028234663852886e38f;
+  else if (gi < -3.4028234663852886e38f) gi = -3.4028234663852886e38f;
   const float mi = b1 * m[i] + (1.f - b1) * gi;
   const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
   m[i] = mi;

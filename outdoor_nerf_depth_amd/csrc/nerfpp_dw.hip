@@ -76,55 +76,29 @@ __device__ __forceinline__ bf16x8 tr_frag(lds_addr off, uint32_t row2 = 512) {
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + row2));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-// Narrow jobs size their LDS images by the operand width: a segment holds 2 rows of W bytes (W = the job's column
-// bytes; every tensor is a multiple of 32 columns = 64 B wide) + 64 B of padding, so that consecutive segments sit 16 or
-// 48 banks apart (4 consecutive segments always fall into 4 disjoint 16-bank windows, like in the full-width image);
-// 16 segments per 32-row chunk.  Smaller chunks leave room for a deeper ring in the same LDS.
-//
-// DMA of a narrow image ("dense" mapping): a global_load_lds wave-instruction always fills 1 KiB of LDS, lane l at +16 l.
-// Issued per segment, an instruction for a 64-byte-wide tensor (dP, DIRX) would carry 8 live lanes out of 64 and the
-// narrow launch would spend as many DMA instructions on its 10-26 KB chunks as the full one on 32 KB (it ran at 0.67 of the
-// full launch's byte rate).  Here instruction j of an image covers image bytes [1024 j, 1024 j + 1024) whatever they
-// are -- several segments of a narrow tensor, lanes that fall on padding switched off -- so a 64-byte-wide tensor takes 3
-// instructions per chunk instead of 16, a 256-byte-wide one 9.
+// Narrow jobs size their LDS images by the operand width: a segment holds 2 rows of W bytes (W = the
+// job's column bytes rounded up to 64 / 128 / 256 / 512) + 64 B of padding, so that consecutive segments
+// sit 16 banks apart like in the full-width image; 16 segments per 32-row chunk.  Smaller chunks leave
+// room for a deeper ring in the same LDS (the narrow jobs are bound by bytes in flight).
 struct NarrowGeom {
   uint32_t w[2];        // image row bytes of A, B
   uint32_t segw[2];     // 2 * w + 64
   uint32_t img[2];      // 16 * segw
-  uint32_t ninst[2];    // DMA wave-instructions per plane: ceil((15 * segw + 2 * w) / 1024)
   uint32_t chunk;       // P * (img[0] + img[1])
   int nbuf;             // ring depth: min(8, LDS bytes / chunk)
 };
+__device__ __forceinline__ uint32_t pow2_width(int bytes) { return bytes <= 64 ? 64u : bytes <= 128 ? 128u : bytes <= 256 ? 256u : 512u; }
 template <int P>
 __device__ __forceinline__ NarrowGeom narrow_geom(const DwJob& job, uint32_t lds_bytes) {
   NarrowGeom g;
-  g.w[0] = (uint32_t)(job.n_o * 2 + 63) / 64 * 64;
-  g.w[1] = (uint32_t)(job.n_i * 2 + 63) / 64 * 64;
+  g.w[0] = pow2_width(job.n_o * 2);
+  g.w[1] = pow2_width(job.n_i * 2);
 #pragma unroll
-  for (int o = 0; o < 2; ++o) {
-    g.segw[o] = 2 * g.w[o] + 64;
-    g.img[o] = 16 * g.segw[o];
-    g.ninst[o] = (15 * g.segw[o] + 2 * g.w[o] + 1023) / 1024;
-  }
+  for (int o = 0; o < 2; ++o) { g.segw[o] = 2 * g.w[o] + 64; g.img[o] = 16 * g.segw[o]; }
   g.chunk = P * (g.img[0] + g.img[1]);
   const int n = (int)(lds_bytes / g.chunk);
   g.nbuf = n > 8 ? 8 : n;
   return g;
-}
-// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the count must be an immediate
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-  switch (n) {
-#define NERFPP_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    NERFPP_W(0) NERFPP_W(1) NERFPP_W(2) NERFPP_W(3) NERFPP_W(4) NERFPP_W(5) NERFPP_W(6) NERFPP_W(7) NERFPP_W(8) NERFPP_W(9)
-    NERFPP_W(10) NERFPP_W(11) NERFPP_W(12) NERFPP_W(13) NERFPP_W(14) NERFPP_W(15) NERFPP_W(16) NERFPP_W(17) NERFPP_W(18) NERFPP_W(19)
-    NERFPP_W(20) NERFPP_W(21) NERFPP_W(22) NERFPP_W(23) NERFPP_W(24) NERFPP_W(25) NERFPP_W(26) NERFPP_W(27) NERFPP_W(28) NERFPP_W(29)
-    NERFPP_W(30) NERFPP_W(31) NERFPP_W(32) NERFPP_W(33) NERFPP_W(34) NERFPP_W(35) NERFPP_W(36) NERFPP_W(37) NERFPP_W(38) NERFPP_W(39)
-    NERFPP_W(40) NERFPP_W(41) NERFPP_W(42) NERFPP_W(43) NERFPP_W(44) NERFPP_W(45) NERFPP_W(46) NERFPP_W(47) NERFPP_W(48) NERFPP_W(49)
-    NERFPP_W(50) NERFPP_W(51) NERFPP_W(52) NERFPP_W(53) NERFPP_W(54) NERFPP_W(55) NERFPP_W(56) NERFPP_W(57) NERFPP_W(58) NERFPP_W(59)
-    NERFPP_W(60)
-#undef NERFPP_W
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // deeper than the counter: wait for everything (safe)
-  }
 }
 __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
   const uint4 w = *(const uint4*)&v;
@@ -296,40 +270,16 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
   } else {
     const NarrowGeom gm = narrow_geom<P>(job, lds_bytes);
     const int NB = gm.nbuf;
-    // dense DMA plan (see NarrowGeom): the chunk's instructions in the order [A plane 0 .. P-1 | B plane 0 .. P-1] are dealt
-    // round-robin to the 8 waves; this wave owns ids wave, wave + 8, ...: c_w of them.  Everything below is computed once
-    // (the geometry must not be indexed with a run-time operand index: scratch loads would sit in vmcnt between the DMA ops).
-    const int n_a = (int)gm.ninst[0], n_b = (int)gm.ninst[1], n_total = P * (n_a + n_b);
-    const int c_w = (n_total - wave + 7) >> 3;
-    constexpr int CMAX = (P * 34 + 7) / 8;           // <= 17 instructions per plane (512-byte rows)
-    // All per-instruction state lives in VGPRs (the wave-uniform parts too: held in SGPRs across the unrolled loop they
-    // spill): byte offset from ga + r0 * rb (64-bit, covers operand and plane), LDS offset, live-lane and operand bits.
-    int64_t d_goff[CMAX];
-    uint32_t d_lds[CMAX];
-    uint32_t d_act = 0, d_isb = 0;                   // bit k: this lane is live in / instruction k belongs to operand B
+    // DMA lane map: the first w/16 lanes carry row 0 of the segment, the next w/16 row 1, the rest idle
+    int d_row[2], d_col[2];
+    bool d_on[2];
 #pragma unroll
-    for (int k = 0; k < CMAX; ++k) {
-      const int id = wave + 8 * k;
-      const bool is_b = id >= P * n_a;
-      const int idl = is_b ? id - P * n_a : id, n_op = is_b ? n_b : n_a;
-      const int pl = idl >= n_op ? 1 : 0, j = idl - pl * n_op;          // P <= 2
-      const uint32_t w_o = is_b ? gm.w[1] : gm.w[0], segw_o = is_b ? gm.segw[1] : gm.segw[0];
-      const uint32_t byte = (uint32_t)j * 1024u + (uint32_t)lane * 16u;
-      const uint32_t seg = byte / segw_o, within = byte - seg * segw_o;
-      const uint32_t r = within >= w_o ? 1u : 0u, col = within - r * w_o;
-      const uint32_t rb = is_b ? (uint32_t)rb_b : (uint32_t)rb_a;
-      const bool act = id < n_total && seg < 16u && within < 2u * w_o && col < (uint32_t)(is_b ? job.n_i : job.n_o) * 2u;
-      d_act |= act ? 1u << k : 0u;
-      d_isb |= is_b ? 1u << k : 0u;
-      d_goff[k] = (is_b ? (int64_t)(gb - ga) + (int64_t)pl * (int64_t)plane_b : (int64_t)pl * (int64_t)plane_a) +
-                  (int64_t)((2u * seg + r) * rb + col);
-      d_lds[k] = (is_b ? P * gm.img[0] : 0u) + (uint32_t)pl * (is_b ? gm.img[1] : gm.img[0]) + (uint32_t)j * 1024u;
-      // pin both to vector registers: left alone the compiler keeps their wave-uniform parts in SGPRs and spills them
-      uint32_t lo = (uint32_t)d_goff[k], hi = (uint32_t)((uint64_t)d_goff[k] >> 32);
-      asm volatile("" : "+v"(lo), "+v"(hi), "+v"(d_lds[k]));
-      d_goff[k] = (int64_t)(((uint64_t)hi << 32) | lo);
+    for (int o = 0; o < 2; ++o) {
+      const int half = gm.w[o] / 16;
+      d_row[o] = lane / half;
+      d_col[o] = (lane - d_row[o] * half) * 16;
+      d_on[o] = d_row[o] < 2 && d_col[o] < (o == 0 ? job.n_o : job.n_i) * 2;
     }
-    asm volatile("" : "+v"(d_act), "+v"(d_isb));
     int slot_i = 0, next_i = 0;
     auto issue = [&]() {                           // next chunk of the slice -> next ring slot
       const int c = next_i, slot = slot_i;
@@ -338,12 +288,17 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
       if (c >= nchunk || dbg == 2) return;
       const int64_t r0 = r_begin + (int64_t)c * 32;
       const uint32_t buf = lds_base + slot * gm.chunk;
-      const int64_t ra = r0 * rb_a, rbb = r0 * rb_b;   // the chunk's first row in each operand
-      asm volatile("" : "+v"(d_act), "+v"(d_isb));   // (keeps the lane masks' compares here instead of hoisted into SGPR pairs)
 #pragma unroll
-      for (int k = 0; k < CMAX; ++k) {
-        if (k < c_w) {                               // wave-uniform; every issued instruction has live lanes (counted waits)
-          if ((d_act >> k) & 1u) glds16(ga + (d_goff[k] + (((d_isb >> k) & 1u) ? rbb : ra)), buf + d_lds[k]);
+      for (int x = 0; x < 4 * P; ++x) {
+        // id = x * 8 + wave (0 .. 32P-1): operand and plane depend on x only (wave < 8), so they are
+        // compile-time after unrolling -- the geometry arrays must not be indexed dynamically (scratch
+        // loads would sit in vmcnt between the DMA ops)
+        const int op = (x * 8) / (16 * P), rem0 = x * 8 - op * 16 * P, pl = rem0 >> 4, seg = (rem0 & 15) + wave;
+        if (d_on[op]) {
+          const int rb = op == 0 ? rb_a : rb_b;
+          const char* src = (op == 0 ? ga + pl * plane_a : gb + pl * plane_b) +
+                            (size_t)(r0 + 2 * seg + d_row[op]) * rb + d_col[op];
+          glds16(src, buf + (op == 0 ? 0u : P * gm.img[0]) + pl * gm.img[op] + seg * gm.segw[op]);
         }
       }
     };
@@ -352,7 +307,15 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
     int slot_c = 0;
     for (int c = 0; c < nchunk; ++c) {
       const int younger = nchunk - 1 - c < NB - 2 ? nchunk - 1 - c : NB - 2;
-      wait_vmcnt_dyn(dbg == 2 ? 0 : younger * c_w);   // this wave's share of chunk c has landed
+      switch (younger) {                           // wave-uniform; the count must be an immediate
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * DMA_PER_CHUNK) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DMA_PER_CHUNK) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_PER_CHUNK) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * DMA_PER_CHUNK) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * DMA_PER_CHUNK) : "memory"); break;
+      }
       __builtin_amdgcn_s_barrier();
       issue();
       const lds_addr buf = slot_c * gm.chunk;

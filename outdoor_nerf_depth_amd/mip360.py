@@ -5,10 +5,11 @@ Upstream (nerf-methods/mipnerf360, JAX) has no FFI; this module mirrors its call
 `train_utils.py:72-169` as `losses` -- with the arithmetic in HIP kernels behind the C ABI of include/mip360_hip.h.
 PyTorch is device memory and streams only.  There is no CPU fallback: `lib()` raises if the library is missing.
 
-Status (round 2): forward pass of the three sampling levels (resampling, cone casting + contraction + IPE, the
-PropMLP / NerfMLP dense layers on the matrix cores, compositing), the loss terms with their gradients, and the
-compositing backward are implemented and parity-tested against oracle/mip360_oracle.py; the MLP backward GEMMs
-(dX, dW), Adam with the upstream learning-rate schedule / gradient clipping and the pmean data-parallel step are not.
+Built: the whole training step of train_utils.create_train_step (:239-370) -- forward pass of the three sampling levels
+(resampling, cone casting + contraction + IPE, the PropMLP / NerfMLP dense layers on the matrix cores, compositing), the
+loss terms with their gradients (charb / mse data term; mse / l1 / kl / urf depth terms; interlevel; distortion), the
+compositing and MLP backward (dX, dW), per-MLP gradient clipping + nan_to_num, Adam with the upstream learning-rate schedule
+and the pmean data-parallel step -- parity-tested link by link and end to end against oracle/mip360_oracle.py.
 """
 import ctypes as C
 import os
@@ -18,7 +19,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MIP360_HIP_LIB') or os.path.join(_HERE, 'libmip360_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
 _fp = C.c_void_p
 _fpp = C.POINTER(C.c_void_p)
@@ -35,6 +36,8 @@ SYMBOLS = {
     'mip360_losses': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fpp, _fpp, C.c_int,
                                 C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp,
                                 _fpp, _fp, C.c_float, _fpp, _fpp]),
+    'mip360_depth_loss_klurf': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp,
+                                          _fp, _fp]),
     'mip360_linear_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, _fp,
                                      C.c_int, _fp, C.c_int, _fp, C.c_int]),
     'mip360_relu_mask_bytes': (C.c_int64, [C.c_int, C.c_int, _fp]),
@@ -209,12 +212,32 @@ def render_level_backward(density, rgb_samples, tdist, directions, g_weights=Non
     return g_density, g_rgbs
 
 
+DEPTH_TYPES = {None: 0, 'none': 0, 'mse': 1, 'l1': 2, 'kl': 3, 'urf': 4}
+
+
+def depth_loss_klurf(depth_loss_type, weights, tdist, depth_sup, distance_mean, directions, sigma, scale=1.0, g_weights=None,
+                     g_distance_mean=None):
+    """depth_loss.depth_loss (internal/depth_loss.py:67-102) for 'kl' / 'urf' of one level: returns the value (device
+    scalar); g_weights [n,S] / g_distance_mean [n], when given, are ACCUMULATED with scale * gradient.  Shapes that
+    upstream's `loss.sum(-2) * depth_mask` cannot broadcast (n != S and n != 1) raise, like JAX does."""
+    n, S = weights.shape
+    out = torch.empty(1, device=weights.device)
+    _check(lib().mip360_depth_loss_klurf(_stream(), DEPTH_TYPES[depth_loss_type], n, S, _p(_f32(weights)), _p(_f32(tdist)),
+                                         _p(_f32(depth_sup)), _p(_f32(distance_mean)) if distance_mean is not None else None,
+                                         _p(_f32(directions)) if directions is not None else None, float(sigma), float(scale),
+                                         _p(out), _p(g_weights), _p(g_distance_mean), None), 'mip360_depth_loss_klurf')
+    return out
+
+
 def losses(rgb, rgb_gt, distance_mean, depth_sup, sdist_nerf, w_nerf, sdist_prop, w_prop, data_loss_type='charb',
            charb_padding=0.001, data_loss_mult=1.0, depth_loss_type='mse', lambda_depth=0.1, depth_weight=2.0,
-           interlevel_loss_mult=1.0, distortion_loss_mult=0.01, dm_prop=None, prop_depth_weight=1.0):
+           interlevel_loss_mult=1.0, distortion_loss_mult=0.01, dm_prop=None, prop_depth_weight=1.0, tdist_nerf=None,
+           tdist_prop=None, directions=None, depth_sigma=0.01):
     """train_utils.py:72-169 + loss_fn :258-300.  depth_weight = 2 / prop_depth_weight = 1 are the reference's
     effective weights: its total adds stats['loss_disp_mse'] = lambda * sum over ALL levels (:143, :268-269) on top of
-    the lambda * depth[nerf] already inside the data loss.  dm_prop: the proposal levels' distance_mean [n] each.
+    the data_loss_mult * lambda * depth[nerf] already inside the data loss.  dm_prop: the proposal levels' distance_mean
+    [n] each.  depth_loss_type 'kl' / 'urf' (internal/depth_loss.py, dispatch train_utils.py:121-128) also need every
+    level's tdist, the ray directions and depth_sigma (= config.depth_sigma * config.depth_scale).
     Returns (scalars[6], g_rgb, g_distance_mean, g_w_nerf, [g_w_prop], [g_dm_prop])."""
     n, Sn = w_nerf.shape
     Sp = w_prop[0].shape[1] if w_prop else 1
@@ -226,14 +249,36 @@ def losses(rgb, rgb_gt, distance_mean, depth_sup, sdist_nerf, w_nerf, sdist_prop
     dm_prop = list(dm_prop) if dm_prop is not None else []
     g_dmp = [torch.empty(n, device=dev) for _ in dm_prop]
     arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
-    dtype = {None: 0, 'none': 0, 'mse': 1, 'l1': 2}[depth_loss_type]
+    dtype = DEPTH_TYPES[depth_loss_type]
+    klurf = dtype >= 3
+    if klurf:
+        if tdist_nerf is None or tdist_prop is None or (dtype == 3 and directions is None):
+            raise Mip360Error("depth_loss_type %r needs tdist_nerf, tdist_prop and the ray directions" % depth_loss_type)
+        if dtype == 4 and len(dm_prop) != len(w_prop):
+            raise Mip360Error("depth_loss_type 'urf' needs the proposal levels' distance_mean (dm_prop)")
     _check(lib().mip360_losses(_stream(), n, Sn, Sp, len(w_prop), _p(_f32(rgb)), _p(_f32(rgb_gt)),
                                _p(distance_mean), _p(depth_sup), _p(_f32(sdist_nerf)), _p(_f32(w_nerf)), arr(sdist_prop),
-                               arr(w_prop), int(data_loss_type == 'charb'), float(charb_padding), float(data_loss_mult), dtype,
-                               float(lambda_depth), float(depth_weight), float(interlevel_loss_mult),
+                               arr(w_prop), int(data_loss_type == 'charb'), float(charb_padding), float(data_loss_mult),
+                               0 if klurf else dtype, float(lambda_depth), float(depth_weight), float(interlevel_loss_mult),
                                float(distortion_loss_mult), _p(scalars), _p(g_rgb), _p(g_dm), _p(g_wn), arr(g_wp), _p(ws),
                                float(prop_depth_weight), arr(dm_prop) if dm_prop else None, arr(g_dmp) if dm_prop else None),
            'mip360_losses')
+    if klurf:
+        # per-level depth_loss.depth_loss values with the weights of train_utils.py:136-143: the NeRF level enters the
+        # total as data_loss_mult * lambda (inside `data`) + (depth_weight - 1) * lambda (loss_disp_mse), a proposal
+        # level as prop_depth_weight * lambda; their gradients are added to what mip360_losses left in g_w_* / g_d*
+        k_nerf = (data_loss_mult + (depth_weight - 1.0)) * lambda_depth
+        v = depth_loss_klurf(depth_loss_type, w_nerf, tdist_nerf, depth_sup, distance_mean, directions, depth_sigma, k_nerf,
+                             g_wn, g_dm if dtype == 4 else None)
+        scalars[2:3] = v
+        scalars[0:1] += k_nerf * v
+        scalars[5:6] = 0.0
+        for k in range(len(w_prop)):
+            kp = prop_depth_weight * lambda_depth
+            v = depth_loss_klurf(depth_loss_type, w_prop[k], tdist_prop[k], depth_sup, dm_prop[k] if dm_prop else None,
+                                 directions, depth_sigma, kp, g_wp[k], g_dmp[k] if (dtype == 4 and g_dmp) else None)
+            scalars[5:6] += v
+            scalars[0:1] += kp * v
     return scalars, g_rgb, g_dm, g_wn, g_wp, g_dmp
 
 
@@ -574,7 +619,7 @@ class Mip360Trainer(object):
     per MLP (torch.distributed, backend nccl = RCCL)."""
 
     def __init__(self, prop_params, nerf_params, device, max_steps=250000, lambda_depth=0.1, depth_loss_type='mse',
-                 world_size=1, grad_max_norm=0.001, adam_eps=1e-6, **model_kw):
+                 world_size=1, grad_max_norm=0.001, adam_eps=1e-6, depth_sigma=0.01, depth_scale=1.0, **model_kw):
         self.device = torch.device(device)
         self.prop = TrainableMLP(prop_params, PROP_CFG, device)
         self.nerf = TrainableMLP(nerf_params, NERF_CFG, device)
@@ -582,7 +627,10 @@ class Mip360Trainer(object):
         self.cfg = dict(num_prop_samples=64, num_nerf_samples=32, num_levels=3, anneal_slope=10., dilation_multiplier=0.5,
                         dilation_bias=0.0025, bg_rgb=1.0)
         self.cfg.update(model_kw)
+        if depth_loss_type not in DEPTH_TYPES:
+            raise ValueError('depth_loss_type %r: mse / l1 (train_utils.py:108-119) or kl / urf (internal/depth_loss.py)' % depth_loss_type)
         self.max_steps, self.lambda_depth, self.depth_loss_type = max_steps, lambda_depth, depth_loss_type
+        self.depth_sigma = depth_sigma * depth_scale                      # train_utils.py:123
         self.world_size, self.grad_max_norm, self.adam_eps = world_size, grad_max_norm, adam_eps
         self.step = 0
         self.overlap_update = True
@@ -625,7 +673,9 @@ class Mip360Trainer(object):
         """train_utils.py:340-364 on the flat gradient buffer of one MLP: mean over ranks (jax.lax.pmean; SUM all-reduce
         over RCCL, then / world_size), global-norm clipping (per MLP), Adam with the log-decayed learning rate, re-pack
         of the bf16 weight copies."""
-        lr = learning_rate(self.step, max_steps=self.max_steps)
+        # optax.adam(learning_rate=lr_fn) evaluates the schedule at the PRE-increment count: lr_fn(0) on the first update
+        # (the bias correction below uses the post-increment count, like optax.scale_by_adam)
+        lr = learning_rate(self.step - 1, max_steps=self.max_steps)
         L = lib()
         if self.world_size > 1:
             import torch.distributed as dist
@@ -656,7 +706,8 @@ class Mip360Trainer(object):
         sc, g_rgb, g_dm, g_wn, g_wp, g_dmp = losses(
             nerf['rgb'], rgb_gt, nerf['distance_mean'], depth_sup, nerf['sdist'], nerf['weights'], [p['sdist'] for p in props],
             [p['weights'] for p in props], depth_loss_type=self.depth_loss_type, lambda_depth=self.lambda_depth,
-            dm_prop=[p['distance_mean'] for p in props] if self.depth_loss_type else None)
+            dm_prop=[p['distance_mean'] for p in props] if self.depth_loss_type else None, tdist_nerf=nerf['tdist'],
+            tdist_prop=[p['tdist'] for p in props], directions=rays['directions'], depth_sigma=self.depth_sigma)
         # NeRF level
         gd, grgbs = render_level_backward(nerf['density'], nerf['rgb_s'], nerf['tdist'], rays['directions'], g_wn, g_rgb, g_dm,
                                           True, self.cfg['bg_rgb'])

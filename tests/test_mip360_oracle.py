@@ -563,3 +563,292 @@ def test_mlp_backward_matches_finite_differences(which):
                 pm[li][which_p][idx] -= h
                 num = (scalar(pp) - scalar(pm)) / (2 * h)
                 np.testing.assert_allclose(g[idx], num, rtol=2e-4, atol=1e-7, err_msg='layer %d %s %r' % (li, 'Wb'[which_p], idx))
+
+
+# ================================================================================================ round 3
+# Literal-valued / closed-form cases of mipnerf360/tests/{math,coord,stepfun,render}_test.py that were not restated yet,
+# and the pieces added to the oracle this round (train step, kl / urf gradients).
+def test_stable_pos_enc_on_multiples_of_half_pi():
+    """coord_test.py:33-59: the doubling-rotation pos_enc used as the high-degree reference, on x = k pi / 2 (literal
+    expected values), and pos_enc against it at degrees where float64 is exact."""
+    def stable_pos_enc(x, n):
+        sin_x, cos_x = np.sin(x), np.cos(x)
+        out = []
+        rot = np.array([[cos_x, -sin_x], [sin_x, cos_x]], dtype='double')
+        for _ in range(n):
+            out.append(rot[::-1, 0, :])
+            rot = np.einsum('ijn,jkn->ikn', rot, rot)
+        return np.reshape(np.transpose(np.stack(out, 0), [2, 1, 0]), [-1, 2 * n])
+    n = 10
+    x = np.linspace(-np.pi, np.pi, 5)
+    z = stable_pos_enc(x, n).reshape([-1, 2, n])
+    z0, z1 = np.zeros_like(z[:, 0, :]), np.ones_like(z[:, 1, :])
+    z0[:, 0] = [0, -1, 0, 1, 0]
+    z1[:, 0] = [-1, 0, 1, 0, -1]
+    z1[:, 1] = [1, -1, 1, -1, 1]
+    np.testing.assert_allclose(z, np.stack([z0, z1], axis=1), atol=1e-10)
+    xs = np.linspace(-1, 1, 7)[:, None]
+    np.testing.assert_allclose(M.pos_enc(xs, 0, 6, append_identity=False), stable_pos_enc(xs[:, 0], 6), atol=1e-9)
+
+
+def test_safe_sin_is_accurate_and_never_nan():
+    """math_test.py:24-47 (safe_sin; safe_cos is not restated -- the path uses safe_sin only, coord.py:99)."""
+    for max_exp, check in ((10, True), (60, False)):
+        x = 10 ** np.linspace(-30, max_exp, 10000)
+        x = np.concatenate([-x[::-1], np.array([0]), x])
+        y = M.safe_sin(x)
+        assert not np.isnan(y).any()
+        if check:
+            assert np.abs(y - np.sin(x)).max() < 1e-4
+
+
+def test_learning_rate_decay_anchor_points():
+    """math_test.py:72-153: lr(0) = lr_init (x lr_delay_mult when delayed), lr(max) = lr_final, lr(max / 2) = geometric
+    mean, flat past the end, and the delayed schedule joins the plain one at lr_delay_steps."""
+    rs = np.random.RandomState(0)
+    for _ in range(10):
+        lr_init = np.exp(rs.randn() - 3)
+        lr_final = lr_init * np.exp(rs.randn() - 5)
+        max_steps = int(np.ceil(100 + 100 * np.exp(rs.randn())))
+        f = lambda s, **kw: M.learning_rate_decay(s, lr_init, lr_final, max_steps, **kw)
+        np.testing.assert_allclose(f(0), lr_init, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(f(max_steps), lr_final, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(f(max_steps / 2), np.sqrt(lr_init * lr_final), atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(f(max_steps + 100), lr_final, atol=1e-5, rtol=1e-5)
+        delay_steps = int(rs.uniform(0.1, 0.4) * max_steps)
+        delay_mult = np.exp(rs.randn() - 3)
+        kw = dict(lr_delay_steps=delay_steps, lr_delay_mult=delay_mult)
+        np.testing.assert_allclose(f(0, **kw), delay_mult * lr_init, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(f(max_steps, **kw), lr_final, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(f(delay_steps, **kw), f(delay_steps), atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(f(max_steps / 2, **kw), np.sqrt(lr_init * lr_final), atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(f(max_steps + 100, **kw), lr_final, atol=1e-5, rtol=1e-5)
+    # the Config defaults of this fork (configs.py:91,118-121) at the literal anchor points
+    lr = lambda s: M.learning_rate_decay(s, 2e-3, 2e-5, 250000, 512, 0.01)
+    np.testing.assert_allclose([lr(0), lr(250000), lr(125000)], [2e-5, 2e-5, 2e-4], rtol=1e-6)
+
+
+def test_sorted_interp_matches_numpy_interp():
+    """math_test.py:155-178 (`sort` variant: the branch invert_cdf uses)."""
+    rs = np.random.RandomState(0)
+    n, d0, d1 = 100, 10, 20
+    x = rs.randn(n, d0)
+    xp, fp = np.sort(rs.randn(n, d1), -1), np.sort(rs.randn(n, d1), -1)
+    z = M.sorted_interp(x, xp, fp)
+    np.testing.assert_allclose(z, np.stack([np.interp(x[i], xp[i], fp[i]) for i in range(n)]), atol=1e-5, rtol=1e-5)
+
+
+def test_sample_single_bin_literal():
+    """stepfun_test.py:477-495: bins [0, 1, 3, 6, 10], one-hot weights: all 625 samples inside the hot bin."""
+    bins = np.array([0, 1, 3, 6, 10], np.float32)
+    rs = np.random.RandomState(0)
+    for jit, single in ((None, False), (rs.rand(1, 625), False), (rs.rand(1, 1), True)):
+        for i in range(len(bins) - 1):
+            w = np.zeros(len(bins) - 1, np.float32)
+            w[i] = 1.
+            with np.errstate(divide='ignore'):
+                s = M.sample(bins[None], np.log(w[None]), 625, jitter01=jit, single_jitter=single)[0]
+            assert (s >= bins[i]).all() and (s <= bins[i + 1]).all()
+
+
+@pytest.mark.parametrize('randomized,bound_domain', [(False, False), (True, False), (False, True), (True, True)])
+def test_sample_intervals_unbiased_literal(randomized, bound_domain):
+    """stepfun_test.py:542-577: t = [-2.5 .. 2.5], logits [0, 0, 100, 0, 0] -- one interval [-0.5, 0.5]."""
+    n, d = 1000, 64
+    domain = (-0.5, 0.5) if bound_domain else (-np.inf, np.inf)
+    t = np.tile(np.array([-2.5, -1.5, -0.5, 0.5, 1.5, 2.5])[None], (n, 1))
+    logits = np.tile(np.array([0, 0, 100., 0, 0])[None], (n, 1))
+    jit = np.random.RandomState(0).rand(n, 1) if randomized else None
+    ts = M.sample_intervals(t, logits, d, jitter01=jit, single_jitter=True, domain=domain)
+    if randomized:
+        assert np.abs(ts.mean(-1)).max() < 0.5 / d
+        np.testing.assert_allclose(np.mean(ts[:, 0] > -0.5), 0.5, atol=3.0 / d)       # binomial spread of 1000 draws
+        np.testing.assert_allclose(np.mean(ts[:, -1] < 0.5), 0.5, atol=3.0 / d)
+    else:
+        np.testing.assert_allclose(ts.mean(-1), np.zeros(n), atol=1e-5, rtol=1e-5)
+    if bound_domain and randomized:
+        # upstream asserts the MEDIAN of the outer edges is +-0.5 (about half of the draws are clamped to the domain, so its
+        # median sits on the clamp for its PRNG key); seed-independent form: the 40 % / 60 % quantiles are the clamp value
+        np.testing.assert_allclose(np.quantile(ts[:, 0], 0.4), -0.5, atol=1e-4)
+        np.testing.assert_allclose(np.quantile(ts[:, -1], 0.6), 0.5, atol=1e-4)
+        assert ts.min() >= -0.5 and ts.max() <= 0.5
+
+
+def test_sample_single_interval_is_a_linspace():
+    """stepfun_test.py:579-586: t = 1..6, logits [0, 0, 100, 0, 0] -> linspace(3, 4, 11)."""
+    t = np.array([1, 2, 3, 4, 5, 6], np.float64)
+    got = M.sample_intervals(t, np.array([0, 0, 100, 0, 0], np.float64), 10, single_jitter=True)
+    np.testing.assert_allclose(got, np.linspace(3, 4, 11), atol=1e-5, rtol=1e-5)
+
+
+def test_lossfun_outer_monotonic_and_self_zero():
+    """stepfun_test.py:657-697: invariant under a monotonic map of t (bit for bit); zero against itself."""
+    rs = np.random.RandomState(0)
+    curve = lambda x: 1 + x ** 3
+    for _ in range(10):
+        d0, d1 = rs.randint(10, 20, 2)
+        t0, t1 = np.sort(rs.rand(d0 + 1)), np.sort(rs.rand(d1 + 1))
+        w0, w1 = np.exp(rs.randn(d0)), np.exp(rs.randn(d1))
+        np.testing.assert_array_equal(M.lossfun_outer(t0, w0, t1, w1), M.lossfun_outer(curve(t0), w0, curve(t1), w1))
+        assert (M.lossfun_outer(t0, w0, t0, w0) < 1e-10).all()
+
+
+@pytest.mark.parametrize('use_avg', [False, True])
+def test_resample_entire_domain_and_single_span(use_avg):
+    """stepfun_test.py:856-896: an interval covering everything sums all values; a sub-span of one bin returns that bin's
+    value (average) or its covered fraction (sum)."""
+    rs = np.random.RandomState(0)
+    d = 32
+    tp, vp = np.sort(rs.randn(d + 1)), rs.randn(d)
+    if not use_avg:
+        np.testing.assert_allclose(M.resample(np.array([-1e6, 1e6]), tp, vp)[0], vp.sum(), atol=1e-4)
+    pad = (tp[d // 2 + 1] - tp[d // 2]) / 4
+    t = np.array([tp[d // 2] + pad, tp[d // 2 + 1] - pad])
+    np.testing.assert_allclose(M.resample(t, tp, vp, use_avg=use_avg)[0], vp[d // 2] * (1.0 if use_avg else 0.5), atol=1e-4)
+
+
+@pytest.mark.parametrize('fn', ['cylinder_to_gaussian', 'conical_frustum_to_gaussian'])
+def test_gaussian_scaling_literal(fn):
+    """render_test.py:200-258: d = (0, 0, 1), t0 = 0.3, t1 = 0.7, radius = 0.4; scaling d by 2.7 scales the mean by 2.7,
+    the covariance along the ray by 2.7^2 and leaves the perpendicular covariance alone."""
+    d = np.array([0., 0., 1.])
+    t0, t1, radius = np.array([0.3]), np.array([0.7]), np.array([0.4])
+    f = getattr(M, fn)
+    mean, cov = f(d, t0, t1, radius, False)
+    scale = 2.7
+    mean_s, cov_s = f(scale * d, t0, t1, radius, False)
+    np.testing.assert_allclose(scale * mean, mean_s, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(scale ** 2 * cov[..., 2, 2], cov_s[..., 2, 2], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(cov[..., :2, :2], cov_s[..., :2, :2], atol=1e-5, rtol=1e-5)
+    if fn == 'cylinder_to_gaussian':          # closed form: mean (t0 + t1) / 2, var_t = (t1 - t0)^2 / 12, var_r = r^2 / 4
+        np.testing.assert_allclose(mean[0], [0, 0, 0.5], atol=1e-12)
+        np.testing.assert_allclose(np.diag(cov[0]), [0.04, 0.04, 0.16 / 12], atol=1e-12)
+
+
+def test_conical_frustum_stable_matches_the_textbook_form():
+    """render_test.py:320-331: the `stable` re-parameterisation equals the direct moments for well-conditioned frusta."""
+    rs = np.random.RandomState(0)
+    n = 50
+    d = rs.randn(n, 3)
+    t0 = np.exp(rs.uniform(-1, 1, n))
+    t1 = t0 + np.exp(rs.uniform(-1, 1, n))
+    r = np.exp(rs.uniform(-3, -1, n))
+    a = M.conical_frustum_to_gaussian(d, t0, t1, r, True, stable=True)
+    b = M.conical_frustum_to_gaussian(d, t0, t1, r, True, stable=False)
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, atol=1e-7, rtol=1e-5)
+
+
+def test_volumetric_rendering_backward_matches_finite_differences():
+    rs = np.random.RandomState(0)
+    n, S = 6, 8
+    d = rs.randn(n, 3)
+    td = np.sort(rs.uniform(0.5, 6, (n, S + 1)), -1)
+    dens, rgbs = rs.rand(n, S) * 2, rs.rand(n, S, 3)
+    far = np.full((n, 1), 1e6)
+    g_rgb, g_dm, g_wx = rs.randn(n, 3), rs.randn(n), rs.randn(n, S)
+    for opaque in (True, False):
+        def f(dd):
+            w = M.compute_alpha_weights(dd, td, d, opaque)[0]
+            r = M.volumetric_rendering(rgbs, w, td, 1.0, far)
+            return (r['rgb'] * g_rgb).sum() + (r['distance_mean'] * g_dm).sum() + (w * g_wx).sum()
+        w = M.compute_alpha_weights(dens, td, d, opaque)[0]
+        gw, g_rgbs = M.volumetric_rendering_backward(rgbs, w, td, 1.0, g_rgb, g_dm)
+        gd = M.alpha_weights_backward(dens, td, d, gw + g_wx, opaque)
+        num = np.zeros_like(dens)
+        for i in range(n):
+            for j in range(S):
+                a, b = dens.copy(), dens.copy()
+                a[i, j] += 1e-6
+                b[i, j] -= 1e-6
+                num[i, j] = (f(a) - f(b)) / 2e-6
+        np.testing.assert_allclose(gd, num, rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(g_rgbs, w[..., None] * g_rgb[:, None, :])
+
+
+@pytest.mark.parametrize('kind', ['kl', 'urf'])
+@pytest.mark.parametrize('n,S', [(6, 6), (1, 9)])
+def test_depth_loss_grads_match_finite_differences(kind, n, S):
+    """closed-form gradient of internal/depth_loss.py (with its `.sum(-2)` / mask broadcast) vs central differences."""
+    rs = np.random.RandomState(n + S)
+    td = np.sort(rs.uniform(0.5, 6, (n, S + 1)), -1)
+    w = M.softmax(rs.randn(n, S))
+    sup = np.where(rs.rand(n) < .7, rs.uniform(1, 5, n), 0.)
+    sup[0] = 3.0
+    pred, dirs, sigma = rs.uniform(1, 5, n), rs.randn(n, 3), 0.7
+    gw, gd = M.depth_loss_grads(w, td, sup, pred, sigma, dirs, kind)
+    f = lambda w_, p_: M.depth_loss(w_, td, sup, p_, sigma, dirs, kind)
+    for idx in [(0, 0), (n - 1, S - 1), (n // 2, S // 2)]:
+        a, b = w.copy(), w.copy()
+        a[idx] += 1e-7
+        b[idx] -= 1e-7
+        np.testing.assert_allclose(gw[idx], (f(a, pred) - f(b, pred)) / 2e-7, rtol=1e-4, atol=1e-9)
+    for i in range(n):
+        a, b = pred.copy(), pred.copy()
+        a[i] += 1e-6
+        b[i] -= 1e-6
+        np.testing.assert_allclose(gd[i], (f(w, a) - f(w, b)) / 2e-6, rtol=1e-5, atol=1e-9)
+    with pytest.raises(ValueError):
+        M.depth_loss_grads(np.ones((5, 3)), np.ones((5, 4)), np.ones(5), np.ones(5), 0.1, np.ones((5, 3)), kind)
+
+
+def test_apply_gradients_is_optax_adam_with_clipping_and_nan_to_num():
+    """train_utils.py:215-236, :344-347, :371-395 on hand-computable numbers: one 2-element 'MLP' per name."""
+    mk = lambda v: [(np.array([[v]], np.float64), np.array([0.0]))]
+    st = M.new_train_state(mk(1.0), mk(-2.0))
+    grads = dict(prop=[(np.array([[3e-4]]), np.array([4e-4]))], nerf=[(np.array([[30.0]]), np.array([40.0]))])
+    mult = M.apply_gradients(st, grads, max_steps=1000, grad_max_norm=1e-3, adam_eps=1e-6)
+    np.testing.assert_allclose(mult['prop'], 1.0)                                    # |g| = 5e-4 < 1e-3: untouched
+    np.testing.assert_allclose(mult['nerf'], 1e-3 / (M.EPS32 + 50.0), rtol=1e-12)    # |g| = 50: scaled to 1e-3
+    lr0 = M.learning_rate_decay(0, 2e-3, 2e-5, 1000, 512, 0.01)                      # schedule at the PRE-increment count
+    g = 3e-4
+    np.testing.assert_allclose(st['prop'][0][0][0, 0], 1.0 - lr0 * g / (abs(g) + 1e-6), rtol=1e-12)   # first step: m_hat / sqrt(v_hat) = sign
+    g = 30.0 * mult['nerf']
+    np.testing.assert_allclose(st['nerf'][0][0][0, 0], -2.0 - lr0 * g / (abs(g) + 1e-6), rtol=1e-12)
+    assert st['count'] == 1
+    # a NaN anywhere in an MLP's gradient: multiplier NaN, every entry nan_to_num'ed to 0 -- moments decay, nothing breaks
+    mu0 = st['nerf'] and st['mu']['nerf'][0][0].copy()
+    p0 = st['nerf'][0][0].copy()
+    mult = M.apply_gradients(st, dict(prop=grads['prop'], nerf=[(np.array([[np.nan]]), np.array([1.0]))]), max_steps=1000)
+    assert np.isnan(mult['nerf'])
+    np.testing.assert_allclose(st['mu']['nerf'][0][0], 0.9 * mu0)
+    assert np.isfinite(st['nerf'][0][0]).all() and st['nerf'][0][0] != p0            # the decayed momentum still moves it
+
+
+def test_loss_and_grads_total_and_gradient_against_finite_differences():
+    """loss_fn + value_and_grad (train_utils.py:258-333) at toy sizes (16 / 8 samples): the total is the sum of the four
+    terms with the depth term counted as upstream counts it, and the NeRF-MLP gradient matches central differences once
+    the stop_gradient'ed interlevel term is switched off (the proposal MLP's would also see the re-sampling)."""
+    rs = np.random.RandomState(0)
+    n = 8
+    d = rs.randn(n, 3)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    rays = dict(origins=rs.randn(n, 3) * 0.3, directions=d, viewdirs=d.copy(), radii=np.full((n, 1), 2e-3),
+                near=np.full((n, 1), 0.2), far=np.full((n, 1), 1e6))
+    small = dict(net_width=16, bottleneck_width=8, net_width_viewdirs=8)
+    saved = dict(M.PROP_CFG), dict(M.NERF_CFG)
+    M.PROP_CFG.update(small)
+    M.NERF_CFG.update(small)
+    try:
+        pp = [(w.astype(np.float64), b.astype(np.float64)) for w, b in M.init_mlp_params(M.PROP_CFG, np.random.RandomState(0))]
+        pn = [(w.astype(np.float64), b.astype(np.float64)) for w, b in M.init_mlp_params(M.NERF_CFG, np.random.RandomState(1))]
+        gt = rs.rand(n, 3)
+        sup = np.where(rs.rand(n) < .6, rs.uniform(1, 4, n), 0.)
+        jit = [rs.rand(n, 1) for _ in range(3)]
+        kw = dict(num_prop_samples=16, num_nerf_samples=8)
+        st, _ = M.loss_and_grads(pp, pn, rays, gt, sup, 0.3, jit, **kw)
+        np.testing.assert_allclose(st['loss'], st['data'] + 0.1 * st['depth_losses'].sum() + st['interlevel'] + st['distortion'])
+        for dl in ('mse', 'l1'):
+            kw2 = dict(kw, interlevel_loss_mult=0.0, depth_loss_type=dl)
+            _, g = M.loss_and_grads(pp, pn, rays, gt, sup, 0.3, jit, **kw2)
+            total = lambda pn_: M.loss_and_grads(pp, pn_, rays, gt, sup, 0.3, jit, **kw2)[0]['loss']
+            for li in (0, 4, len(pn) - 1):
+                idx = tuple(rs.randint(0, s) for s in pn[li][0].shape)
+                a = [(w.copy(), b.copy()) for w, b in pn]
+                b_ = [(w.copy(), b.copy()) for w, b in pn]
+                a[li][0][idx] += 1e-6
+                b_[li][0][idx] -= 1e-6
+                np.testing.assert_allclose(g['nerf'][li][0][idx], (total(a) - total(b_)) / 2e-6, rtol=2e-4, atol=1e-9)
+    finally:
+        M.PROP_CFG.clear(); M.PROP_CFG.update(saved[0])
+        M.NERF_CFG.clear(); M.NERF_CFG.update(saved[1])
