@@ -195,20 +195,30 @@ def run_mode(args, precision, rank, world, device, batches):
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
+    if world > 1:
+        tr.wait_taps = []                        # exposed (un-hidden) part of the side-stream update incl. the all-reduce
     t0 = time.perf_counter()
     last = None
     for i in range(K):
         last = tr.train_step(batches[W + i], events=events.get(i))
     tr.flush()                                   # the last step's level-1 all-reduce + Adam belong to the timed region
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0               # this rank's own clock, before waiting for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank, exposed = None, None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # diagnosis of a scaling run: every rank's own ms per step and the update time its main stream had to wait for
+        mine = torch.tensor([1e3 * own / K, sum(a.elapsed_time(b) for a, b in tr.wait_taps) / K], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(float(x[0]), 4) for x in allr]
+        exposed = [round(float(x[1]), 4) for x in allr]
     tr.check_cameras()
     loss = [float(s[0]) for s in last]
     assert all(np.isfinite(loss)), 'non-finite loss %r' % (loss,)
@@ -240,6 +250,7 @@ def run_mode(args, precision, rank, world, device, batches):
     tied = [k for k in order if share[k] >= 0.98 * top]
     dominant = tied[0]
     return dict(elapsed=elapsed, ms_per_step=1e3 * elapsed / K, value=n * K * world / elapsed, loss=loss,
+                per_rank_ms_per_step=per_rank, exposed_update_ms_per_step=exposed,
                 value_per_gpu=n * K / elapsed, kernels=kernels, dominant=dominant, co_dominant=tied, share_ms=share,
                 pmc_ok=(n == 1024 and precision == 1 and PMC_TRAFFIC is not None))
 
@@ -434,7 +445,12 @@ def main():
                                'both levels fwd+bwd+Adam' % (args.depth_sup_type, args.depth_loss_type,
                                                              args.lambda_depth, args.n_rand),
                    'n_rand_per_gpu': args.n_rand, 'parallelism': 'dp%d (ray batches, RCCL grad all-reduce)' % world,
-                   'dist_backend': (backend if world > 1 else None)},
+                   'dist_backend': (backend if world > 1 else None),
+                   # N > 1 diagnostics: each rank's own clock over the timed steps (ms per step, before the closing
+                   # barrier) and the time per step its main stream waited for the side-stream parameter update (slab
+                   # sum -> all-reduce -> Adam -> re-pack) that the next level's forward did not hide
+                   'per_rank_ms_per_step': r['per_rank_ms_per_step'],
+                   'exposed_update_ms_per_step': r['exposed_update_ms_per_step']},
         'roofline': roofline(r),
         'final_loss': r['loss'],
         'gates': {

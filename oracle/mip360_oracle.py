@@ -590,10 +590,12 @@ def mlp_backward(params, cache, g_density, g_rgb=None, q=None):
 def model_forward(prop_params, nerf_params, rays, train_frac=1.0, jitter01=None, basis=None, num_prop_samples=64,
                   num_nerf_samples=32, num_levels=3, anneal_slope=10., dilation_multiplier=0.5, dilation_bias=0.0025,
                   raydist_fn='reciprocal', opaque_background=True, single_jitter=True, resample_padding=0.0,
-                  bg_rgb=1.0, caches=None, q=None):
+                  bg_rgb=1.0, caches=None, q=None, sdist_override=None):
     """Model.__call__ (models.py:76-303) for configs/360.gin: 2 proposal levels + 1 NeRF level.
     rays: dict origins, directions, viewdirs [N,3], radii, near, far [N,1].  jitter01: None (deterministic) or a
     list of num_levels arrays [N,1] in [0,1) replacing the per-level jax.random.uniform of stepfun.sample.
+    sdist_override (test infrastructure): per-level sample positions to use instead of the re-sampled ones, so that an
+    implementation whose earlier levels differ by rounding can be compared level by level on identical intervals.
     Returns (renderings, ray_history) like upstream."""
     basis = pos_basis_t() if basis is None else basis
     _, s_to_t = construct_ray_warps(raydist_fn, rays['near'], rays['far'])
@@ -615,6 +617,8 @@ def model_forward(prop_params, nerf_params, rays, train_frac=1.0, jitter01=None,
             logits = np.where(sdist[..., 1:] > sdist[..., :-1], anneal * np.log(weights + resample_padding), -np.inf)
         sdist = sample_intervals(sdist, logits, ns, None if jitter01 is None else jitter01[lvl], single_jitter,
                                  domain=(s_near, s_far))
+        if sdist_override is not None:
+            sdist = np.asarray(sdist_override[lvl], sdist.dtype)
         tdist = s_to_t(sdist)
         means, covs = cast_rays(tdist, rays['origins'], rays['directions'], rays['radii'], 'cone', diag=False)
         cache = None

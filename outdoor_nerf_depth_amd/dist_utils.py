@@ -42,6 +42,8 @@ def gather_ragged(t, sizes, rank, world_size):
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
+    if pad.is_cuda and dist.get_backend() == 'gloo':
+        pad = pad.cpu()          # gloo (the shared-GPU / CPU test backend) gathers host tensors only; RCCL gathers in place
     outs = [torch.empty_like(pad) for _ in range(world_size)]
     dist.all_gather(outs, pad)
     if rank != 0:

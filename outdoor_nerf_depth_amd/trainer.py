@@ -71,6 +71,10 @@ class NerfppTrainer(object):
         # the same level of the next step.  overlap_allreduce=False keeps everything on the caller's stream.
         self.update_stream = torch.cuda.Stream(device=self.device) if overlap_allreduce else None
         self._pending = {}                # level -> event recorded after its update on the side stream
+        # diagnostic (bench.py, N > 1): when a list, every _update_end appends a (before, after) timing-event pair around
+        # the main stream's wait for the side-stream update -- the part of [slab sum, all-reduce, Adam, re-pack] that the
+        # next level's sampling + forward did NOT hide
+        self.wait_taps = None
 
     # -- parameter update ----------------------------------------------------------------------------
     def _update(self, m, step):
@@ -115,7 +119,14 @@ class NerfppTrainer(object):
     def _update_end(self, m):
         done = self._pending.pop(m, None)
         if done is not None:
-            torch.cuda.current_stream().wait_event(done)
+            if self.wait_taps is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                torch.cuda.current_stream().wait_event(done)
+                b.record()
+                self.wait_taps.append((a, b))
+            else:
+                torch.cuda.current_stream().wait_event(done)
 
     def flush(self):
         """Order the caller's stream after the parameter updates still running on the side stream.  Call before
