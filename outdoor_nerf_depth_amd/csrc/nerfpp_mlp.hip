@@ -747,10 +747,13 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
           if (!(blk & 1)) pass_write<16>(stage, lane, frags, 4 * (blk >> 1));
           else pass_store(stage, base, 256, wrow0, lane, 4 * (blk >> 1));
         }
-        if (partner && blk >= 1 && blk <= 4) {
-          handoff_flush_part<16, 4>(region, lane, base, 256, wrow0 - 32, blk - 1);
-          if (blk == 1) mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + REGION_MASK + lane * 16);
-        }
+        // The loader's tile (visible after the barrier of block 1): one 128-byte segment each for waves 1..4, in a block
+        // where their own tile only does LDS writes.  (Wave 1 alone used to write all four segments: 32 wave-stores per
+        // layer on one wave against 16 on the others, and the slowest wave sets the pace at every barrier.)
+        if (wave >= 1 && wave <= 4 && blk == 2)
+          handoff_flush_part<16, 4>(region, lane, base, 256, wrow0 - (size_t)wave * 32, wave - 1);
+        if (partner && blk == 1)
+          mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + REGION_MASK + lane * 16);
       }
     }
   };
@@ -916,7 +919,9 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
           if (!(blk & 1)) pass_write<NCH>(stage, lane, frags, 4 * (blk >> 1));
           else pass_store(stage, base, ld, wrow0, lane, 4 * (blk >> 1));
         }
-        if (partner && blk >= 1 && blk <= PARTS) handoff_flush_part<NCH, PARTS>(region, lane, base, ld, wrow0 - 32, blk - 1);
+        // the loader's tile: one 128-byte segment per helper wave 1..PARTS (see mlp_fwd_kernel::psave_h)
+        if (wave >= 1 && wave <= PARTS && blk == 2)
+          handoff_flush_part<NCH, PARTS>(region, lane, base, ld, wrow0 - (size_t)wave * 32, wave - 1);
       }
     }
   };

@@ -22,7 +22,7 @@ class NerfppTrainer(object):
     def __init__(self, device, precision=L.PREC_SPLIT_BF16, cascade_samples=(64, 128), lrate=5e-4,
                  use_depth=True, depth_loss_type='mse', lambda_depth=0.1, depth_sigma=0.01, depth_scale=1.0,
                  world_size=1, level_params=None, overlap_allreduce=True, optim_autoexpo=False, img_names=None,
-                 lambda_autoexpo=1.0, seed=777, torch_rng=False, fuse_loss=True):
+                 lambda_autoexpo=1.0, seed=777, torch_rng=False, fuse_loss=False):
         """seed: key of the in-kernel sampling RNG (the CLI passes (rank+1)*777 like ddp_train_nerf.py:406-408);
         torch_rng=True draws the four uniform tensors with torch.rand in the reference's call order instead
         (4 extra launches per step)."""
@@ -48,7 +48,11 @@ class NerfppTrainer(object):
         self.grads = [torch.zeros(L.LEVEL_PARAMS + 4, device=self.device) for _ in self.engines]
         self.step_count = 0
         self.seed, self.torch_rng = int(seed), bool(torch_rng)
-        self.fuse_loss = bool(fuse_loss)      # loss-head gradient inside the compositing backward (not with auto-exposure)
+        # loss-head gradient inside the compositing backward (nerfpp_backward_args.fused_loss; not with auto-exposure).
+        # Bit-identical to the two-call path; measured in one process (tools/ab_step.py, profiles/r03_ab_*): 2.717 ms per
+        # step fused vs 2.704 separate -- the loss launch it takes off the critical path (~9 us) is paid back by the recount
+        # in every compositing workgroup and the extra stream events, so the default stays the separate launch.
+        self.fuse_loss = bool(fuse_loss)
         self.rng_step = 0                 # counter of the in-kernel RNG (not reset by checkpoint reloads of step_count)
         # rays whose closest point to the origin lies outside the unit sphere, summed over all steps since
         # the last check_cameras() (the reference raises on the spot, ddp_train_nerf.py:62-63; here the
