@@ -105,7 +105,7 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
 NetWs make_netws(char* ws, const WsLayout& L, int net) {
   NetWs w;
   for (int t = 0; t < T_COUNT; ++t) w.t[t] = (__bf16*)(ws + L.tensor[net][t]);
-  w.t[T_DG] = w.t[T_DS] + DG_COL0;
+  w.t[T_DG] = w.t[T_DS] + (DG_COL0 / 16) * (FRAG_BYTES / 2);      // fragment-major: column 32 = chunk block 2 of every tile
   return w;
 }
 

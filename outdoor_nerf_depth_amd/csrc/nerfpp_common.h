@@ -141,13 +141,20 @@ __host__ __device__ constexpr int feat_m(int f) { return 8 * (f / 16) + 4 * ((f 
 __host__ __device__ constexpr int pe_ref_of_feat(int net, int f) { return pe_ref_of_lane_slot(pe_dim(net), feat_hi(f), feat_m(f)); }
 __host__ __device__ constexpr int dir_ref_of_feat(int f) { return dir_ref_of_lane_slot(feat_hi(f), feat_m(f)); }
 
-// ---- saved tensors (training): row-major [rows_padded][ld] bf16, one plane per precision part ---
+// ---- saved tensors (training): FRAGMENT-MAJOR bf16, one plane per precision part ------------------------------
+// A tensor of `ld` columns (a multiple of 16) over rows_padded rows (a multiple of 256) is stored as
+// [rows_padded / 32 tiles][ld / 16 chunks][1 KiB block]; the block of (tile, chunk c) holds at byte (2 j + hi) * 16 the
+// 8 bf16 that lane (j, hi) of the producing wave holds for row 32 * tile + j: features 16 c + kslot(0, hi, t), t = 0..7,
+// i.e. the 8-byte piece q = 2 (t >> 2) + hi carries features 16 c + 4 q .. 4 q + 3 in natural order.  It is exactly the
+// accumulator-layout register image of the fused MLP kernels (one contiguous 1 KiB wave-store per chunk, no transposition)
+// and the weight-gradient kernel reads its sample-major MFMA fragments from it with ds_read_b64_tr_b16.  A "column offset"
+// of 16 k columns is k blocks (T_DG = T_DS + 2 blocks).  Same bytes as a row-major [rows_padded][ld] tensor.
 enum Tensor {
   T_X = 0, T_H0 = 1, /* .. T_H7 = 8 */ T_R = 9, T_G = 10, T_DIRX = 11,
   T_DZ0 = 12, /* .. T_DZ7 = 19 */ T_DR = 20, T_DS = 21, T_DG = 22, T_DP = 23, T_COUNT = 24
 };
-// dS (32 columns) and dG (128 columns) share one row-major tensor [rows][160]: T_DS points at column 0,
-// T_DG at column 32 of it, so the weight-gradient job that contracts both with H7 reads H7 once.
+// dS (32 columns) and dG (128 columns) share one tensor of 160 columns: T_DS points at column 0 (chunks 0, 1),
+// T_DG at column 32 (chunk 2) of it, so the weight-gradient job that contracts both with H7 reads H7 once.
 constexpr int DSG_LD = 160, DG_COL0 = 32;
 __host__ __device__ constexpr int tensor_ld(int net, int t) {
   return t == T_X ? kpew(net) : (t >= T_H0 && t <= T_R) ? 256 : t == T_G ? 128 : t == T_DIRX ? 32

@@ -7,18 +7,20 @@
 // parameter layout.  Every operand tensor is read exactly once per job.
 //
 // Data path (dw_kernel):
-//   * operands stay row-major [rows][ld] bf16 in HBM (as the fused MLP kernels wrote them) and are
-//     DMA'd (global_load_lds_dwordx4) into LDS as [32 rows][512 B] images: a 1 KiB wave-instruction
-//     covers 2 rows; each 1 KiB segment is followed by 64 B of padding so that the 4 rows one
-//     transposed read touches fall into 4 disjoint bank windows.  Tensors narrower than 256 columns
-//     fill only the left part of the image (inactive DMA lanes).
-//   * MFMA wants the sample axis on the k-slots: fragments come from ds_read_b64_tr_b16 -- a
-//     16-lane group reads a [4 samples x 16 features] block and receives it transposed
-//     (lane = feature, 4 samples per lane).  Both operands use the same sample->slot map, so the
-//     contraction is exact whatever that map is.
+//   * operands are the FRAGMENT-MAJOR saved tensors of the fused MLP kernels (nerfpp_mlp.hip): per 32-row tile and
+//     16-column chunk one 1 KiB block holding, at byte (2 j + hi) * 16, the 8 bf16 lane (j, hi) of the producing wave
+//     had for row j.  A 32-row chunk of an operand is ld/16 consecutive blocks: the DMA (global_load_lds_dwordx4) is a
+//     linear copy, one whole 1-KiB-contiguous block per wave-instruction -- also for the tensors that are only 32 or 64
+//     columns wide (row-major, their instructions carried 8-32 live lanes).  In LDS the blocks sit 1152 B apart.
+//   * MFMA wants the sample axis on the k-slots: fragments come from ds_read_b64_tr_b16 -- a 16-lane group reads a
+//     [4 samples x 16 features] patch and receives it transposed (lane = feature, 4 samples per lane).  In a block the
+//     four 8-byte pieces of a sample's 16 features are at (2 j + (q & 1)) * 16 + 8 * (q >> 1), q = feature quad, i.e.
+//     the 16 lanes of a group read 128 contiguous bytes, the group next to it (the same samples of the next chunk)
+//     1152 B = 32 banks further: conflict-free.  Both operands use the same sample->slot map, so the contraction is
+//     exact whatever that map is.
 //   * 8 waves; full 256x256 jobs: wave (wo = w>>2, wi = w&3) owns out-blocks [4wo, 4wo+4) x in-blocks
 //     [2wi, 2wi+2), 8 accumulators of 32x32 (128 VGPRs); narrow jobs deal their blocks round-robin.
-//     32-row chunks through a 4-deep LDS ring (inline-asm DMA, counted vmcnt), one raw barrier per chunk.
+//     32-row chunks through an LDS ring (inline-asm DMA, counted vmcnt), one raw barrier per chunk.
 //   * the number of row slices is per job (dw_plan, nerfpp_common.h): every launch fills the 256 CUs
 //     once with workgroups that move about the same number of bytes.
 //   * bias gradients: VALU column sums of the A fragments, split over the waves that share them.
@@ -52,8 +54,8 @@ constexpr JobTable build_jobs(bool full) {
 __constant__ JobTable c_full = build_jobs(true);
 __constant__ JobTable c_narrow = build_jobs(false);
 
-constexpr int SEG = FRAG_BYTES + 64;
-constexpr int OPER_BYTES = 16 * SEG;          // 32 rows x 512 B + padding
+constexpr int BLKP = FRAG_BYTES + 128;        // LDS stride of the 1 KiB chunk blocks (odd blocks land 32 banks off the even ones)
+constexpr int OPER_BYTES = 16 * BLKP;         // 32 rows x 256 columns
 
 // LDS-DMA through inline asm: hipcc's waitcnt pass must not see it, or it drains vmcnt to 0 before
 // every LDS read of the ring (it cannot prove the transposed reads do not alias the in-flight
@@ -69,36 +71,46 @@ __device__ __forceinline__ void glds16(const void* g, uint32_t lds_abs) {
 // (a flat pointer would drag a flat->LDS null check into divergent code and trips a backend bug).
 extern __shared__ __attribute__((aligned(16))) char dw_smem[];
 typedef uint32_t lds_addr;
-// row2 = byte distance between the two rows of a segment (512 in the full-width image)
-__device__ __forceinline__ bf16x8 tr_frag(lds_addr off, uint32_t row2 = 512) {
+// second read: the next 4 samples of the block (4 x 32 B further)
+__device__ __forceinline__ bf16x8 tr_frag(lds_addr off, uint32_t row2 = 128) {
   __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)dw_smem;
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off));
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + row2));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-// Narrow jobs size their LDS images by the operand width: a segment holds 2 rows of W bytes (W = the
-// job's column bytes rounded up to 64 / 128 / 256 / 512) + 64 B of padding, so that consecutive segments
-// sit 16 banks apart like in the full-width image; 16 segments per 32-row chunk.  Smaller chunks leave
-// room for a deeper ring in the same LDS (the narrow jobs are bound by bytes in flight).
+// Narrow jobs: an operand image is its n/16 chunk blocks per plane; smaller chunks leave room for a deeper ring.
 struct NarrowGeom {
-  uint32_t w[2];        // image row bytes of A, B
-  uint32_t segw[2];     // 2 * w + 64
-  uint32_t img[2];      // 16 * segw
+  uint32_t nblk[2];     // 1 KiB blocks (= DMA wave-instructions) per plane of A, B
+  uint32_t img[2];      // nblk * BLKP
   uint32_t chunk;       // P * (img[0] + img[1])
   int nbuf;             // ring depth: min(8, LDS bytes / chunk)
 };
-__device__ __forceinline__ uint32_t pow2_width(int bytes) { return bytes <= 64 ? 64u : bytes <= 128 ? 128u : bytes <= 256 ? 256u : 512u; }
 template <int P>
 __device__ __forceinline__ NarrowGeom narrow_geom(const DwJob& job, uint32_t lds_bytes) {
   NarrowGeom g;
-  g.w[0] = pow2_width(job.n_o * 2);
-  g.w[1] = pow2_width(job.n_i * 2);
-#pragma unroll
-  for (int o = 0; o < 2; ++o) { g.segw[o] = 2 * g.w[o] + 64; g.img[o] = 16 * g.segw[o]; }
+  g.nblk[0] = (uint32_t)job.n_o / 16;
+  g.nblk[1] = (uint32_t)job.n_i / 16;
+  g.img[0] = g.nblk[0] * BLKP;
+  g.img[1] = g.nblk[1] * BLKP;
   g.chunk = P * (g.img[0] + g.img[1]);
   const int n = (int)(lds_bytes / g.chunk);
   g.nbuf = n > 8 ? 8 : n;
   return g;
+}
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the count must be an immediate
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {
+#define NERFPP_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    NERFPP_W(0) NERFPP_W(1) NERFPP_W(2) NERFPP_W(3) NERFPP_W(4) NERFPP_W(5) NERFPP_W(6) NERFPP_W(7) NERFPP_W(8) NERFPP_W(9)
+    NERFPP_W(10) NERFPP_W(11) NERFPP_W(12) NERFPP_W(13) NERFPP_W(14) NERFPP_W(15) NERFPP_W(16) NERFPP_W(17) NERFPP_W(18) NERFPP_W(19)
+    NERFPP_W(20) NERFPP_W(21) NERFPP_W(22) NERFPP_W(23) NERFPP_W(24) NERFPP_W(25) NERFPP_W(26) NERFPP_W(27) NERFPP_W(28) NERFPP_W(29)
+    NERFPP_W(30) NERFPP_W(31) NERFPP_W(32) NERFPP_W(33) NERFPP_W(34) NERFPP_W(35) NERFPP_W(36) NERFPP_W(37) NERFPP_W(38) NERFPP_W(39)
+    NERFPP_W(40) NERFPP_W(41) NERFPP_W(42) NERFPP_W(43) NERFPP_W(44) NERFPP_W(45) NERFPP_W(46) NERFPP_W(47) NERFPP_W(48) NERFPP_W(49)
+    NERFPP_W(50) NERFPP_W(51) NERFPP_W(52) NERFPP_W(53) NERFPP_W(54) NERFPP_W(55) NERFPP_W(56) NERFPP_W(57) NERFPP_W(58) NERFPP_W(59)
+    NERFPP_W(60)
+#undef NERFPP_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // deeper than the counter: wait for everything (safe)
+  }
 }
 __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
   const uint4 w = *(const uint4*)&v;
@@ -120,10 +132,10 @@ __device__ __forceinline__ void compute_chunk(lds_addr buf, int wo, int wi, int 
     for (int p = 0; p < P; ++p) {
 #pragma unroll
       for (int x = 0; x < 4; ++x)
-        if (FULL || x < nbo) fa[x][p] = tr_frag(buf + p * OPER_BYTES + kk * 8 * SEG + (4 * wo + x) * 64);
+        if (FULL || x < nbo) fa[x][p] = tr_frag(buf + p * OPER_BYTES + kk * 512 + 2 * (4 * wo + x) * BLKP);
 #pragma unroll
       for (int x = 0; x < 2; ++x)
-        if (FULL || x < nbi) fb[x][p] = tr_frag(buf + (P + p) * OPER_BYTES + kk * 8 * SEG + (2 * wi + x) * 64);
+        if (FULL || x < nbi) fb[x][p] = tr_frag(buf + (P + p) * OPER_BYTES + kk * 512 + 2 * (2 * wi + x) * BLKP);
     }
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo) {
@@ -160,8 +172,8 @@ __device__ __forceinline__ void compute_chunk_rr(lds_addr buf_a, lds_addr buf_b,
       bf16x8 fa[P], fb[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        fa[p] = tr_frag(buf_a + p * gm.img[0] + kk * 8 * gm.segw[0] + bo * 64, gm.w[0]);
-        fb[p] = tr_frag(buf_b + p * gm.img[1] + kk * 8 * gm.segw[1] + bi * 64, gm.w[1]);
+        fa[p] = tr_frag(buf_a + p * gm.img[0] + kk * 512 + 2 * bo * BLKP);
+        fb[p] = tr_frag(buf_b + p * gm.img[1] + kk * 512 + 2 * bi * BLKP);
       }
       acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[k], 0, 0, 0);
       if constexpr (P == 2) {
@@ -224,36 +236,36 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
   float bsum_rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int n_ib = job.n_i / 32, nblk = (job.n_o / 32) * n_ib;
 
-  // DMA: 2 operands x P planes x 16 segments per chunk, 4P wave-instructions per wave
-  constexpr int DMA_PER_CHUNK = 4 * P;           // wave-instructions per wave per chunk
+  // DMA: 2 operands x P planes x (columns / 16) one-KiB blocks per 32-row chunk; full jobs: 4P wave-instructions per wave
+  constexpr int DMA_PER_CHUNK = 4 * P;           // wave-instructions per wave per chunk (full jobs)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
-  // per-lane position inside an operand image for the transposed reads (see header comment):
-  // 16-lane group g: lane-half hi = g>>1, feature sub-block g&1; lane a16: sample a16>>2, piece a16&3
+  // per-lane position inside an operand image for the transposed reads (see header comment): 16-lane group g reads
+  // chunk (g & 1) of a 32-column block for k-half (g >> 1) (8 samples each); lane a16: sample a16 >> 2 of the 4 a read
+  // covers, feature quad q = a16 & 3
   const int g = lane >> 4, a16 = lane & 15;
-  const int lane_seg = 4 * (g >> 1) + (a16 >> 2), lane_col = (16 * (g & 1) + 4 * (a16 & 3)) * 2;
+  const int lane_off = (g & 1) * BLKP + ((((g >> 1) * 8 + (a16 >> 2)) * 2 + (a16 & 1)) * 16) + ((a16 >> 1) & 1) * 8;
+  // blocks per 32-row tile of each operand TENSOR (the job may use a leading part of it) and the tile of row r: r / 32
+  const size_t tb_a = (size_t)(rb_a >> 5), tb_b = (size_t)(rb_b >> 5);
 
   // Ring pipeline: chunks c+1 .. c+NBUF-2 stay in flight while chunk c is consumed.  All VMEM ops of
   // this kernel's main loop are LDS-DMA loads (same type, in-order), so a COUNTED vmcnt is exact:
   // "at most k*DMA_PER_CHUNK outstanding" == "chunk c has landed" when k younger chunks were issued.
   // Raw s_barrier (a __syncthreads() would drain vmcnt to 0 and kill the overlap).
   if constexpr (FULL) {
-    const int dma_col = (lane & 31) * 16, dma_row = lane >> 5;
-    constexpr int NBUF = P == 1 ? 4 : 2;         // LDS ring depth (P=1: 4 x 34 KiB, P=2: 2 x 68 KiB)
+    constexpr int NBUF = P == 1 ? 4 : 2;         // LDS ring depth (P=1: 4 x 36 KiB, P=2: 2 x 72 KiB)
     auto issue = [&](int c) {
       if (c >= nchunk || dbg == 2) return;
-      const int64_t r0 = r_begin + (int64_t)c * 32;
+      const size_t tile = (size_t)((r_begin >> 5) + c);
       const uint32_t buf = lds_base + (c % NBUF) * (2 * P * OPER_BYTES);
 #pragma unroll
       for (int x = 0; x < 4 * P; ++x) {
         const int id = x * 8 + wave;               // 0 .. 32P-1
-        const int op = id / (16 * P), rem = id - op * 16 * P, pl = rem >> 4, seg = rem & 15;
-        const int rb = op == 0 ? rb_a : rb_b;
-        const char* src = (op == 0 ? ga + pl * plane_a : gb + pl * plane_b) +
-                          (size_t)(r0 + 2 * seg + dma_row) * rb + dma_col;
-        glds16(src, buf + (op * P + pl) * OPER_BYTES + seg * SEG);
+        const int op = id / (16 * P), rem = id - op * 16 * P, pl = rem >> 4, blk = rem & 15;
+        const char* src = (op == 0 ? ga + pl * plane_a + (tile * tb_a + blk) * FRAG_BYTES
+                                   : gb + pl * plane_b + (tile * tb_b + blk) * FRAG_BYTES) + lane * 16;
+        glds16(src, buf + (op * P + pl) * OPER_BYTES + blk * BLKP);
       }
     };
-    const int lane_off = lane_seg * SEG + lane_col;
 #pragma unroll
     for (int c = 0; c < NBUF - 1; ++c) issue(c);
     for (int c = 0; c < nchunk; ++c) {
@@ -270,52 +282,40 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
   } else {
     const NarrowGeom gm = narrow_geom<P>(job, lds_bytes);
     const int NB = gm.nbuf;
-    // DMA lane map: the first w/16 lanes carry row 0 of the segment, the next w/16 row 1, the rest idle
-    int d_row[2], d_col[2];
-    bool d_on[2];
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int half = gm.w[o] / 16;
-      d_row[o] = lane / half;
-      d_col[o] = (lane - d_row[o] * half) * 16;
-      d_on[o] = d_row[o] < 2 && d_col[o] < (o == 0 ? job.n_o : job.n_i) * 2;
-    }
+    // the chunk's blocks in the order [A plane 0 .. P-1 | B plane 0 .. P-1] are dealt round-robin to the 8 waves: wave w
+    // issues ids w, w + 8, ... (c_w of them; every instruction is one whole block, all 64 lanes live) and waits for ITS OWN
+    // instructions before the barrier
+    const int n_a = (int)gm.nblk[0], n_b = (int)gm.nblk[1], n_total = P * (n_a + n_b);
+    const int c_w = (n_total - wave + 7) >> 3;
+    constexpr int CMAX = (P * 32 + 7) / 8;
     int slot_i = 0, next_i = 0;
     auto issue = [&]() {                           // next chunk of the slice -> next ring slot
       const int c = next_i, slot = slot_i;
       ++next_i;
       slot_i = slot_i + 1 == NB ? 0 : slot_i + 1;
       if (c >= nchunk || dbg == 2) return;
-      const int64_t r0 = r_begin + (int64_t)c * 32;
+      const size_t tile = (size_t)((r_begin >> 5) + c);
       const uint32_t buf = lds_base + slot * gm.chunk;
+      const char* ca = ga + tile * tb_a * FRAG_BYTES + lane * 16;
+      const char* cb = gb + tile * tb_b * FRAG_BYTES + lane * 16;
 #pragma unroll
-      for (int x = 0; x < 4 * P; ++x) {
-        // id = x * 8 + wave (0 .. 32P-1): operand and plane depend on x only (wave < 8), so they are
-        // compile-time after unrolling -- the geometry arrays must not be indexed dynamically (scratch
-        // loads would sit in vmcnt between the DMA ops)
-        const int op = (x * 8) / (16 * P), rem0 = x * 8 - op * 16 * P, pl = rem0 >> 4, seg = (rem0 & 15) + wave;
-        if (d_on[op]) {
-          const int rb = op == 0 ? rb_a : rb_b;
-          const char* src = (op == 0 ? ga + pl * plane_a : gb + pl * plane_b) +
-                            (size_t)(r0 + 2 * seg + d_row[op]) * rb + d_col[op];
-          glds16(src, buf + (op == 0 ? 0u : P * gm.img[0]) + pl * gm.img[op] + seg * gm.segw[op]);
+      for (int k = 0; k < CMAX; ++k) {
+        const int id = wave + 8 * k;
+        if (id < n_total) {                          // wave-uniform
+          const bool is_b = id >= P * n_a;
+          const int idl = is_b ? id - P * n_a : id, n_op = is_b ? n_b : n_a;
+          const int pl = idl >= n_op ? 1 : 0, blk = idl - pl * n_op;   // P <= 2
+          const char* src = (is_b ? cb + pl * plane_b : ca + pl * plane_a) + (size_t)blk * FRAG_BYTES;
+          glds16(src, buf + (is_b ? P * gm.img[0] : 0u) + (uint32_t)pl * (is_b ? gm.img[1] : gm.img[0]) + (uint32_t)blk * BLKP);
         }
       }
     };
-    const lds_addr off_a = lane_seg * gm.segw[0] + lane_col, off_b = P * gm.img[0] + lane_seg * gm.segw[1] + lane_col;
+    const lds_addr off_a = lane_off, off_b = P * gm.img[0] + lane_off;
     for (int c = 0; c < NB - 1; ++c) issue();
     int slot_c = 0;
     for (int c = 0; c < nchunk; ++c) {
       const int younger = nchunk - 1 - c < NB - 2 ? nchunk - 1 - c : NB - 2;
-      switch (younger) {                           // wave-uniform; the count must be an immediate
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * DMA_PER_CHUNK) : "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DMA_PER_CHUNK) : "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_PER_CHUNK) : "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * DMA_PER_CHUNK) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * DMA_PER_CHUNK) : "memory"); break;
-      }
+      wait_vmcnt_dyn(dbg == 2 ? 0 : younger * c_w);   // this wave's share of chunk c has landed
       __builtin_amdgcn_s_barrier();
       issue();
       const lds_addr buf = slot_c * gm.chunk;
@@ -399,7 +399,7 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   const DwSched sf = make_sched(a.plan, true), sn = make_sched(a.plan, false);
   dim3 gfull(sf.wg_end[sf.njobs - 1]), gnarrow(sn.wg_end[sn.njobs - 1]);
   dim3 block(512);
-  const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;
+  const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;     // 144 KiB
   static const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
   if (P == 1) {
     hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);

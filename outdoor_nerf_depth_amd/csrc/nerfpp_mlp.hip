@@ -356,156 +356,54 @@ __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
   __builtin_nontemporal_store(vv, (u32x4*)gptr);
 }
 
-// fragments -> row-major [rows][ld] bf16 tensor (hi plane, then lo plane at +plane elements).
-// The accumulator layout gives every lane 8-byte pieces of 32 DIFFERENT rows, so the tile is first
-// transposed through LDS and then written with 16 B per lane (128-byte row segments), non-temporal.
-// (Rows past the end of the batch (tile tail, < rows_padded) must be written as zeros so the
-// weight-gradient GEMMs can run over whole 32-row chunks without masking: the kernels zero those
-// lanes' fragments -- zero_invalid, last tile only -- before they get here.)
-//
-// Bank-conflict-free transposition image (bf16 kernels; PMC SQ_LDS_BANK_CONFLICT ~ 0):
-//   * a row of the image holds one sample's 128-byte segment (per-wave staging) or its whole 512 bytes
-//     (loader hand-off region), with a row stride of 2 (mod 32) dwords: 34 dwords = 136 B / 130 dwords
-//     = 520 B.  ds_write_b64 is served in groups of 16 consecutive lanes = 16 consecutive rows over 32
-//     banks: bank = 2*row + const, all distinct.
-//   * rows are only 8-byte aligned then, so the read side uses 8-byte reads, and the lanes of a 32-lane
-//     read group take rows {a, a+1, a+16, a+17} (8 sixteen-byte pieces each): their row offsets are
-//     {0, 2, 32, 34} (mod 64) dwords and the pieces step by 4, which tiles the 64 banks exactly.
-template <int PC> constexpr int stage_row() { return PC == 4 ? 136 : PC * 32 + 16; }
-template <int PC> constexpr int stage_bytes() { return 32 * stage_row<PC>(); }
-constexpr int REGION_ROW = 520;
-constexpr int REGION_MASK = 32 * REGION_ROW;                 // 64 x 16 B of ReLU sign words after the tile
-constexpr int REGION_BYTES = 18432;
-static_assert(REGION_MASK + 1024 <= REGION_BYTES, "hand-off region");
+// Saved tensors are FRAGMENT-MAJOR (nerfpp_common.h, "saved tensors"): the 16 bytes lane (j, hi) holds of chunk c of a
+// wave's 32-row tile go to byte ((tile32 * (ld / 16) + c) * 1024 + (2 j + hi) * 16) of the tensor (hi plane, then the
+// lo plane at +plane elements).  A chunk of a tile is therefore ONE 1-KiB-contiguous wave-store straight from the
+// accumulator-layout registers: no transposition through LDS, no lgkmcnt wait in the save path, and the weight-gradient
+// kernel DMAs whole 1 KiB blocks (nerfpp_dw.hip gathers its sample-major MFMA fragments from them with
+// ds_read_b64_tr_b16 and per-lane addresses).  (Until round 3 the tensors were row-major and every tile went through a
+// per-wave LDS transposition image: 36 KiB of LDS, 8 ds_write_b64 + 8 ds_read_b64 + a wait per 4 chunks, and wave-stores
+// made of eight 128-byte row segments.)
+// Rows past the end of the batch (tile tail, < rows_padded) must be written as zeros so the weight-gradient GEMMs can
+// run over whole 32-row chunks without masking: the kernels zero those lanes' fragments -- zero_invalid, last tile only
+// -- before they get here.
+constexpr int REGION_MASK = 16 * FRAG_BYTES;                 // hand-off region: 16 chunk blocks, then 64 x 16 B of sign words
+constexpr int REGION_BYTES = REGION_MASK + 1024;
 
-// read-side lane map: lane -> (row within a 4-row step, 16-byte piece of the 128-byte segment)
-__device__ __forceinline__ int xp_row(int lane) { return (lane >> 5) * 2 + ((lane >> 3) & 1) + 16 * ((lane >> 4) & 1); }
-__device__ __forceinline__ int xp_piece(int lane) { return lane & 7; }
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// image [32 rows][ROWB] -> global rows: segment `seg` (128 B) of all 32 rows, 4 wave-stores; only the
-// first seg_bytes of the segment exist (narrow tensors).  The reads are 8 x ds_read_b64 issued through
-// inline asm (2 LDS cycles each over 64 banks; left to itself the compiler fuses each pair into a
-// ds_read2_b64: 8 cycles over 32 banks) followed by one lgkmcnt(0) that carries the values as operands.
-template <int ROWB>
-__device__ __forceinline__ void xp_store_segment(const char* img, char* g_seg, int ld, int lane, int seg, int seg_bytes) {
-  const int row = xp_row(lane), piece = xp_piece(lane);
-  if (piece * 16 >= seg_bytes) return;
-  const uint32_t sl = (uint32_t)(uintptr_t)(img + row * ROWB + seg * 128 + piece * 16);   // low 32 bits = LDS address
-  char* gl = g_seg + (size_t)row * ld * 2 + piece * 16;
-  u32x2 lo[4], hi[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo[it]) : "v"(sl), "n"(it * 4 * ROWB) : "memory");
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi[it]) : "v"(sl), "n"(it * 4 * ROWB + 8) : "memory");
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]));
-#pragma unroll
-  for (int it = 0; it < 4; ++it)
-    store_nt16(gl + (size_t)it * 4 * ld * 2, make_uint4(lo[it][0], lo[it][1], hi[it][0], hi[it][1]));
+__device__ __forceinline__ char* frag_addr(__bf16* base, int ld, size_t wave_row0, int c, int lane) {
+  const size_t blk = (wave_row0 >> 5) * (size_t)(ld >> 4) + (size_t)c;
+  return (char*)base + blk * FRAG_BYTES + ((((lane & 31) << 1) | (lane >> 5)) << 4);
 }
-// write side: lane (j, hi) puts its 8-byte pieces of chunks [c0, c0+n) into row j of the image
-template <int ROWB, int NCH, int P>
-__device__ __forceinline__ void xp_write(char* img, int lane, const Frag<P> (&h)[NCH], int p, int c0, int n, int col0) {
-  char* w = img + (lane & 31) * ROWB + 8 * (lane >> 5) + col0;
+template <int P>
+__device__ __forceinline__ void store_chunk(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, int c, const Frag<P>& f) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c < n) {
-      const uint4 bits = *(const uint4*)&h[c0 + c].v[p];
-      *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
-      *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
-    }
-  }
+  for (int p = 0; p < P; ++p) store_nt16(frag_addr(base + p * plane, ld, wave_row0, c, lane), *(const uint4*)&f.v[p]);
 }
-
-template <int NCH, int P, int PC>
-__device__ __forceinline__ void save_frags(char* stage, __bf16* base, size_t plane, int ld, size_t wave_row0,
-                                           int lane, const Frag<P> (&h)[NCH]) {
-  constexpr int SR = stage_row<PC>();
+template <int NCH, int P>
+__device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, const Frag<P> (&h)[NCH]) {
   if constexpr ((NERFPP_DBG & 2) != 0) return;
-  if constexpr (PC == 4) {
+  // Scheduling fences on both sides: the LDS-staged save this replaces was a fence by construction (wave barriers);
+  // without one the scheduler starts the next stage's accumulator set while this stage's is still being converted and
+  // stored (the split-bf16 backward went from 371 to 512 registers + spills).
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-#pragma unroll
-      for (int c0 = 0; c0 < NCH; c0 += 4) {
-        const int nc = NCH - c0 < 4 ? NCH - c0 : 4;
-        xp_write<SR, NCH, P>(stage, lane, h, p, c0, nc, 0);
-        lds_wave_sync();
-        xp_store_segment<SR>(stage, (char*)(base + p * plane + wave_row0 * ld + c0 * 16), ld, lane, 0, nc * 32);
-        lds_wave_sync();
-      }
-    }
-  } else {
-    const int j = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-#pragma unroll
-      for (int c0 = 0; c0 < NCH; c0 += PC) {
-        const int nc = NCH - c0 < PC ? NCH - c0 : PC;           // chunks in this pass (compile-time after unroll)
-        char* w = stage + j * SR + 8 * hi;
-#pragma unroll
-        for (int c = 0; c < PC; ++c) {
-          if (c < nc) {
-            const uint4 bits = *(const uint4*)&h[c0 + c].v[p];
-            *(uint2*)(w + 32 * c) = make_uint2(bits.x, bits.y);
-            *(uint2*)(w + 32 * c + 16) = make_uint2(bits.z, bits.w);
-          }
-        }
-        lds_wave_sync();
-        const int lpr = 2 * nc;                               // 16-byte pieces per row
-        char* g = (char*)(base + p * plane + wave_row0 * ld + c0 * 16);
-#pragma unroll
-        for (int it = 0; it < PC; ++it) {
-          const int idx = it * 64 + lane;
-          if (it < nc) {
-            const int row = idx / lpr, piece = idx - row * lpr;
-            store_nt16(g + (size_t)row * ld * 2 + piece * 16, *(const uint4*)(stage + row * SR + piece * 16));
-          }
-        }
-        lds_wave_sync();
-      }
-    }
-  }
+  for (int c = 0; c < NCH; ++c) store_chunk<P>(base, plane, ld, wave_row0, lane, c, h[c]);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-// The same save, cut in two halves per 4-chunk pass so a stage can spread it over its blocks (P = 1):
-// pass_write in block 2p, pass_store in block 2p+1 -- no LDS round trip is waited for in place.
-template <int NCH>
-__device__ __forceinline__ void pass_write(char* stage, int lane, const Frag<1> (&h)[NCH], int c0) {
-  if constexpr ((NERFPP_DBG & 2) != 0) return;
-  xp_write<stage_row<4>(), NCH, 1>(stage, lane, h, 0, c0, 4, 0);
-}
-__device__ __forceinline__ void pass_store(const char* stage, __bf16* base, int ld, size_t wave_row0, int lane, int c0) {
-  if constexpr ((NERFPP_DBG & 2) != 0) return;
-  lds_wave_sync();
-  xp_store_segment<stage_row<4>()>(stage, (char*)(base + wave_row0 * ld + c0 * 16), ld, lane, 0, 128);
-}
-
-// ---- PIPE_ROLES hand-off: the loader's tile goes to an LDS region, wave 1 writes it out later --------
+// ---- PIPE_ROLES hand-off: the loader never stores; its tile goes to an LDS region (lane-linear chunk blocks,
+// conflict-free 16-byte accesses) and helper waves write it out after the next barrier --------------------------------
 template <int NCH>
 __device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<1> (&h)[NCH]) {
   if constexpr ((NERFPP_DBG & (2 | 16)) != 0) return;
 #pragma unroll
-  for (int c0 = 0; c0 < NCH; c0 += 4) xp_write<REGION_ROW, NCH, 1>(region, lane, h, 0, c0, NCH - c0 < 4 ? NCH - c0 : 4, c0 * 32);
+  for (int c = 0; c < NCH; ++c) *(uint4*)(region + (c * 64 + lane) * 16) = *(const uint4*)&h[c].v[0];
 }
-// wave 1, after the barrier that follows the loader's handoff_write: region -> HBM (mask_dst: this lane's
-// slot of the loader's sign-word block, or nullptr)
-template <int NCH>
-__device__ __forceinline__ void handoff_flush(const char* region, int lane, __bf16* base, int ld, size_t row0,
-                                              uint4* mask_dst) {
+// chunks [c0, c0 + n) of the loader's tile (tile rows row0 .. row0 + 31): region -> HBM
+__device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, int ld, size_t row0, int c0, int n) {
   if constexpr ((NERFPP_DBG & 16) != 0) return;
-  char* g = (char*)(base + row0 * ld);
-#pragma unroll
-  for (int seg = 0; seg < (NCH + 3) / 4; ++seg)
-    xp_store_segment<REGION_ROW>(region, g + seg * 128, ld, lane, seg, NCH * 32 - seg * 128);
-  if (mask_dst) *mask_dst = *(const uint4*)(region + REGION_MASK + lane * 16);
-}
-// one 128-byte segment (= 4 chunks) of the same flush: part in [0, NCH/4)
-template <int NCH, int PARTS>
-__device__ __forceinline__ void handoff_flush_part(const char* region, int lane, __bf16* base, int ld, size_t row0, int part) {
-  static_assert(NCH % 4 == 0 && PARTS == NCH / 4, "one part per 128-byte segment");
-  if constexpr ((NERFPP_DBG & 16) != 0) return;
-  xp_store_segment<REGION_ROW>(region, (char*)(base + row0 * ld) + part * 128, ld, lane, part, 128);
+#pragma unroll 4
+  for (int c = c0; c < c0 + n; ++c) store_nt16(frag_addr(base, ld, row0, c, lane), *(const uint4*)(region + (c * 64 + lane) * 16));
 }
 
 // dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
@@ -647,13 +545,11 @@ struct FwdLds {
   static constexpr int MODE = !TRAIN ? PIPE_RING : (P == 1 ? PIPE_ROLES : PIPE_CLASSIC);
   static constexpr bool ROLES = MODE == PIPE_ROLES;
   static constexpr bool BIAS_LDS = MODE != PIPE_CLASSIC;
-  static constexpr int PC = ROLES ? 4 : 8;                                   // staging pass width (chunks)
-  // ring depth: as deep as the 160 KiB of LDS allow (the background net's wider encoding costs a slot)
-  static constexpr int NBUF = MODE == PIPE_CLASSIC ? 2 : MODE == PIPE_RING ? (P == 1 ? 4 : 3) : (NET == 0 ? 4 : 3);
+  // ring depth: as deep as the 160 KiB of LDS allow
+  static constexpr int NBUF = MODE == PIPE_CLASSIC ? 2 : MODE == PIPE_RING ? (P == 1 ? 4 : 3) : 4;
   static constexpr int W = NBUF * BLK_FRAGS * P * FRAG_BYTES;
   static constexpr int REGION = W;
-  static constexpr int STAGE = REGION + (ROLES ? REGION_BYTES : 0);
-  static constexpr int STASH = STAGE + (TRAIN ? NW * stage_bytes<PC>() : 0);
+  static constexpr int STASH = REGION + (ROLES ? REGION_BYTES : 0);
   static constexpr int BIAS = STASH + NW * kpe(NET) * P * 1024;
   static constexpr int TOTAL = BIAS + (BIAS_LDS ? FWD_BIAS_FLOATS * 4 : 0);
 };
@@ -661,12 +557,10 @@ template <int P, int NW>
 struct BwdLds {
   static constexpr int MODE = P == 1 ? PIPE_ROLES : PIPE_CLASSIC;
   static constexpr bool ROLES = MODE == PIPE_ROLES;
-  static constexpr int PC = ROLES ? 4 : 8;
   static constexpr int NBUF = ROLES ? 4 : 2;
   static constexpr int W = NBUF * BLK_FRAGS * P * FRAG_BYTES;
   static constexpr int REGION = W;
-  static constexpr int STAGE = REGION + (ROLES ? REGION_BYTES : 0);
-  static constexpr int MASKS = STAGE + NW * stage_bytes<PC>();              // 2 x NW KiB of sign words (ROLES)
+  static constexpr int MASKS = REGION + (ROLES ? REGION_BYTES : 0);          // 2 x NW KiB of sign words (ROLES)
   static constexpr int TOTAL = MASKS + (ROLES ? 2 * NW * 1024 : 0);
 };
 
@@ -676,7 +570,7 @@ struct BwdLds {
 template <int NET, int P, int NW, bool TRAIN>
 __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpFwdArgs a) {
   using LD = FwdLds<NET, P, NW, TRAIN>;
-  constexpr int KPE = kpe(NET), PC = LD::PC;
+  constexpr int KPE = kpe(NET);
   constexpr bool ROLES = LD::ROLES;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
@@ -692,7 +586,6 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 #endif
   const bool tail = wrow0 + 32 > (size_t)a.rows;                            // wave-uniform
   char* region = smem + LD::REGION;
-  char* stage = loader ? region : smem + LD::STAGE + wave * stage_bytes<PC>();   // the loader never stages
   char* pe_stash = smem + LD::STASH + wave * (KPE * P * 1024);
   const size_t nblk32 = a.rows_padded / 32;
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
@@ -714,19 +607,27 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   auto bias_init1 = [&](f32x16 (&acc_)[1], int off) {
     if constexpr (!LD::BIAS_LDS) init_bias<1>(acc_, a.bias + off, hi); else init_bias_lds<1>(acc_, LD::BIAS + off * 4, hi);
   };
-  // after the first barrier of a stage: wave 1 writes out what the loader handed over at the end of
-  // the previous stage (statically known per stage; mask_stage < 0: no sign words)
+  const size_t tile_row0 = wrow0 - (size_t)wave * 32;                       // = the loader's rows
+  // after the first barrier of a stage: helper waves 1..4 write out what the loader handed over at the end of the
+  // previous stage (chunk c by wave 1 + c % 4; statically known per stage; mask_stage < 0: no sign words)
   auto flush = [&](int blk, auto nch_c, __bf16* base, int ld, int mask_stage) __attribute__((always_inline)) {
     if constexpr (ROLES) {
-      if (partner && blk == 0)
-        handoff_flush<decltype(nch_c)::value>(region, lane, base, ld, wrow0 - 32,
-                                              mask_stage >= 0 ? mask_out - 64 + (size_t)mask_stage * nblk32 * 64 : nullptr);
+      constexpr int NCH = decltype(nch_c)::value;
+      if (blk == 0 && wave >= 1 && wave <= 4) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if ((c & 3) == wave - 1) handoff_flush_chunks(region, lane, base, ld, tile_row0, c, 1);
+        if (partner && mask_stage >= 0)
+          mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + REGION_MASK + lane * 16);
+      }
     }
   };
-  // [rows,256] trunk activations.  finish_h: what stays in the producing stage's epilogue (sign words,
-  // tail zeroing; the whole save when the pipe has no roles).  psave_h: runs in every block of the
-  // CONSUMING stage (the tile is its B operand): storers transpose + write one quarter per block pair,
-  // the loader hands its tile over in block 0 and wave 1 writes that out in blocks 1..4.
+  // [rows,256] trunk activations.  finish_h: what stays in the producing stage's epilogue (sign words, tail zeroing; the
+  // whole save when the pipe has no roles).  psave_h: runs in every block of the CONSUMING stage (the tile is its B
+  // operand, still in registers): a storer writes two chunks per block straight from them (16 wave-stores of 1 KiB over
+  // the stage's first 8 blocks); the loader hands its tile over in block 0 and waves 1..4 write a quarter of it each in
+  // block 2 (wave 1 alone used to: 32 wave-stores per layer on one wave against 16 on the others, and the slowest wave
+  // sets the pace at every barrier).
   auto finish_h = [&](__bf16* base, Frag<P> (&frags)[16], uint4 bits, int mask_stage) __attribute__((always_inline)) {
     if constexpr (!TRAIN) return;
     if (tail) zero_invalid(frags, valid);
@@ -735,7 +636,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
       else mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
     } else {
       mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
-      save_frags<16, P, PC>(stage, base, plane_rows * 256, 256, wrow0, lane, frags);
+      save_frags<16, P>(base, plane_rows * 256, 256, wrow0, lane, frags);
     }
   };
   auto psave_h = [&](int blk, const Frag<P> (&frags)[16], __bf16* base, int mask_stage) __attribute__((always_inline)) {
@@ -743,15 +644,13 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
       if (loader) {
         if (blk == 0) handoff_write<16>(region, lane, frags);
       } else {
-        if (blk < 8) {
-          if (!(blk & 1)) pass_write<16>(stage, lane, frags, 4 * (blk >> 1));
-          else pass_store(stage, base, 256, wrow0, lane, 4 * (blk >> 1));
+        if constexpr ((NERFPP_DBG & 2) == 0) {
+          if (blk < 8) {
+            store_chunk<P>(base, 0, 256, wrow0, lane, 2 * blk, frags[2 * blk]);
+            store_chunk<P>(base, 0, 256, wrow0, lane, 2 * blk + 1, frags[2 * blk + 1]);
+          }
         }
-        // The loader's tile (visible after the barrier of block 1): one 128-byte segment each for waves 1..4, in a block
-        // where their own tile only does LDS writes.  (Wave 1 alone used to write all four segments: 32 wave-stores per
-        // layer on one wave against 16 on the others, and the slowest wave sets the pace at every barrier.)
-        if (wave >= 1 && wave <= 4 && blk == 2)
-          handoff_flush_part<16, 4>(region, lane, base, 256, wrow0 - (size_t)wave * 32, wave - 1);
+        if (wave <= 4 && blk == 2) handoff_flush_chunks(region, lane, base, 256, tile_row0, 4 * (wave - 1), 4);
         if (partner && blk == 1)
           mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + REGION_MASK + lane * 16);
       }
@@ -768,11 +667,11 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
         if (has_mask) *(uint4*)(region + REGION_MASK + lane * 16) = bits;
       } else {
         if (has_mask) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
-        save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
+        save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags);
       }
     } else {
       if (has_mask) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
-      save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
+      save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags);
     }
   };
   const uint4 nobits = make_uint4(0, 0, 0, 0);
@@ -875,7 +774,6 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 template <int NET, int P, int NW>
 __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpBwdArgs a) {
   using LD = BwdLds<P, NW>;
-  constexpr int PC = LD::PC;
   constexpr bool ROLES = LD::ROLES;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
@@ -886,7 +784,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;
   const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
   char* region = smem + LD::REGION;
-  char* stage = loader ? region : smem + LD::STAGE + wave * stage_bytes<PC>();
+  const size_t tile_row0 = wrow0 - (size_t)wave * 32;
   const size_t nblk32 = a.rows_padded / 32;
   const uint4* mask_in = a.masks + (wrow0 / 32) * 64 + lane;
   const uint32_t lds0 = lds_base_addr();
@@ -906,28 +804,28 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     if constexpr (ROLES) return *(const uint4*)(smem + LD::MASKS + ((mstage & 1) * NW + wave) * 1024 + lane * 16);
     else return mask_in[(size_t)mstage * nblk32 * 64];
   };
-  // dZ tensors are written out while the NEXT stage consumes them (see stage_gemm): storers transpose +
-  // store one 4-chunk pass per block pair; the loader hands its tile over in block 0 and wave 1 writes it
-  // out in the following blocks.  Without roles (split-bf16) the tile is saved in the epilogue instead.
+  // dZ tensors are written out while the NEXT stage consumes them (see stage_gemm): a storer writes its chunks straight
+  // from the operand registers, spread over the stage's blocks; the loader hands its tile over in block 0 and waves
+  // 1..NCH/4 write four chunks of it each in block 2.  Without roles (split-bf16) the tile is saved in the epilogue.
   auto psave = [&](int blk, auto nch_c, const auto& frags, __bf16* base, int ld) __attribute__((always_inline)) {
-    constexpr int NCH = decltype(nch_c)::value, NPASS = NCH / 4, PARTS = NCH / 4;
+    constexpr int NCH = decltype(nch_c)::value, PARTS = NCH / 4;
     if constexpr (ROLES) {
       if (loader) {
         if (blk == 0) handoff_write<NCH>(region, lane, frags);
       } else {
-        if (blk < 2 * NPASS) {
-          if (!(blk & 1)) pass_write<NCH>(stage, lane, frags, 4 * (blk >> 1));
-          else pass_store(stage, base, ld, wrow0, lane, 4 * (blk >> 1));
+        if constexpr ((NERFPP_DBG & 2) == 0) {
+          if (2 * blk < NCH) {
+            store_chunk<P>(base, 0, ld, wrow0, lane, 2 * blk, frags[2 * blk]);
+            store_chunk<P>(base, 0, ld, wrow0, lane, 2 * blk + 1, frags[2 * blk + 1]);
+          }
         }
-        // the loader's tile: one 128-byte segment per helper wave 1..PARTS (see mlp_fwd_kernel::psave_h)
-        if (wave >= 1 && wave <= PARTS && blk == 2)
-          handoff_flush_part<NCH, PARTS>(region, lane, base, ld, wrow0 - (size_t)wave * 32, wave - 1);
+        if (wave <= PARTS && blk == 2) handoff_flush_chunks(region, lane, base, ld, tile_row0, 4 * (wave - 1), 4);
       }
     }
   };
   auto save = [&](auto nch_c, __bf16* base, int ld, const auto& frags) __attribute__((always_inline)) {
     constexpr int NCH = decltype(nch_c)::value;
-    if constexpr (!ROLES) save_frags<NCH, P, PC>(stage, base, plane_rows * ld, ld, wrow0, lane, frags);
+    if constexpr (!ROLES) save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags);
   };
 
   // sign words 8 and 7 first: they are needed after the first barriers, and the loader's counted waits
@@ -945,10 +843,10 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     Frag<P> t[2];
     t[0] = zero_frag<P>(); t[1] = zero_frag<P>();
     if (hi == 0) { set_slot<P>(t[0], 0, dd.x); set_slot<P>(t[0], 1, dd.y); set_slot<P>(t[0], 2, dd.z); }
-    save_frags<2, P, PC>(stage, a.ws.t[T_DP], plane_rows * 32, 32, r0, lane, t);
+    save_frags<2, P>(a.ws.t[T_DP], plane_rows * 32, 32, r0, lane, t);
     t[0] = zero_frag<P>();
     if (hi == 0) set_slot<P>(t[0], 0, dd.w);
-    save_frags<2, P, PC>(stage, a.ws.t[T_DS], plane_rows * DSG_LD, DSG_LD, r0, lane, t);   // columns 0..31 of [dS | dG]
+    save_frags<2, P>(a.ws.t[T_DS], plane_rows * DSG_LD, DSG_LD, r0, lane, t);   // chunks 0, 1 of [dS | dG]
   };
   {
     const size_t rr = row_raw - 32;                         // the loader's row of this lane (partner only)
@@ -1000,8 +898,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   }
   if constexpr (ROLES) {
     // dZ0 is the last tensor and no barrier follows: every wave (the loader too -- its DMA is done)
-    // writes its own tile; the loader stages through the hand-off region
-    save_frags<16, P, PC>(stage, a.ws.t[T_DZ0], plane_rows * 256, 256, wrow0, lane, dz);
+    // writes its own tile
+    save_frags<16, P>(a.ws.t[T_DZ0], plane_rows * 256, 256, wrow0, lane, dz);
   }
 }
 
