@@ -15,6 +15,9 @@ inverse-CDF sampling, both cascade levels (64 and 64+128 samples per ray, fg + b
 all-reduce (N > 1) and Adam.  Ray batches are resident in HBM before the timed region.  Prints ONE JSON
 line (rank 0).
 
+Every trainer is set up with SETUP_STEPS untimed steps (code objects, workspaces, and the GPU back at its steady clock:
+an MI355X needs ~20 ms of load after any idle, profiles/r03_step_curve.json) before the W warm-up and K timed steps.
+
 value               : single-pass bf16 MFMA operands (the arithmetic north_star names), rays/s over all GPUs
 parity_forward_mode : split-bf16 forward (rendered RGB / depth / loss within 1e-4 of float32) + bf16 backward
 parity_mode         : split-bf16 everywhere (3 MFMA passes): the mode the 1e-4 parity tests run in
@@ -24,6 +27,7 @@ roofline            : SURVEY 8(d): algorithmic dense-layer FLOP (1.797 GFLOP per
                       the launch stream; the HBM view of the weight-gradient GEMM as a sub-object
 cpu_baseline        : oracle/nerfpp_torch_cpu.py (PyTorch-CPU restatement of the path, the way the reference
                       runs on CPU) on the host cores: N_rand 1024, 2 warm-up + 5 timed steps, median
+render              : SURVEY 8 f-2: one 375x1242 frame through render_single_image, whole call and MLP kernels alone
 """
 import argparse
 import json
@@ -47,6 +51,7 @@ SURVEY_ALGO_BYTES_PER_RAY = 18.8e3   # inputs + outputs + amortised
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
 DW_BYTES_PER_ROW = (4960 + 5024) * 2
 FLOP_PER_RAY_RENDER = 0.613e9    # forward only, both levels
+SETUP_STEPS = 12                 # untimed steps run when a trainer is set up, before the W warm-up steps (see run_mode)
 # HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16: PARSED at start-up from the rocprofv3 --pmc passes committed
 # under profiles/ (they cannot be collected inside this process: separate --pmc runs, MI355X_MICROARCH.md "HBM").  The
 # field is named `traffic_from_profile`-style in the output (`traffic_source`), it is not a live measurement.
@@ -187,6 +192,11 @@ def run_mode(args, precision, rank, world, device, batches):
         for e in ev['fwd'] + ev['bwd']:
             e.record()                           # materialise the hipEvent_t handles
         events[i] = [None, ev]
+    # Engine set-up (untimed, reported as config.setup_steps): code objects loaded, workspaces allocated and touched, and
+    # the GPU back at its steady clock -- after any idle an MI355X needs ~20 ms of this load (8 steps) to ramp
+    # (profiles/r03_step_curve.json); the W warm-up steps below then start from the state a training run is in
+    for i in range(SETUP_STEPS):
+        tr.train_step(batches[i % len(batches)])
     for i in range(W):
         tr.train_step(batches[i])
     tr.flush()
@@ -445,6 +455,7 @@ def main():
                                'both levels fwd+bwd+Adam' % (args.depth_sup_type, args.depth_loss_type,
                                                              args.lambda_depth, args.n_rand),
                    'n_rand_per_gpu': args.n_rand, 'parallelism': 'dp%d (ray batches, RCCL grad all-reduce)' % world,
+                   'setup_steps': SETUP_STEPS,
                    'dist_backend': (backend if world > 1 else None),
                    # N > 1 diagnostics: each rank's own clock over the timed steps (ms per step, before the closing
                    # barrier) and the time per step its main stream waited for the side-stream parameter update (slab

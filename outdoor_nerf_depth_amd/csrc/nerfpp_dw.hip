@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "nerfpp_common.h"
 #include "nerfpp_kernels.h"
 
@@ -96,21 +97,6 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const DwJob& job, uint32_t lds
   const int n = (int)(lds_bytes / g.chunk);
   g.nbuf = n > 8 ? 8 : n;
   return g;
-}
-// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the count must be an immediate
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-  switch (n) {
-#define NERFPP_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    NERFPP_W(0) NERFPP_W(1) NERFPP_W(2) NERFPP_W(3) NERFPP_W(4) NERFPP_W(5) NERFPP_W(6) NERFPP_W(7) NERFPP_W(8) NERFPP_W(9)
-    NERFPP_W(10) NERFPP_W(11) NERFPP_W(12) NERFPP_W(13) NERFPP_W(14) NERFPP_W(15) NERFPP_W(16) NERFPP_W(17) NERFPP_W(18) NERFPP_W(19)
-    NERFPP_W(20) NERFPP_W(21) NERFPP_W(22) NERFPP_W(23) NERFPP_W(24) NERFPP_W(25) NERFPP_W(26) NERFPP_W(27) NERFPP_W(28) NERFPP_W(29)
-    NERFPP_W(30) NERFPP_W(31) NERFPP_W(32) NERFPP_W(33) NERFPP_W(34) NERFPP_W(35) NERFPP_W(36) NERFPP_W(37) NERFPP_W(38) NERFPP_W(39)
-    NERFPP_W(40) NERFPP_W(41) NERFPP_W(42) NERFPP_W(43) NERFPP_W(44) NERFPP_W(45) NERFPP_W(46) NERFPP_W(47) NERFPP_W(48) NERFPP_W(49)
-    NERFPP_W(50) NERFPP_W(51) NERFPP_W(52) NERFPP_W(53) NERFPP_W(54) NERFPP_W(55) NERFPP_W(56) NERFPP_W(57) NERFPP_W(58) NERFPP_W(59)
-    NERFPP_W(60)
-#undef NERFPP_W
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // deeper than the counter: wait for everything (safe)
-  }
 }
 __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
   const uint4 w = *(const uint4*)&v;
@@ -288,40 +274,70 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
     const int n_a = (int)gm.nblk[0], n_b = (int)gm.nblk[1], n_total = P * (n_a + n_b);
     const int c_w = (n_total - wave + 7) >> 3;
     constexpr int CMAX = (P * 32 + 7) / 8;
-    int slot_i = 0, next_i = 0;
-    auto issue = [&]() {                           // next chunk of the slice -> next ring slot
-      const int c = next_i, slot = slot_i;
-      ++next_i;
-      slot_i = slot_i + 1 == NB ? 0 : slot_i + 1;
-      if (c >= nchunk || dbg == 2) return;
-      const size_t tile = (size_t)((r_begin >> 5) + c);
-      const uint32_t buf = lds_base + slot * gm.chunk;
-      const char* ca = ga + tile * tb_a * FRAG_BYTES + lane * 16;
-      const char* cb = gb + tile * tb_b * FRAG_BYTES + lane * 16;
+    const lds_addr off_a = lane_off, off_b = P * gm.img[0] + lane_off;
+    // The main loop is instantiated per value of c_w (1 .. CMAX; wave-uniform, the waves of a workgroup differ by at most
+    // one): the counted waits need immediates, and a 61-way switch on younger * c_w in every chunk cost 5-11 % of the
+    // launch (jump table + refetch).  Every instantiation runs the same number of barriers.
+    auto run = [&](auto cw_c) __attribute__((always_inline)) {
+      constexpr int CW = decltype(cw_c)::value;
+      int slot_i = 0, next_i = 0;
+      auto issue = [&]() __attribute__((always_inline)) {          // next chunk of the slice -> next ring slot
+        const int c = next_i, slot = slot_i;
+        ++next_i;
+        slot_i = slot_i + 1 == NB ? 0 : slot_i + 1;
+        if (c >= nchunk || dbg == 2) return;
+        const size_t tile = (size_t)((r_begin >> 5) + c);
+        const uint32_t buf = lds_base + slot * gm.chunk;
+        const char* ca = ga + tile * tb_a * FRAG_BYTES + lane * 16;
+        const char* cb = gb + tile * tb_b * FRAG_BYTES + lane * 16;
 #pragma unroll
-      for (int k = 0; k < CMAX; ++k) {
-        const int id = wave + 8 * k;
-        if (id < n_total) {                          // wave-uniform
+        for (int k = 0; k < CW; ++k) {
+          const int id = wave + 8 * k;                 // < n_total by the definition of c_w
           const bool is_b = id >= P * n_a;
           const int idl = is_b ? id - P * n_a : id, n_op = is_b ? n_b : n_a;
           const int pl = idl >= n_op ? 1 : 0, blk = idl - pl * n_op;   // P <= 2
           const char* src = (is_b ? cb + pl * plane_b : ca + pl * plane_a) + (size_t)blk * FRAG_BYTES;
           glds16(src, buf + (is_b ? P * gm.img[0] : 0u) + (uint32_t)pl * (is_b ? gm.img[1] : gm.img[0]) + (uint32_t)blk * BLKP);
         }
+      };
+      for (int c = 0; c < NB - 1; ++c) issue();
+      int slot_c = 0;
+      for (int c = 0; c < nchunk; ++c) {
+        const int younger = nchunk - 1 - c < NB - 2 ? nchunk - 1 - c : NB - 2;
+        switch (dbg == 2 ? 0 : younger) {            // wave-uniform; the count must be an immediate
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CW) : "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CW) : "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * CW) : "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * CW) : "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        issue();
+        const lds_addr buf = slot_c * gm.chunk;
+        slot_c = slot_c + 1 == NB ? 0 : slot_c + 1;
+        if (dbg == 1) continue;
+        compute_chunk_rr<P>(buf + off_a, buf + off_b, gm, wave, n_ib, nblk, job.gb_off >= 0, acc_rr, bsum_rr);
       }
     };
-    const lds_addr off_a = lane_off, off_b = P * gm.img[0] + lane_off;
-    for (int c = 0; c < NB - 1; ++c) issue();
-    int slot_c = 0;
-    for (int c = 0; c < nchunk; ++c) {
-      const int younger = nchunk - 1 - c < NB - 2 ? nchunk - 1 - c : NB - 2;
-      wait_vmcnt_dyn(dbg == 2 ? 0 : younger * c_w);   // this wave's share of chunk c has landed
-      __builtin_amdgcn_s_barrier();
-      issue();
-      const lds_addr buf = slot_c * gm.chunk;
-      slot_c = slot_c + 1 == NB ? 0 : slot_c + 1;
-      if (dbg == 1) continue;
-      compute_chunk_rr<P>(buf + off_a, buf + off_b, gm, wave, n_ib, nblk, job.gb_off >= 0, acc_rr, bsum_rr);
+    static_assert(CMAX <= 8 && 6 * CMAX < 63, "counted waits fit the vmcnt field");
+    switch (c_w) {
+      case 1: run(std::integral_constant<int, 1>{}); break;
+      case 2: run(std::integral_constant<int, 2>{}); break;
+      case 3: run(std::integral_constant<int, 3>{}); break;
+      case 4: run(std::integral_constant<int, 4>{}); break;
+      default:
+        if constexpr (P == 2) {
+          switch (c_w) {
+            case 5: run(std::integral_constant<int, 5>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            case 7: run(std::integral_constant<int, 7>{}); break;
+            default: run(std::integral_constant<int, 8>{}); break;
+          }
+        } else {
+          run(std::integral_constant<int, 4>{});
+        }
     }
   }
 

@@ -353,7 +353,17 @@ __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
 #endif
   if constexpr ((NERFPP_DBG & 4) != 0) { *(uint4*)gptr = v; return; }                                     // plain (temporal) store
   const u32x4 vv = {v.x, v.y, v.z, v.w};
+#if defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 1      // probes: cache-policy variants of the activation stores
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gptr), "v"(vv) : "memory");
+#elif defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(gptr), "v"(vv) : "memory");
+#elif defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(gptr), "v"(vv) : "memory");
+#elif defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 4
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(gptr), "v"(vv) : "memory");
+#else
   __builtin_nontemporal_store(vv, (u32x4*)gptr);
+#endif
 }
 
 // Saved tensors are FRAGMENT-MAJOR (nerfpp_common.h, "saved tensors"): the 16 bytes lane (j, hi) holds of chunk c of a
