@@ -164,16 +164,21 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
 #pragma unroll
   for (int blk = 0; blk < NKC / KPB; ++blk) {
     const char* l = pipe.acquire();
-    // the two waves of a SIMD (w, w+4) run the hook at opposite ends of the block, so one of them
-    // always has MFMAs to issue while the other waits on LDS / issues stores
-    if (pipe.wave >= 4) hook(blk);
+    // Where the hook (the saves) runs in a block.  With the LDS-staged saves of rounds 1-2 the two waves of a SIMD ran it at
+    // opposite ends (0), so that one always had MFMAs to issue while the other waited on LDS; with direct register stores
+    // there is nothing to wait for and "after the MFMAs" for every wave (1) measures 1.4 % faster in the forward
+    // (0.633 vs 0.642 ms at N_rand 1024), "before" (2) the same as (0).
+#ifndef NERFPP_HOOK_ORDER
+#define NERFPP_HOOK_ORDER 1
+#endif
+    if (NERFPP_HOOK_ORDER == 2 || (NERFPP_HOOK_ORDER == 0 && pipe.wave >= 4)) hook(blk);
 #pragma unroll
     for (int kl = 0; kl < KPB; ++kl) {
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob)
         mfma_p<P>(acc[ob], l + (kl * NOB + ob) * P * FRAG_BYTES, b[blk * KPB + kl]);
     }
-    if (pipe.wave < 4) hook(blk);
+    if (NERFPP_HOOK_ORDER == 1 || (NERFPP_HOOK_ORDER == 0 && pipe.wave < 4)) hook(blk);
     if constexpr (P == 1 && NERFPP_LDS_PREFETCH > 0) {
       // shape the block's schedule: NERFPP_LDS_PREFETCH weight fragments in flight ahead of the MFMA
       // that consumes them (LDS latency is ~2-4 MFMA slots; the default schedule keeps only 1-2 ahead)
