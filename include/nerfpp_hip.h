@@ -148,6 +148,17 @@ int nerfpp_pack_level(void* stream, int precision, const float* params, const in
 
 int64_t nerfpp_workspace_bytes(int n_rays, int n_samples, int precision, int training);
 
+/* Where a saved tensor of a training-mode forward / backward lives inside `workspace` (for inspection and tests; the
+ * product path never needs it).  tensor: 0 X (encoded point, internal column order), 1..8 H0..H7 (trunk activations, 256
+ * columns in the reference's neuron order), 10 G (128), 11 DIRX (32), 12..19 dZ0..dZ7 (256), 21 [dS | dG] (160; 22 = its
+ * dG part), 23 dP (32).  Layout: FRAGMENT-MAJOR bf16 -- element (row r, column f) of a tensor with `ld` columns is at
+ *   byte_offset + ((r / 32) * (ld / 16) + f / 16) * 1024 + (2 * (r % 32) + ((f % 16) / 4) % 2) * 16
+ *               + 2 * (4 * ((f % 16) / 8) + f % 4)
+ * (per 32-row tile and 16-column chunk one 1 KiB block = the register image of the wave that produced it); in split-bf16
+ * precision the `lo` plane follows at + plane_bytes.  Rows = n_rays * n_samples in (ray, sample) order. */
+int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, int tensor,
+                            int64_t* byte_offset, int32_t* ld, int64_t* plane_bytes);
+
 typedef struct {
   int32_t n_rays, n_samples;       /* S = 64 (level 0) or 192 (level 1) in the reference */
   int32_t precision, training;     /* training != 0 keeps what nerfpp_level_backward needs */

@@ -67,6 +67,7 @@ SYMBOLS = {
     'nerfpp_packed_bytes': (C.c_int64, [C.c_int]),
     'nerfpp_pack_level': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp]),
     'nerfpp_workspace_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'nerfpp_workspace_tensor': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i64p, _i32p, _i64p]),
     'nerfpp_level_forward': (C.c_int, [_fp, C.POINTER(ForwardArgs)]),
     'nerfpp_loss': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [_fp] * 12),
     'nerfpp_level_backward': (C.c_int, [_fp, C.POINTER(BackwardArgs)]),

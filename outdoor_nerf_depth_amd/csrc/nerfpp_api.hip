@@ -286,6 +286,19 @@ int64_t nerfpp_workspace_bytes(int n_rays, int n_samples, int precision, int tra
   return (int64_t)ws_layout(n_rays, n_samples, precision, training != 0).total;
 }
 
+int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, int tensor, int64_t* byte_offset,
+                            int32_t* ld, int64_t* plane_bytes) {
+  REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= NERFPP_MAX_SAMPLES && prec_ok(precision), "sizes / precision");
+  REQUIRE(net >= 0 && net < N_NET && tensor >= 0 && tensor < T_COUNT && tensor != T_R && tensor != T_DR, "net / tensor id");
+  REQUIRE(byte_offset && ld && plane_bytes, "non-null outputs");
+  const WsLayout L = ws_layout(n_rays, n_samples, precision, true);
+  const int l = tensor_ld(net, tensor);
+  *byte_offset = tensor == T_DG ? (int64_t)L.tensor[net][T_DS] + (DG_COL0 / 16) * FRAG_BYTES : (int64_t)L.tensor[net][tensor];
+  *ld = l;
+  *plane_bytes = (int64_t)L.rows_padded * l * 2;
+  return NERFPP_OK;
+}
+
 int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
   REQUIRE(a, "args");
   REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");

@@ -264,6 +264,24 @@ class LevelEngine(object):
             self._fwd = (n, S, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
         return out
 
+    def saved_tensor(self, net, tensor, plane=0):
+        """A saved tensor of the last training-mode forward / backward as a float32 [rows, ld] torch tensor (inspection /
+        tests only): un-does the fragment-major layout of include/nerfpp_hip.h (nerfpp_workspace_tensor)."""
+        if self._fwd is None:
+            raise L.NerfppError('saved_tensor() needs a preceding forward(training=True)')
+        n, S = self._fwd[0], self._fwd[1]
+        off, ld, pb = C.c_int64(), C.c_int32(), C.c_int64()
+        L.check(L.lib().nerfpp_workspace_tensor(n, S, self.precision, int(net), int(tensor), C.byref(off), C.byref(ld),
+                                                C.byref(pb)), 'nerfpp_workspace_tensor')
+        rows, ld = n * S, ld.value
+        rows_p = (rows + 31) // 32 * 32
+        nblk = rows_p // 32 * (ld // 16)
+        raw = self.workspace[off.value + plane * pb.value: off.value + plane * pb.value + nblk * 1024]
+        blk = raw.view(torch.bfloat16).view(rows_p // 32, ld // 16, 32, 2, 8)      # [tile, chunk, j, hi, slot t]
+        # slot t of lane-half hi = column 8 (t >> 2) + 4 hi + (t & 3) of the chunk
+        blk = blk.view(rows_p // 32, ld // 16, 32, 2, 2, 4).permute(0, 2, 1, 4, 3, 5)   # [tile, j, chunk, t >> 2, hi, t & 3]
+        return blk.reshape(rows_p, ld)[:rows].float()
+
     def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None, events=None, defer_reduce=False,
                  fused_loss=None):
         """Gradient of the loss w.r.t. the flat parameters given dL/d rgb, dL/d depth and (KL)

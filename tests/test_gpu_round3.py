@@ -163,3 +163,34 @@ def test_sample_fine_pair_rng_and_det_at_bench_size(ops):
     d, _ = ops.sample_fine_pair(fg_z, wf, bg_z, wb, n_new, det=True)
     u_det = np.broadcast_to(O.torch_linspace(0.0, 1.0, n_new), (n, n_new))
     np.testing.assert_array_equal(N(d), O.fine_depths(N(fg_z), N(wf), u_det)[0])
+
+
+# ------------------------------------------------------------------------------------------------ saved tensors (layout)
+@pytest.mark.parametrize('precision', [1, 2])
+def test_saved_activations_in_the_workspace_match_the_oracle(ops, precision):
+    """The fragment-major saved tensors, read back through nerfpp_workspace_tensor and un-permuted: H0..H7 and G of both nets
+    against the oracle's activations of the same forward (48 rays x 64 samples: the last 256-row tile is ragged).  Checks
+    the layout contract of include/nerfpp_hip.h directly, not only through the gradients."""
+    n, S = 48, 64
+    b = _batch(n, 8)
+    level = O.init_params_like_reference(1)[0]
+    eng = ops.LevelEngine(T(flat(level)), precision=precision)
+    ray_o, ray_d = T(b['ray_o']), T(b['ray_d'])
+    far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, T(b['min_depth']), S, rng=(3, 1))
+    eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True)
+    cache = {}
+    O.nerf_forward(level, b['ray_o'], b['ray_d'], N(far), N(fg_z), N(bg_z), cache=cache, bf16=(precision == 1))
+    tol = dict(rtol=2e-2, atol=2e-2) if precision == 1 else dict(rtol=3e-5, atol=3e-5)
+    for net, key in ((0, 'fg'), (1, 'bg')):
+        c = cache[key]
+        for l in range(8):
+            got = N(eng.saved_tensor(net, 1 + l))
+            if precision == 2:
+                got = got + N(eng.saved_tensor(net, 1 + l, plane=1))          # hi + lo
+            want = np.maximum(c['pre'][l], 0)
+            assert got.shape == want.shape == (n * S, 256)
+            np.testing.assert_allclose(got, want, err_msg='net %d H%d' % (net, l), **tol)
+        g = N(eng.saved_tensor(net, 10))
+        if precision == 2:
+            g = g + N(eng.saved_tensor(net, 10, plane=1))
+        np.testing.assert_allclose(g, c['g'], err_msg='net %d G' % net, **tol)

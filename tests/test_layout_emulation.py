@@ -266,3 +266,39 @@ def test_mip360_library_loads_and_exports_every_declared_symbol():
     assert b'non-null' in lib.mip360_last_error()
     b = M3.pos_basis_t()
     assert b.shape == (3, 21)
+
+
+def test_fragment_major_saved_tensor_layout_is_a_bijection():
+    """nerfpp_common.h, "saved tensors": element (row r, column f) of a tensor with ld columns lives at
+    ((r // 32) * (ld // 16) + f // 16) * 1024 + (2 * (r % 32) + hi) * 16 + 2 * t  with, inside the 16-column chunk,
+    hi = ((f % 16) // 4) % 2 and slot t = 4 * ((f % 16) // 8) + f % 4 (the kslot map) -- what lane (j, hi) of the producing
+    wave holds in slot t of chunk c.  Host-side emulation: the map is a bijection onto the same bytes as a row-major
+    tensor, a wave's chunk is 1 KiB contiguous, and the four 8-byte pieces ds_read_b64_tr_b16 gathers per sample are the
+    feature quads in natural order."""
+    def addr(r, f, ld):
+        fw = f % 16
+        hi, t = (fw // 4) % 2, 4 * (fw // 8) + fw % 4
+        return ((r // 32) * (ld // 16) + f // 16) * 1024 + (2 * (r % 32) + hi) * 16 + 2 * t
+    for ld, rows in ((256, 64), (160, 32), (96, 64), (32, 96)):
+        seen = np.zeros(rows * ld * 2, np.int32)
+        for r in range(rows):
+            for f in range(ld):
+                a = addr(r, f, ld)
+                assert a % 2 == 0 and a + 2 <= seen.size
+                seen[a] += 1
+        assert (seen[0::2] == 1).all() and (seen[1::2] == 0).all()       # every bf16 slot exactly once
+        # a wave's chunk (32 rows x 16 columns) is one contiguous, 1 KiB-aligned block
+        blk = sorted(addr(r, f, ld) for r in range(32, 64) for f in range(16, 32)) if rows >= 64 and ld >= 32 else None
+        if blk:
+            assert blk[0] % 1024 == 0 and blk[-1] - blk[0] == 1022 and len(set(blk)) == 512
+    # kslot consistency with nerfpp_common.h: slot t of lane-half hi in chunk c is feature 16c + 8(t>>2) + 4hi + (t&3)
+    for c in range(3):
+        for hi in range(2):
+            for t in range(8):
+                f = 16 * c + 8 * (t >> 2) + 4 * hi + (t & 3)
+                assert addr(5, f, 64) == (0 * 4 + c) * 1024 + (2 * 5 + hi) * 16 + 2 * t
+    # the transposed read: piece q (features 4q..4q+3 of the chunk) of sample j sits at (2j + (q & 1)) * 16 + 8 * (q >> 1)
+    for j in (0, 7, 31):
+        for q in range(4):
+            want = (2 * j + (q & 1)) * 16 + 8 * (q >> 1)
+            assert [addr(j, 4 * q + e, 16) for e in range(4)] == [want + 2 * e for e in range(4)]
