@@ -149,6 +149,23 @@ int mip360_linear_relu_mask_bf16(void* stream, int m, int n, int k, const void* 
 int mip360_linear_masked_bf16(void* stream, int m, int n, int k, const void* a, int lda, const void* w, int ldw,
                               void* c_bf16, int ldc, const void* mask, int ldmask);
 
+/* ---- fragment-major ("fm") dense layers: the wide layers' activations in the order the matrix cores consume and
+ * produce them (csrc/mip360_fm.hip).  A [rows, ld] bf16 tensor (rows % 32 == 0, ld % 16 == 0) is 1 KiB blocks of
+ * 32 rows x 16 columns, block (r / 32, c / 16) at ((r / 32) * (ld / 16) + c / 16) * 1024 bytes; in a block, element
+ * (row, f) -- hi = (f / 4) % 2, t = 4 (f / 8) + f % 4 -- is at byte 16 * (8 (row >> 2) + 4 (hi ^ (row >> 4)) + (row & 3))
+ * + 2 t.  Replaces nn.Dense + nn.relu of MLP.__call__ (internal/models.py:436-606) for the 256- / 1024-wide layers.
+ *   mip360_to_fm / mip360_from_fm : row-major bf16 [rows, cols] (row stride ld_src / ld_dst elements) <-> columns
+ *       [col0, col0 + cols) of an fm tensor with ld columns.
+ *   mip360_linear_fm : C = act(A W^T + b); A [m, k], W [n, k], C [m, n] all fm; m, n multiples of 256, k a multiple of
+ *       32 (>= 128).  act 0: bias only; 1: ReLU, and one bit per output (non-zero) to `mask` (mip360_fm_mask_bytes
+ *       bytes); 2: no bias, outputs whose bit in `mask` (written by an act-1 call with the same m, n) is clear are
+ *       zeroed -- the dX chain.  The bias is added by the matrix cores as bf16 hi + lo (2^-17 relative). */
+int mip360_to_fm(void* stream, int rows, int cols, const void* src_bf16, int ld_src, void* dst_fm, int ld_dst, int col0_dst);
+int mip360_from_fm(void* stream, int rows, int cols, const void* src_fm, int ld_src, int col0_src, void* dst_bf16, int ld_dst);
+int64_t mip360_fm_mask_bytes(int m, int n);
+int mip360_linear_fm(void* stream, int m, int n, int k, const void* a_fm, int lda, const void* w_fm, int ldw,
+                     const float* bias, int act, void* c_fm, int ldc, void* mask);
+
 /* ---- training side (upstream: jax.value_and_grad + optax, train_utils.py:215-236, 303-370) ---------------------- */
 
 /* d kernel [n_in, n_out] (flax layout, float32, row stride ldg) = scale * H[m, n_in]^T dZ[m, n_out]: bf16 operands,

@@ -29,6 +29,7 @@ OUT_MIP360 = os.path.join(PKG, 'libmip360_hip.so')
 SOURCES_MIP360 = {
     'mip360_kernels.hip': ['-ffp-contract=off'],    # arithmetic order of the oracle
     'mip360_gemm.hip': [],
+    'mip360_fm.hip': [],
     'mip360_train.hip': [],
     'mip360_api.hip': [],
 }

@@ -25,6 +25,10 @@ void mip360_launch_losses(hipStream_t st, int n, int s_nerf, int s_prop, int n_p
 void mip360_launch_depth_klurf(hipStream_t st, int type, int n, int S, const float* w, const float* td, const float* sup,
                                const float* dm, const float* dirs, float sigma, float scale, float* out, float* g_w,
                                float* g_dm, float* accum);
+int mip360_launch_linear_fm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
+                            int act, void* C, int ldc, void* mask);
+int mip360_launch_to_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, void* dst, int ld_dst, int col0_dst);
+int mip360_launch_from_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, int col0_src, void* dst, int ld_dst);
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                           int act, float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux,
                           void* mask, int ldmask);
@@ -199,6 +203,33 @@ int mip360_linear_masked_bf16(void* stream, int m, int n, int k, const void* a, 
   mip360_launch_linear((hipStream_t)stream, m, n, k, a, lda, w, ldw, nullptr, 6, 0.f, c_bf16, ldc, nullptr, 0, nullptr, 0,
                        (void*)mask, ldmask);
   return check_launch("linear_masked_bf16");
+}
+
+// ---- fragment-major dense layers (mip360_fm.hip)
+
+int64_t mip360_fm_mask_bytes(int m, int n) { return m > 0 && n > 0 ? (int64_t)(m / 256) * (n / 256) * 8 * 64 * 16 : 0; }
+
+int mip360_to_fm(void* stream, int rows, int cols, const void* src_bf16, int ld_src, void* dst_fm, int ld_dst, int col0_dst) {
+  REQUIRE(src_bf16 && dst_fm && rows > 0 && cols > 0, "non-null pointers");
+  REQUIRE(mip360_launch_to_fm((hipStream_t)stream, rows, cols, src_bf16, ld_src, dst_fm, ld_dst, col0_dst) == 0,
+          "rows % 32 == 0, cols / ld_dst / col0_dst % 16 == 0, ld_src % 4 == 0");
+  return check_launch("to_fm");
+}
+
+int mip360_from_fm(void* stream, int rows, int cols, const void* src_fm, int ld_src, int col0_src, void* dst_bf16, int ld_dst) {
+  REQUIRE(src_fm && dst_bf16 && rows > 0 && cols > 0, "non-null pointers");
+  REQUIRE(mip360_launch_from_fm((hipStream_t)stream, rows, cols, src_fm, ld_src, col0_src, dst_bf16, ld_dst) == 0,
+          "rows % 32 == 0, cols / ld_src / col0_src % 16 == 0, ld_dst % 4 == 0");
+  return check_launch("from_fm");
+}
+
+int mip360_linear_fm(void* stream, int m, int n, int k, const void* a_fm, int lda, const void* w_fm, int ldw, const float* bias,
+                     int act, void* c_fm, int ldc, void* mask) {
+  REQUIRE(a_fm && w_fm && c_fm, "non-null operands and output");
+  REQUIRE(lda >= k && ldw >= k && ldc >= n, "leading dimensions >= k / n");
+  REQUIRE(mip360_launch_linear_fm((hipStream_t)stream, m, n, k, a_fm, lda, w_fm, ldw, bias, act, c_fm, ldc, mask) == 0,
+          "m, n multiples of 256; k a multiple of 32, >= 128; leading dimensions multiples of 16; act 0 / 1 need bias, 1 / 2 the mask");
+  return check_launch("linear_fm");
 }
 
 int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void* h, int ldh, const void* dz, int lddz,

@@ -1,0 +1,376 @@
+// Fragment-major dense layers of the MipNeRF-360 MLPs (models.py:436-606 nn.Dense + nn.relu, and the dX chain of
+// jax.grad): the activations between the wide layers never exist in row-major form.
+//
+// Layout ("fm").  A [rows, ld] bf16 tensor (rows % 32 == 0, ld % 16 == 0) is stored as 1 KiB blocks of 32 rows x 16
+// columns, block (r / 32, c / 16) at ((r / 32) * (ld / 16) + c / 16) * 1024.  Inside a block the 16-byte unit of
+// (row, hi) -- hi = ((c % 16) / 4) % 2 -- holds the 8 columns {4 hi + 0..3, 8 + 4 hi + 0..3} (element t = 4 ((c % 16) / 8)
+// + c % 4) and sits at unit index  u = 8 (row >> 2) + 4 (hi ^ (row >> 4)) + (row & 3).
+//   * A unit is exactly what one lane of v_mfma_f32_32x32x16_bf16 supplies for a 16-wide k step (lane = row + 32 hi; the
+//     k order inside the step is the same permutation for both operands, so the contraction is exact), AND what one lane
+//     of the 32 x 32 accumulator block owns of a 16-column block of the output (registers 8 b .. 8 b + 7 of lane
+//     (row, hi) are columns 16 b + {4 hi + 0..3, 8 + 4 hi + 0..3}).  So a layer's epilogue stores its accumulators with
+//     plain 16-byte stores, 1 KiB contiguous per wave instruction, no LDS staging, and the next layer's operand DMA
+//     (global_load_lds_dwordx4) is a linear copy of whole blocks whose LDS image needs no swizzle.
+//   * The unit order makes BOTH read patterns conflict-free: ds_read_b128 by lane (row, hi) (the 16-lane service groups
+//     of MI355X_MICROARCH.md "LDS" see 16 distinct units mod 16), and the ds_read_b64_tr_b16 patches of the weight-
+//     gradient kernel (4 rows x 16 columns = 8 consecutive units).
+//
+// Kernel (linear_fm_kernel): C = act(A W^T + b) on 256 x 256 tiles, 8 waves of 128 x 64 (4 x 2 MFMA blocks, operands
+// swapped so that the accumulator block is C^T: lane = row).  Persistent workgroups; the operand stream is ONE ring of
+// five 32 KiB slots (a slot = 32 k-elements of both operands) that runs across tile boundaries: the first half-steps of
+// the next tile are in flight while the current tile finishes, and the epilogue (registers -> global) does not touch
+// LDS.  The two wave groups run half a step apart (one multiplies while the other reads fragments / issues DMA / stores)
+// as in linear_bf16_pp64_kernel.  Every VMEM instruction is inline asm: loads and stores share vmcnt and return in
+// order, the counted waits below rely on the exact instruction sequence (and a compiler that saw the stores would drain
+// vmcnt at every barrier).
+#include "probe_env.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mip360fm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ __forceinline__ uint32_t unit_of(int row, int hi) { return 8u * (row >> 2) + 4u * (hi ^ (row >> 4)) + (row & 3); }
+
+extern __shared__ __attribute__((aligned(16))) char fm_smem[];
+
+// LDS-DMA of 64 x 16 bytes: global address = wave-uniform base + per-lane offset, LDS address = dst + 16 * lane
+__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+__device__ __forceinline__ uint64_t uniform64(const void* p) {
+  const uint64_t b = (uint64_t)(uintptr_t)p;
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+}
+
+struct Cfg {
+  static constexpr int SLOT = 32768, NSLOT = 5, WOFF = 16384, LDS = SLOT * NSLOT;
+  static constexpr int AHEAD = 4;                   // the fragment-read phase of half-step x issues the DMA of x + AHEAD
+};
+
+// ACT 0: C = A W^T + b;  1: relu(A W^T + b), bit mask of the non-zero outputs to `mask` (when not null);
+//     2: (A W^T) with the elements whose mask bit is clear set to zero (the dX chain; no bias)
+// mask: one uint4 per (tile, wave, lane): word i = MFMA row block i of the wave, bit 8 j + p + 16 e = accumulator
+// registers 2 p + e of column block j -- the same lanes own the same elements in the layer that writes it and the
+// one that applies it (equal tile shapes).
+template <int ACT>
+__global__ __launch_bounds__(512, 1)
+void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, const char* __restrict__ W, int ldw,
+                      const float* __restrict__ bias, char* __restrict__ C, int ldc, u32x4* __restrict__ mask) {
+  constexpr int SLOT = Cfg::SLOT;
+  // VMEM instructions of one epilogue + preload (older than the DMA issued after it): output stores, mask store / load, bias loads
+  constexpr int NE = ACT == 0 ? 16 + 2 : ACT == 1 ? 16 + 1 + 2 : 16 + 1;
+  constexpr int VM_STEADY = 3 * 4, VM_PEEL = VM_STEADY + NE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, grp = wm;            // group 0 = waves 0-3 = tile rows 0-127
+  const int tiles_n = N >> 8, tiles_m = M >> 8, tiles = tiles_m * tiles_n;
+  const int nh = K >> 5;                                        // half-steps (32 k-elements) per tile, >= 4
+  const int T = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)fm_smem;
+  const int row = lane & 31, hi = lane >> 5;
+  const uint32_t u16 = unit_of(row, hi) * 16u;
+  const uint32_t pa0 = lds0 + u16 + (uint32_t)wm * 8192u, pb0 = lds0 + Cfg::WOFF + u16 + (uint32_t)wn * 4096u;
+  const uint32_t voff = (uint32_t)lane * 16u;
+  const size_t a_rb = (size_t)(lda >> 4) * 1024, w_rb = (size_t)(ldw >> 4) * 1024, c_rb = (size_t)(ldc >> 4) * 1024;
+
+  auto decode = [&](int t, int& tile_m, int& tile_n) {          // XCD-aware order (gridDim.x % 8 == 0 or one tile each)
+    const int vb = (int)blockIdx.x + t * (int)gridDim.x;
+    const int xcd = vb & 7, id = vb >> 3;
+    const int full = (tiles_m / 8) * 8;
+    const int group = id / tiles_n;
+    if (group * 8 + 8 <= full) { tile_m = group * 8 + xcd; tile_n = id - group * tiles_n; }
+    else { const int r = vb - full * tiles_n; tile_m = full + r / tiles_n; tile_n = r - (r / tiles_n) * tiles_n; }
+  };
+
+  // ---- DMA issue cursor: wave w fetches row block w of the A tile and row block w of the W tile, 2 x 1 KiB each per half-step
+  int it = 0, ih = 0;
+  uint32_t islot = 0;
+  const char *iA = A, *iW = W;
+  auto set_issue_tile = [&](int t) {
+    int tm, tn;
+    decode(t, tm, tn);
+    iA = A + (size_t)(tm * 8 + wave) * a_rb;
+    iW = W + (size_t)(tn * 8 + wave) * w_rb;
+  };
+  auto issue = [&]() {
+    const uint32_t d = lds0 + islot + (uint32_t)wave * 2048u;
+    glds16(iA, voff, d);
+    glds16(iA + 1024, voff, d + 1024u);
+    glds16(iW, voff, d + Cfg::WOFF);
+    glds16(iW + 1024, voff, d + Cfg::WOFF + 1024u);
+    islot = islot == (Cfg::NSLOT - 1) * SLOT ? 0u : islot + SLOT;
+    iA += 2048; iW += 2048;
+    if (++ih == nh) { ih = 0; ++it; set_issue_tile(it < T ? it : 0); }   // past the last tile: re-loads of tile 0 into free slots keep the counts uniform
+  };
+
+  bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+  f32x16 acc[4][2];
+#define FM_READ(s_)                                                                                                    \
+  {                                                                                                                    \
+    const uint32_t pa = pa0 + (s_), pb = pb0 + (s_);                                                                   \
+    asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:2048\n\tds_read_b128 %2, %12 offset:4096\n\t"    \
+                 "ds_read_b128 %3, %12 offset:6144\n\tds_read_b128 %4, %13\n\tds_read_b128 %5, %13 offset:2048\n\t"     \
+                 "ds_read_b128 %6, %12 offset:1024\n\tds_read_b128 %7, %12 offset:3072\n\tds_read_b128 %8, %12 offset:5120\n\t" \
+                 "ds_read_b128 %9, %12 offset:7168\n\tds_read_b128 %10, %13 offset:1024\n\tds_read_b128 %11, %13 offset:3072"   \
+                 : "=&v"(fa0[0]), "=&v"(fa0[1]), "=&v"(fa0[2]), "=&v"(fa0[3]), "=&v"(fb0[0]), "=&v"(fb0[1]),            \
+                   "=&v"(fa1[0]), "=&v"(fa1[1]), "=&v"(fa1[2]), "=&v"(fa1[3]), "=&v"(fb1[0]), "=&v"(fb1[1])             \
+                 : "v"(pa), "v"(pb) : "memory");                                                                       \
+  }
+#define FM_LGKM0()                                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
+               : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fa1[0]),      \
+                 "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fb1[0]), "+v"(fb1[1]) :: "memory")
+#define FM_MUL()                                                                                                       \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                       \
+  }
+#define FM_MUL_FIRST()                                                                                                 \
+  {                                                                                                                    \
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], zero, 0, 0, 0);                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                       \
+  }
+#define FM_VMCNT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define FM_PHASE_END()                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);
+  auto next_slot = [&](uint32_t s) { return s == (Cfg::NSLOT - 1) * SLOT ? 0u : s + SLOT; };
+
+  // ---- per-tile side data, fetched one tile ahead (asm loads: covered by the counted waits of the following half-steps)
+  uint32_t bias_raw[2] = {0u, 0u};                              // float bits of bias[n0 + 64 wn + 32 j + row]
+  u32x4 mw = {0u, 0u, 0u, 0u};                                  // ACT 2: this lane's mask words of the tile
+  auto preload = [&](int t) {
+    int tm, tn;
+    decode(t < T ? t : 0, tm, tn);
+    if (ACT != 2) {
+      const uint64_t b = uniform64(bias + tn * 256 + wn * 64);
+      const uint32_t o = (uint32_t)row * 4u;
+      asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128"
+                   : "=&v"(bias_raw[0]), "=&v"(bias_raw[1]) : "v"(o), "s"(b) : "memory");
+    } else {
+      const uint64_t b = uniform64(mask + ((size_t)(tm * tiles_n + tn) * 8 + wave) * 64);
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(mw) : "v"(voff), "s"(b) : "memory");
+    }
+  };
+
+  // ---- epilogue of tile t: bias through the matrix pipe, activation, bf16, 16 wave-contiguous stores
+  auto bias_mfma = [&]() {
+    if (ACT == 2) return;
+    asm volatile("" : "+v"(bias_raw[0]), "+v"(bias_raw[1]));      // (consumed here, behind the waits that covered the loads)
+    bf16x8 ones, bfr[2];
+    {
+      u32x4 o = {hi ? 0u : 0x3F803F80u, 0u, 0u, 0u};
+      ones = __builtin_bit_cast(bf16x8, o);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float b = __builtin_bit_cast(float, bias_raw[j]);
+      const __bf16 bh = (__bf16)b;
+      const __bf16 bl = (__bf16)(b - (float)bh);
+      const uint32_t w0 = (uint32_t)__builtin_bit_cast(uint16_t, bh) | ((uint32_t)__builtin_bit_cast(uint16_t, bl) << 16);
+      u32x4 v = {hi ? 0u : w0, 0u, 0u, 0u};
+      bfr[j] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], ones, acc[i][j], 0, 0, 0);
+  };
+  // (a store's data registers are read a few cycles after issue: the s_nop behind every asm store keeps the compiler's next
+  // VALU write -- it cannot see that the asm is a store -- out of that window)
+  auto epilogue = [&](int t) {
+    int tm, tn;
+    decode(t, tm, tn);
+    if (ACT == 2) asm volatile("" : "+v"(mw));
+    u32x4 mout = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint64_t cb = uniform64(C + (size_t)(tm * 8 + wm * 4 + i) * c_rb + (size_t)(tn * 16 + wn * 4) * 1024);
+      uint32_t word = 0u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          float v0 = acc[i][j][2 * p], v1 = acc[i][j][2 * p + 1];
+          if (ACT == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          const f32x2 f = {v0, v1};
+          uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+          if (ACT == 1) {
+            w &= 0x7FFF7FFFu;                                    // (-0 -> +0)
+            const uint32_t nz = ((w & 0xFFFFu) ? 1u : 0u) | ((w >> 16) ? 0x10000u : 0u);
+            word |= nz << (8 * j + p);
+          }
+          if (ACT == 2) w &= ((mw[i] >> (8 * j + p)) & 0x00010001u) * 0xFFFFu;
+          pk[p] = w;
+        }
+        const u32x4 lo = {pk[0], pk[1], pk[2], pk[3]}, hi4 = {pk[4], pk[5], pk[6], pk[7]};
+        if (j == 0)
+          asm volatile("global_store_dwordx4 %0, %1, %3\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024\n\ts_nop 1" ::"v"(u16), "v"(lo), "v"(hi4), "s"(cb) : "memory");
+        else
+          asm volatile("global_store_dwordx4 %0, %1, %3 offset:2048\n\tglobal_store_dwordx4 %0, %2, %3 offset:3072\n\ts_nop 1" ::"v"(u16), "v"(lo), "v"(hi4), "s"(cb) : "memory");
+      }
+      mout[i] = word;
+    }
+    if (ACT == 1) {
+      // (a null mask pointer still issues the store -- to a scratch line the launcher provides -- so that the counts hold)
+      const uint64_t b = uniform64(mask + ((size_t)(tm * tiles_n + tn) * 8 + wave) * 64);
+      asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(mout), "s"(b) : "memory");
+    }
+  };
+
+  // ---- prologue: half-steps 0 .. AHEAD-1 and the first tile's side data, synchronously
+  set_issue_tile(0);
+  issue(); issue(); issue(); issue();
+  preload(0);
+  FM_VMCNT(0);
+  asm volatile("" : "+v"(bias_raw[0]), "+v"(bias_raw[1]), "+v"(mw));
+  FM_PHASE_END();
+  uint32_t cs = 0;                                              // slot of the half-step whose fragments are read next
+  // Schedule (x = half-step counted over all tiles of the workgroup):
+  //   group 0: [MUL(x), wait] | [read(x + 1), DMA(x + 5)]          group 1: [read(x), DMA(x + 4), wait] | [MUL(x)]
+  // "wait" = own DMA of half-step x + 1 has landed (3 younger half-steps of 4 instructions may be out; + NE while the
+  // epilogue's instructions are younger than it, i.e. for the first three half-steps of a tile; the first tile's were
+  // awaited by the prologue).  The barrier after it publishes x + 1 to both groups one phase before they read it.
+  if (grp == 0) {
+    FM_READ(cs); issue(); FM_LGKM0(); cs = next_slot(cs);
+    FM_PHASE_END();
+    for (int t = 0; t < T; ++t) {
+#define FM_G0_STEP(MUL_, VM_, TAIL_)                                                                                   \
+      MUL_;                                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      FM_VMCNT(VM_);                                                                                                   \
+      FM_PHASE_END();                                                                                                  \
+      TAIL_;                                                                                                           \
+      FM_READ(cs); issue(); FM_LGKM0(); cs = next_slot(cs);                                                            \
+      FM_PHASE_END();
+      FM_G0_STEP(FM_MUL_FIRST(), VM_PEEL, (void)0);
+      FM_G0_STEP(FM_MUL(), VM_PEEL, (void)0);
+      FM_G0_STEP(FM_MUL(), VM_PEEL, (void)0);
+      for (int h = 3; h < nh - 1; ++h) { FM_G0_STEP(FM_MUL(), VM_STEADY, (void)0); }
+      FM_G0_STEP({ FM_MUL(); bias_mfma(); }, VM_STEADY, { epilogue(t); preload(t + 1); });
+    }
+  } else {
+    FM_PHASE_END();
+    for (int t = 0; t < T; ++t) {
+#define FM_G1_STEP(MUL_, VM_)                                                                                          \
+      FM_READ(cs); issue(); FM_LGKM0(); cs = next_slot(cs);                                                            \
+      FM_VMCNT(VM_);                                                                                                   \
+      FM_PHASE_END();                                                                                                  \
+      MUL_;                                                                                                            \
+      FM_PHASE_END();
+      FM_G1_STEP(FM_MUL_FIRST(), VM_PEEL);
+      FM_G1_STEP(FM_MUL(), VM_PEEL);
+      FM_G1_STEP(FM_MUL(), VM_PEEL);
+      for (int h = 3; h < nh - 1; ++h) { FM_G1_STEP(FM_MUL(), VM_STEADY); }
+      FM_G1_STEP({ FM_MUL(); bias_mfma(); }, VM_STEADY);
+      epilogue(t);
+      preload(t + 1);
+    }
+  }
+  FM_VMCNT(0);
+#undef FM_G0_STEP
+#undef FM_G1_STEP
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// row-major <-> fragment-major (bf16): one thread per 16-byte unit
+__global__ __launch_bounds__(256) void to_fm_kernel(int rows, int cols, const uint16_t* __restrict__ src, int ld_src, char* __restrict__ dst,
+                                                    int ld_dst, int col0_dst) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;   // unit: (row block, col block, row, hi)
+  const int cb_n = cols >> 4;
+  const int64_t blk = id >> 6;
+  if (blk >= (int64_t)(rows >> 5) * cb_n) return;
+  const int rb = (int)(blk / cb_n), cb = (int)(blk - (int64_t)rb * cb_n), row = (int)(id & 31), hi = (int)((id >> 5) & 1);
+  const uint16_t* s = src + (size_t)(rb * 32 + row) * ld_src + cb * 16 + 4 * hi;
+  const uint2 a = *(const uint2*)s, b = *(const uint2*)(s + 8);
+  char* d = dst + ((size_t)rb * (ld_dst >> 4) + (col0_dst >> 4) + cb) * 1024 + unit_of(row, hi) * 16;
+  *(uint4*)d = make_uint4(a.x, a.y, b.x, b.y);
+}
+__global__ __launch_bounds__(256) void from_fm_kernel(int rows, int cols, const char* __restrict__ src, int ld_src, int col0_src,
+                                                      uint16_t* __restrict__ dst, int ld_dst) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cb_n = cols >> 4;
+  const int64_t blk = id >> 6;
+  if (blk >= (int64_t)(rows >> 5) * cb_n) return;
+  const int rb = (int)(blk / cb_n), cb = (int)(blk - (int64_t)rb * cb_n), row = (int)(id & 31), hi = (int)((id >> 5) & 1);
+  const uint4 v = *(const uint4*)(src + ((size_t)rb * (ld_src >> 4) + (col0_src >> 4) + cb) * 1024 + unit_of(row, hi) * 16);
+  uint16_t* d = dst + (size_t)(rb * 32 + row) * ld_dst + cb * 16 + 4 * hi;
+  *(uint2*)d = make_uint2(v.x, v.y);
+  *(uint2*)(d + 8) = make_uint2(v.z, v.w);
+}
+
+}  // namespace mip360fm
+
+static int fm_n_cu() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    n_cu = n_cu >= 8 ? n_cu / 8 * 8 : 8;
+  }
+  return n_cu;
+}
+
+// M, N multiples of 256; K a multiple of 32, >= 128; lda / ldw / ldc multiples of 16 (columns of the fm tensors)
+int mip360_launch_linear_fm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
+                            int act, void* C, int ldc, void* mask) {
+  using namespace mip360fm;
+  if (M <= 0 || N <= 0 || M % 256 || N % 256 || K % 32 || K < 128 || lda % 16 || ldw % 16 || ldc % 16) return 1;
+  if ((act == 2 && !mask) || (act != 2 && !bias) || (act == 1 && !mask) || act < 0 || act > 2) return 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)linear_fm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute((const void*)linear_fm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute((const void*)linear_fm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    attr_set = true;
+  }
+  const int tiles = (M / 256) * (N / 256), n_cu = fm_n_cu();
+  const dim3 grid(tiles < n_cu ? tiles : n_cu), block(512);
+#define FM_LAUNCH(ACT_)                                                                                                 \
+  hipLaunchKernelGGL((linear_fm_kernel<ACT_>), grid, block, Cfg::LDS, st, M, N, K, (const char*)A, lda, (const char*)W, ldw, bias,  \
+                     (char*)C, ldc, (u32x4*)mask)
+  if (act == 0) FM_LAUNCH(0);
+  else if (act == 1) FM_LAUNCH(1);
+  else FM_LAUNCH(2);
+#undef FM_LAUNCH
+  return 0;
+}
+
+int mip360_launch_to_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, void* dst, int ld_dst, int col0_dst) {
+  if (rows % 32 || cols % 16 || ld_dst % 16 || col0_dst % 16 || ld_src % 4) return 1;
+  const int64_t units = (int64_t)(rows / 32) * (cols / 16) * 64;
+  hipLaunchKernelGGL(mip360fm::to_fm_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, rows, cols, (const uint16_t*)src, ld_src,
+                     (char*)dst, ld_dst, col0_dst);
+  return 0;
+}
+int mip360_launch_from_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, int col0_src, void* dst, int ld_dst) {
+  if (rows % 32 || cols % 16 || ld_src % 16 || col0_src % 16 || ld_dst % 4) return 1;
+  const int64_t units = (int64_t)(rows / 32) * (cols / 16) * 64;
+  hipLaunchKernelGGL(mip360fm::from_fm_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, rows, cols, (const char*)src, ld_src,
+                     col0_src, (uint16_t*)dst, ld_dst);
+  return 0;
+}
