@@ -165,6 +165,10 @@ int mip360_from_fm(void* stream, int rows, int cols, const void* src_fm, int ld_
 int64_t mip360_fm_mask_bytes(int m, int n);
 int mip360_linear_fm(void* stream, int m, int n, int k, const void* a_fm, int lda, const void* w_fm, int ldw,
                      const float* bias, int act, void* c_fm, int ldc, void* mask);
+/* mip360_grad_weight_bf16 (below) with both operands in fm layout; n_in, n_out multiples of 256, m of 32.  Same slab
+ * contract: grad_kernel == NULL leaves the sums to mip360_grad_weight_reduce. */
+int mip360_grad_weight_fm(void* stream, int m, int n_in, int n_out, const void* h_fm, int ldh, const void* dz_fm, int lddz,
+                          int ksplit, float* slabs, float* grad_kernel, int ldg, float scale, float* grad_bias);
 
 /* ---- training side (upstream: jax.value_and_grad + optax, train_utils.py:215-236, 303-370) ---------------------- */
 

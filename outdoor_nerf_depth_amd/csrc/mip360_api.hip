@@ -27,6 +27,8 @@ void mip360_launch_depth_klurf(hipStream_t st, int type, int n, int S, const flo
                                float* g_dm, float* accum);
 int mip360_launch_linear_fm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                             int act, void* C, int ldc, void* mask);
+int mip360_launch_grad_weight_fm(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
+                                 float* slabs, int ldc, float* bias_slabs);
 int mip360_launch_to_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, void* dst, int ld_dst, int col0_dst);
 int mip360_launch_from_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, int col0_src, void* dst, int ld_dst);
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
@@ -238,6 +240,16 @@ int mip360_grad_weight_bf16(void* stream, int m, int n_in, int n_out, const void
   REQUIRE(h && dz && slabs && ldh >= n_in && lddz >= n_out && ldg >= n_out && ldh % 8 == 0 && lddz % 8 == 0, "pointers / leading dimensions");
   mip360_launch_grad_weight((hipStream_t)stream, m, n_in, n_out, h, ldh, dz, lddz, ksplit, slabs, grad_kernel, ldg, scale, grad_bias);
   return check_launch("grad_weight_bf16");
+}
+
+int mip360_grad_weight_fm(void* stream, int m, int n_in, int n_out, const void* h_fm, int ldh, const void* dz_fm, int lddz,
+                          int ksplit, float* slabs, float* grad_kernel, int ldg, float scale, float* grad_bias) {
+  REQUIRE(h_fm && dz_fm && slabs && ksplit >= 1 && ksplit <= 256 && ldh >= n_in && lddz >= n_out && ldg >= n_out, "pointers / leading dimensions");
+  float* bias_slabs = grad_bias ? slabs + (size_t)ksplit * n_in * ldg : nullptr;
+  REQUIRE(mip360_launch_grad_weight_fm((hipStream_t)stream, m, n_in, n_out, h_fm, ldh, dz_fm, lddz, ksplit, slabs, ldg, bias_slabs) == 0,
+          "m a multiple of 32, n_in / n_out multiples of 256, leading dimensions multiples of 16");
+  if (grad_kernel) mip360_launch_grad_weight_reduce((hipStream_t)stream, n_in, n_in, n_out, ksplit, slabs, grad_kernel, ldg, scale, grad_bias);
+  return check_launch("grad_weight_fm");
 }
 
 int mip360_grad_weight_reduce(void* stream, int rows, int n_in, int n_out, int ksplit, const float* slabs, float* grad_kernel, int ldg,

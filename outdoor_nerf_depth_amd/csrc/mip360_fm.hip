@@ -55,10 +55,14 @@ __device__ __forceinline__ uint64_t uniform64(const void* p) {
          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
 }
 
+#ifndef FM_NSLOT
+#define FM_NSLOT 5
+#endif
 struct Cfg {
-  static constexpr int SLOT = 32768, NSLOT = 5, WOFF = 16384, LDS = SLOT * NSLOT;
-  static constexpr int AHEAD = 4;                   // the fragment-read phase of half-step x issues the DMA of x + AHEAD
+  static constexpr int SLOT = 32768, NSLOT = FM_NSLOT, WOFF = 16384, LDS = SLOT * NSLOT;
+  static constexpr int AHEAD = NSLOT - 1;           // the fragment-read phase of half-step x issues the DMA of x + AHEAD
 };
+static_assert(Cfg::AHEAD == 3 || Cfg::AHEAD == 4, "ring depth 4 or 5");
 
 // ACT 0: C = A W^T + b;  1: relu(A W^T + b), bit mask of the non-zero outputs to `mask` (when not null);
 //     2: (A W^T) with the elements whose mask bit is clear set to zero (the dX chain; no bias)
@@ -72,7 +76,7 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   constexpr int SLOT = Cfg::SLOT;
   // VMEM instructions of one epilogue + preload (older than the DMA issued after it): output stores, mask store / load, bias loads
   constexpr int NE = ACT == 0 ? 16 + 2 : ACT == 1 ? 16 + 1 + 2 : 16 + 1;
-  constexpr int VM_STEADY = 3 * 4, VM_PEEL = VM_STEADY + NE;
+  constexpr int AHEAD = Cfg::AHEAD, VM_STEADY = (AHEAD - 1) * 4, VM_PEEL = VM_STEADY + NE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, grp = wm;            // group 0 = waves 0-3 = tile rows 0-127
   const int tiles_n = N >> 8, tiles_m = M >> 8, tiles = tiles_m * tiles_n;
@@ -243,7 +247,8 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
 
   // ---- prologue: half-steps 0 .. AHEAD-1 and the first tile's side data, synchronously
   set_issue_tile(0);
-  issue(); issue(); issue(); issue();
+#pragma unroll
+  for (int x = 0; x < AHEAD; ++x) issue();
   preload(0);
   FM_VMCNT(0);
   asm volatile("" : "+v"(bias_raw[0]), "+v"(bias_raw[1]), "+v"(mw));
@@ -253,7 +258,7 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   //   group 0: [MUL(x), wait] | [read(x + 1), DMA(x + 5)]          group 1: [read(x), DMA(x + 4), wait] | [MUL(x)]
   // "wait" = own DMA of half-step x + 1 has landed (3 younger half-steps of 4 instructions may be out; + NE while the
   // epilogue's instructions are younger than it, i.e. for the first three half-steps of a tile; the first tile's were
-  // awaited by the prologue).  The barrier after it publishes x + 1 to both groups one phase before they read it.
+  // awaited by the prologue; with a 4-slot ring: 2 younger half-steps, two peeled half-steps).  The barrier after it publishes x + 1 to both groups one phase before they read it.
   if (grp == 0) {
     FM_READ(cs); issue(); FM_LGKM0(); cs = next_slot(cs);
     FM_PHASE_END();
@@ -268,8 +273,8 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
       FM_PHASE_END();
       FM_G0_STEP(FM_MUL_FIRST(), VM_PEEL, (void)0);
       FM_G0_STEP(FM_MUL(), VM_PEEL, (void)0);
-      FM_G0_STEP(FM_MUL(), VM_PEEL, (void)0);
-      for (int h = 3; h < nh - 1; ++h) { FM_G0_STEP(FM_MUL(), VM_STEADY, (void)0); }
+      if constexpr (AHEAD == 4) { FM_G0_STEP(FM_MUL(), VM_PEEL, (void)0); }
+      for (int h = AHEAD - 1; h < nh - 1; ++h) { FM_G0_STEP(FM_MUL(), VM_STEADY, (void)0); }
       FM_G0_STEP({ FM_MUL(); bias_mfma(); }, VM_STEADY, { epilogue(t); preload(t + 1); });
     }
   } else {
@@ -283,8 +288,8 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
       FM_PHASE_END();
       FM_G1_STEP(FM_MUL_FIRST(), VM_PEEL);
       FM_G1_STEP(FM_MUL(), VM_PEEL);
-      FM_G1_STEP(FM_MUL(), VM_PEEL);
-      for (int h = 3; h < nh - 1; ++h) { FM_G1_STEP(FM_MUL(), VM_STEADY); }
+      if constexpr (AHEAD == 4) { FM_G1_STEP(FM_MUL(), VM_PEEL); }
+      for (int h = AHEAD - 1; h < nh - 1; ++h) { FM_G1_STEP(FM_MUL(), VM_STEADY); }
       FM_G1_STEP({ FM_MUL(); bias_mfma(); }, VM_STEADY);
       epilogue(t);
       preload(t + 1);
@@ -293,6 +298,183 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   FM_VMCNT(0);
 #undef FM_G0_STEP
 #undef FM_G1_STEP
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradients from fm operands: dK[i][o] = sum_m H[m][i] dZ[m][o] (jax.grad of nn.Dense, flax kernel layout [in, out]).
+// 256 x 256 output tile, 8 waves of 128 (i) x 64 (o), split over row slices into float32 slabs (summed in a fixed order by
+// slab_sum2_kernel).  A chunk = 32 rows of both operands = 2 x 16 blocks, DMA'd as they are (1 KiB per instruction) into a
+// 4-deep ring with the blocks 1152 B apart; the contraction runs over the rows, so the MFMA fragments come from
+// ds_read_b64_tr_b16: a 16-lane group reads the [4 rows x 16 columns] patch of one block -- 8 consecutive units = 128
+// contiguous bytes -- and the neighbouring group (the next block) lands 128 B further in the bank window: conflict-free.
+// Both operands use the same row -> k-slot map.
+constexpr int GBLKP = 1152, GOPER = 16 * GBLKP, GCHUNK = 2 * GOPER, GNBUF = 4;      // 4 x 36 KiB = 144 KiB
+
+__device__ __forceinline__ bf16x8 tr_frag_fm(uint32_t off) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)fm_smem;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + 128));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool PP>
+__global__ __launch_bounds__(512) void grad_weight_fm_kernel(int M, int I, int O, const char* __restrict__ H, int ldh,
+                                                             const char* __restrict__ dZ, int lddz, int ksplit,
+                                                             float* __restrict__ slabs, int ldc, float* __restrict__ bias_slabs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 2, wo = wave & 3;
+  const int tiles_o = O / 256, tiles = (I / 256) * tiles_o;
+  int slice, b;                                         // all tiles of a row slice on one XCD (they share its rows through that L2)
+  if ((ksplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, id = blockIdx.x >> 3, per_xcd = ksplit >> 3;
+    slice = xcd * per_xcd + id / tiles;
+    b = id % tiles;
+  } else {
+    slice = blockIdx.x / tiles;
+    b = blockIdx.x - slice * tiles;
+  }
+  const int ti = b / tiles_o, to = b - ti * tiles_o;
+  const int i0 = ti * 256, o0 = to * 256;
+  const int64_t chunks_total = M / 32;
+  const int64_t per = (chunks_total + ksplit - 1) / ksplit;
+  const int64_t c_begin = (int64_t)slice * per, c_end = c_begin + per < chunks_total ? c_begin + per : chunks_total;
+  const int nchunk = c_end > c_begin ? (int)(c_end - c_begin) : 0;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)fm_smem;
+  const uint32_t voff = (uint32_t)lane * 16u;
+  const size_t h_rb = (size_t)(ldh >> 4) * 1024, z_rb = (size_t)(lddz >> 4) * 1024;
+  const char* gh = H + (size_t)(i0 >> 4) * 1024;
+  const char* gz = dZ + (size_t)(o0 >> 4) * 1024;
+  auto issue = [&](int c, int slot) {
+    const size_t mb = (size_t)(c_begin + c);
+    const uint32_t buf = lds_base + (uint32_t)slot * GCHUNK;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int id = x * 8 + wave, op = id >> 4, blk = id & 15;
+      const char* src = op == 0 ? gh + mb * h_rb + (size_t)blk * 1024 : gz + mb * z_rb + (size_t)blk * 1024;
+      glds16(src, voff, buf + op * GOPER + blk * GBLKP);
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  const bool do_bias = bias_slabs != nullptr && ti == 0 && wi == 0;
+  float bsum[2] = {0.f, 0.f};
+  // transposed-read lane map: 16-lane group g: block (g & 1) of the 32-column MFMA block, k half g >> 1 (8 rows); a16: row
+  // a16 >> 2 of the 4 a read covers, column quad q = a16 & 3 -> unit half hi = q & 1, byte half q >> 1.  Unit of (row, hi) =
+  // 8 (row >> 2) + 4 (hi ^ (row >> 4)) + (row & 3) with row = 16 kk + 8 (g >> 1) + (a16 >> 2) (+ 4: second read, + 128 B)
+  const int g = lane >> 4, a16 = lane & 15;
+  uint32_t lane_off[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+    lane_off[kk] = (uint32_t)((g & 1) * GBLKP + kk * 512 + (g >> 1) * 256 + 64 * ((a16 & 1) ^ kk) + 16 * (a16 >> 2) + 8 * ((a16 >> 1) & 1));
+  auto read_frags = [&](uint32_t buf, bf16x8 (&fh)[2][4], bf16x8 (&fz)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) fh[kk][x] = tr_frag_fm(buf + lane_off[kk] + 2 * (4 * wi + x) * GBLKP);
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fz[kk][y] = tr_frag_fm(buf + GOPER + lane_off[kk] + 2 * (2 * wo + y) * GBLKP);
+    }
+  };
+  auto multiply = [&](const bf16x8 (&fh)[2][4], const bf16x8 (&fz)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kk][x], fz[kk][y], acc[x][y], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[y] += (float)fz[kk][y][e];
+      }
+    }
+  };
+  if constexpr (PP) {
+  // Two wave groups half a chunk apart (one multiplies while the other reads fragments and issues DMA), as in
+  // linear_fm_kernel:   group 0: [MUL(x), wait] | [read(x + 1), DMA(x + 4)]     group 1: [read(x), DMA(x + 3), wait] | [MUL(x)]
+  // wait = own DMA of chunk x + 1 has landed (2 younger chunks of 4 instructions may be out); chunks past the end of the
+  // slice are re-loads of its last chunk into free slots (uniform counts).
+  constexpr int AHEAD = GNBUF - 1;
+  int ic = 0;
+  auto issue_next = [&]() { issue(ic < nchunk ? ic : nchunk - 1, ic % GNBUF); ++ic; };
+  if (nchunk > 0) {
+#pragma unroll
+    for (int c = 0; c < AHEAD; ++c) issue_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FM_PHASE_END();
+    bf16x8 fh[2][4], fz[2][2];
+    if (wi == 0) {
+      read_frags(0u, fh, fz);
+      issue_next();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      FM_PHASE_END();
+      for (int c = 0; c < nchunk; ++c) {
+        multiply(fh, fz);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * 4) : "memory");
+        FM_PHASE_END();
+        read_frags((uint32_t)((c + 1) % GNBUF) * GCHUNK, fh, fz);
+        issue_next();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FM_PHASE_END();
+      }
+    } else {
+      FM_PHASE_END();
+      for (int c = 0; c < nchunk; ++c) {
+        read_frags((uint32_t)(c % GNBUF) * GCHUNK, fh, fz);
+        issue_next();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * 4) : "memory");
+        FM_PHASE_END();
+        multiply(fh, fz);
+        FM_PHASE_END();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  } else {                                          // lock-step: short slices (the ping-pong prologue is synchronous)
+#pragma unroll
+  for (int c = 0; c < GNBUF - 1; ++c) if (c < nchunk) issue(c, c % GNBUF);
+  for (int c = 0; c < nchunk; ++c) {
+    const int younger = nchunk - 1 - c < GNBUF - 2 ? nchunk - 1 - c : GNBUF - 2;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c + GNBUF - 1 < nchunk) issue(c + GNBUF - 1, (c + GNBUF - 1) % GNBUF);
+    bf16x8 fh[2][4], fz[2][2];
+    read_frags((uint32_t)(c % GNBUF) * GCHUNK, fh, fz);
+    multiply(fh, fz);
+  }
+  }
+  float* slab = slabs + (size_t)slice * I * ldc;
+  const int hi = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    const int o = o0 + wo * 64 + y * 32 + j;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * 128 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        slab[(size_t)i * ldc + o] = acc[x][y][r];
+      }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const float tot = bsum[y] + __shfl_xor(bsum[y], 32, 64);
+      const int o = o0 + wo * 64 + y * 32 + j;
+      if (hi == 0) bias_slabs[(size_t)slice * O + o] = tot;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -372,5 +554,26 @@ int mip360_launch_from_fm(hipStream_t st, int rows, int cols, const void* src, i
   const int64_t units = (int64_t)(rows / 32) * (cols / 16) * 64;
   hipLaunchKernelGGL(mip360fm::from_fm_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, rows, cols, (const char*)src, ld_src,
                      col0_src, (uint16_t*)dst, ld_dst);
+  return 0;
+}
+
+// slabs: ksplit x [I, ldc] floats (+ ksplit x O bias slabs when bias_slabs != null); I, O multiples of 256, M of 32
+int mip360_launch_grad_weight_fm(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
+                                 float* slabs, int ldc, float* bias_slabs) {
+  using namespace mip360fm;
+  if (M <= 0 || M % 32 || I <= 0 || O <= 0 || I % 256 || O % 256 || ldh % 16 || lddz % 16 || ksplit < 1) return 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)grad_weight_fm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GNBUF * GCHUNK);
+    (void)hipFuncSetAttribute((const void*)grad_weight_fm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GNBUF * GCHUNK);
+    attr_set = true;
+  }
+  const dim3 grid((I / 256) * (O / 256) * ksplit);
+  if (M / 32 / ksplit >= 96)                       // measured: ping-pong wins from ~100 chunks per slice (131072 rows / 16: -8 %), loses below (32 chunks: +10 %)
+    hipLaunchKernelGGL(grad_weight_fm_kernel<true>, grid, dim3(512), GNBUF * GCHUNK, st, M, I, O, (const char*)H, ldh, (const char*)dZ, lddz, ksplit,
+                       slabs, ldc, bias_slabs);
+  else
+    hipLaunchKernelGGL(grad_weight_fm_kernel<false>, grid, dim3(512), GNBUF * GCHUNK, st, M, I, O, (const char*)H, ldh, (const char*)dZ, lddz, ksplit,
+                       slabs, ldc, bias_slabs);
   return 0;
 }

@@ -48,6 +48,8 @@ SYMBOLS = {
     'mip360_from_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int]),
     'mip360_fm_mask_bytes': (C.c_int64, [C.c_int, C.c_int]),
     'mip360_linear_fm': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
+    'mip360_grad_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
+                                        C.c_float, _fp]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                           C.c_float, _fp]),

@@ -103,5 +103,54 @@ def main():
         print('%7d x %4d x %4d : ' % (m, n, k) + '  '.join('%s %.0f us (%.0f TF/s)' % (key, v, fl / v / 1e6) for key, v in res.items()))
 
 
-if __name__ == '__main__':
+
+
+def check_dw(m, n_in, n_out, ksplit, seed=0, time_it=False, reps=10):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    h = torch.randn(m, n_in, device=dev, generator=g).to(torch.bfloat16)
+    dz = torch.randn(m, n_out, device=dev, generator=g).to(torch.bfloat16)
+    h_fm, dz_fm = to_fm(h), to_fm(dz)
+    slabs = torch.empty(ksplit * (n_in * n_out + n_out), device=dev)
+    out, bias = torch.empty(n_in, n_out, device=dev), torch.empty(n_out, device=dev)
+    M._check(L.mip360_grad_weight_fm(st(), m, n_in, n_out, p(h_fm), n_in, p(dz_fm), n_out, ksplit, p(slabs), p(out), n_out, 1.0, p(bias)),
+             'grad_weight_fm')
+    rows = min(m, 16384)
+    if rows == m:
+        ref = h.float().t() @ dz.float()
+        err = ((out - ref).abs().max() / ref.abs().max()).item()
+        eb = ((bias - dz.float().sum(0)).abs().max() / dz.float().sum(0).abs().max()).item()
+    else:                                                       # against the row-major kernel
+        out2, bias2 = torch.empty_like(out), torch.empty_like(bias)
+        M._check(L.mip360_grad_weight_bf16(st(), m, n_in, n_out, p(h), n_in, p(dz), n_out, ksplit, p(slabs), p(out2), n_out, 1.0, p(bias2)),
+                 'grad_weight_bf16')
+        err = ((out - out2).abs().max() / out2.abs().max()).item()
+        eb = ((bias - bias2).abs().max() / bias2.abs().max()).item()
+    line = 'dW check %6d x %4d x %4d ksplit %3d : rel err kernel %.2e bias %.2e' % (m, n_in, n_out, ksplit, err, eb)
+    if time_it:
+        t_fm = timeit(lambda: L.mip360_grad_weight_fm(st(), m, n_in, n_out, p(h_fm), n_in, p(dz_fm), n_out, ksplit, p(slabs), None, n_out, 1.0,
+                                                      p(bias)), reps)
+        t_rm = timeit(lambda: L.mip360_grad_weight_bf16(st(), m, n_in, n_out, p(h), n_in, p(dz), n_out, ksplit, p(slabs), None, n_out, 1.0,
+                                                        p(bias)), reps)
+        fl = 2.0 * m * n_in * n_out
+        line += '   fm %.0f us (%.0f TF/s)  rm %.0f us (%.0f TF/s)' % (t_fm, fl / t_fm / 1e6, t_rm, fl / t_rm / 1e6)
+    print(line)
+    assert err < 2e-3 and eb < 2e-3, (err, eb)
+
+
+def main_dw():
+    check_dw(256, 256, 256, 1)
+    check_dw(4096, 512, 256, 8)
+    check_dw(8192, 1024, 1024, 16, seed=1)
+    check_dw(131072, 1024, 1024, 16, time_it=True)
+    check_dw(131072, 1536, 1024, 8, time_it=True)
+    check_dw(131072, 512, 1024, 32, time_it=True)
+    check_dw(131072, 1024, 256, 64, time_it=True)
+    check_dw(262144, 256, 256, 256, time_it=True)
+    check_dw(262144, 512, 256, 128, time_it=True)
+
+
+if __name__ == '__main__' and '--dw' in sys.argv:
+    main_dw()
+
+if __name__ == '__main__' and '--dw' not in sys.argv:
     main()
