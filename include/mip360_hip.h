@@ -165,6 +165,13 @@ int mip360_from_fm(void* stream, int rows, int cols, const void* src_fm, int ld_
 int64_t mip360_fm_mask_bytes(int m, int n);
 int mip360_linear_fm(void* stream, int m, int n, int k, const void* a_fm, int lda, const void* w_fm, int ldw,
                      const float* bias, int act, void* c_fm, int ldc, void* mask);
+/* One output column (the density head): out[m * ldo] = act(A[m, :k] . w + bias[0]); A fm, w bf16 [k]; act 0 / 1 (ReLU) /
+ * 2 (softplus(x + act_param)).  mip360_grad_weight_col_fm: d kernel[i] = scale * sum_m H[m][i] z[m], z = column zcol of
+ * the fm tensor dz; slabs >= ksplit * (n_in + 1) floats; grad_bias = scale * sum_m z[m]. */
+int mip360_rowdot_fm(void* stream, int m, int k, const void* a_fm, int lda, const void* w_bf16, const float* bias, int act,
+                     float act_param, float* out, int ldo);
+int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,
+                              int ksplit, float* slabs, float* grad_kernel, float scale, float* grad_bias);
 /* mip360_grad_weight_bf16 (below) with both operands in fm layout; n_in, n_out multiples of 256, m of 32.  Same slab
  * contract: grad_kernel == NULL leaves the sums to mip360_grad_weight_reduce. */
 int mip360_grad_weight_fm(void* stream, int m, int n_in, int n_out, const void* h_fm, int ldh, const void* dz_fm, int lddz,

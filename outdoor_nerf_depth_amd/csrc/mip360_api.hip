@@ -29,6 +29,10 @@ int mip360_launch_linear_fm(hipStream_t st, int M, int N, int K, const void* A, 
                             int act, void* C, int ldc, void* mask);
 int mip360_launch_grad_weight_fm(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
                                  float* slabs, int ldc, float* bias_slabs);
+int mip360_launch_rowdot_fm(hipStream_t st, int M, int K, const void* A, int lda, const void* w, const float* bias, int act, float act_param,
+                            float* out, int ldo);
+int mip360_launch_grad_weight_col_fm(hipStream_t st, int M, int I, const void* H, int ldh, const void* dZ, int lddz, int zcol, int ksplit,
+                                     float* slabs, int ldc, float* bias_slabs);
 int mip360_launch_to_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, void* dst, int ld_dst, int col0_dst);
 int mip360_launch_from_fm(hipStream_t st, int rows, int cols, const void* src, int ld_src, int col0_src, void* dst, int ld_dst);
 void mip360_launch_linear(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
@@ -89,6 +93,7 @@ int mip360_cast_encode(void* stream, int n_rays, int n_samples, const float* tdi
                        const float* directions, const float* radii, const float* basis_t, void* enc, int out_bf16, int ld) {
   REQUIRE(n_rays > 0 && n_samples >= 1 && ld >= MIP360_IPE_DIM, "sizes, ld >= 504");
   REQUIRE(tdist && origins && directions && radii && basis_t && enc, "non-null pointers");
+  REQUIRE(out_bf16 != 2 || (ld % 16 == 0 && ld >= 512 && ((int64_t)n_rays * n_samples) % 32 == 0), "fm output: ld % 16 == 0, rows % 32 == 0");
   mip360_launch_cast_encode((hipStream_t)stream, n_rays, n_samples, tdist, origins, directions, radii, basis_t, enc,
                             out_bf16, ld);
   return check_launch("cast_encode");
@@ -250,6 +255,24 @@ int mip360_grad_weight_fm(void* stream, int m, int n_in, int n_out, const void* 
           "m a multiple of 32, n_in / n_out multiples of 256, leading dimensions multiples of 16");
   if (grad_kernel) mip360_launch_grad_weight_reduce((hipStream_t)stream, n_in, n_in, n_out, ksplit, slabs, grad_kernel, ldg, scale, grad_bias);
   return check_launch("grad_weight_fm");
+}
+
+int mip360_rowdot_fm(void* stream, int m, int k, const void* a_fm, int lda, const void* w_bf16, const float* bias, int act,
+                     float act_param, float* out, int ldo) {
+  REQUIRE(a_fm && w_bf16 && out && lda >= k && ldo >= 1, "pointers / leading dimensions");
+  REQUIRE(mip360_launch_rowdot_fm((hipStream_t)stream, m, k, a_fm, lda, w_bf16, bias, act, act_param, out, ldo) == 0,
+          "m a multiple of 32, k / lda multiples of 16, act in 0..2");
+  return check_launch("rowdot_fm");
+}
+
+int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,
+                              int ksplit, float* slabs, float* grad_kernel, float scale, float* grad_bias) {
+  REQUIRE(h_fm && dz_fm && slabs && ksplit >= 1 && ksplit <= 256 && ldh >= n_in, "pointers / leading dimensions");
+  float* bias_slabs = grad_bias ? slabs + (size_t)ksplit * n_in : nullptr;
+  REQUIRE(mip360_launch_grad_weight_col_fm((hipStream_t)stream, m, n_in, h_fm, ldh, dz_fm, lddz, zcol, ksplit, slabs, 1, bias_slabs) == 0,
+          "m a multiple of 32, n_in and leading dimensions multiples of 16, 0 <= zcol < lddz");
+  if (grad_kernel) mip360_launch_grad_weight_reduce((hipStream_t)stream, n_in, n_in, 1, ksplit, slabs, grad_kernel, 1, scale, grad_bias);
+  return check_launch("grad_weight_col_fm");
 }
 
 int mip360_grad_weight_reduce(void* stream, int rows, int n_in, int n_out, int ksplit, const float* slabs, float* grad_kernel, int ldg,

@@ -478,6 +478,107 @@ __global__ __launch_bounds__(512) void grad_weight_fm_kernel(int M, int I, int O
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// One output column from an fm operand (the density head, models.py:497 raw_density = Dense(1)(x)): a wave streams the
+// K / 16 blocks of a 32-row block (1 KiB per load, lane = unit); the two units of a row sit 4 lanes apart.
+__device__ __forceinline__ void unit_to_row_hi(int u, int& row, int& hi) {
+  row = ((u >> 3) << 2) | (u & 3);
+  hi = ((u >> 2) & 1) ^ (row >> 4);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void rowdot_fm_kernel(int M, int K, const char* __restrict__ A, int lda, const uint16_t* __restrict__ w,
+                                                        const float* __restrict__ bias, float act_param, float* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63, rb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rb * 32 >= M) return;
+  int row, hi;
+  unit_to_row_hi(lane, row, hi);
+  const char* a = A + (size_t)rb * (size_t)(lda >> 4) * 1024 + lane * 16;
+  const uint16_t* wl = w + 4 * hi;
+  float acc = 0.f;
+  const int nb = K >> 4;
+  auto dot8 = [&](const uint4 x, const uint2 w0, const uint2 w1) {
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w0.x, w0.y, w1.x, w1.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc += __builtin_bit_cast(float, xs[q] << 16) * __builtin_bit_cast(float, ws[q] << 16);
+      acc += __builtin_bit_cast(float, xs[q] & 0xFFFF0000u) * __builtin_bit_cast(float, ws[q] & 0xFFFF0000u);
+    }
+  };
+  int cb = 0;
+  for (; cb + 8 <= nb; cb += 8) {
+    uint4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = *(const uint4*)(a + (size_t)(cb + u) * 1024);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dot8(x[u], *(const uint2*)(wl + (cb + u) * 16), *(const uint2*)(wl + (cb + u) * 16 + 8));
+  }
+  for (; cb < nb; ++cb) dot8(*(const uint4*)(a + (size_t)cb * 1024), *(const uint2*)(wl + cb * 16), *(const uint2*)(wl + cb * 16 + 8));
+  acc += __shfl_xor(acc, 4, 64);
+  if (hi == 0) {
+    float v = acc + (bias ? bias[0] : 0.f);
+    if (ACT == 1) v = fmaxf(v, 0.f);
+    if (ACT == 2) { const float x = v + act_param; v = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+    out[(size_t)(rb * 32 + row) * ldo] = v;
+  }
+}
+
+// d kernel[i] = sum_m H[m][i] z[m] for a one-column dZ (column zcol of an fm tensor): wave = (row slice, 16-column block of H),
+// lane = unit, float32 accumulation over the slice's row blocks, then a butterfly over the 32 rows.  Slabs as the MFMA
+// kernels write them (slabs[slice][i * ldc], bias slabs [slice] = sum_m z[m]).
+__global__ __launch_bounds__(256) void grad_weight_col_fm_kernel(int M, int I, const char* __restrict__ H, int ldh, const char* __restrict__ dZ,
+                                                                 int lddz, int zcol, int ksplit, float* __restrict__ slabs, int ldc,
+                                                                 float* __restrict__ bias_slabs) {
+  const int lane = threadIdx.x & 63, nb = I >> 4;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int slice = wid / nb, cb = wid - slice * nb;
+  if (slice >= ksplit) return;
+  int row, hi;
+  unit_to_row_hi(lane, row, hi);
+  const int64_t rbs = M / 32, per = (rbs + ksplit - 1) / ksplit;
+  const int64_t b0 = (int64_t)slice * per, b1 = b0 + per < rbs ? b0 + per : rbs;
+  const size_t h_rb = (size_t)(ldh >> 4) * 1024, z_rb = (size_t)(lddz >> 4) * 1024;
+  const int zf = zcol & 15;
+  const char* hp = H + (size_t)cb * 1024 + lane * 16;
+  const char* zp = dZ + (size_t)(zcol >> 4) * 1024 + unit_of(row, (zf >> 2) & 1) * 16 + 2 * (4 * (zf >> 3) + (zf & 3));
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, zsum = 0.f;
+  auto fma8 = [&](const uint4 x, const uint16_t zr) {
+    const float z = __builtin_bit_cast(float, (uint32_t)zr << 16);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[2 * q] += __builtin_bit_cast(float, xs[q] << 16) * z;
+      acc[2 * q + 1] += __builtin_bit_cast(float, xs[q] & 0xFFFF0000u) * z;
+    }
+    zsum += z;
+  };
+  int64_t b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    uint4 x[8];
+    uint16_t z[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { x[u] = *(const uint4*)(hp + (size_t)(b + u) * h_rb); z[u] = *(const uint16_t*)(zp + (size_t)(b + u) * z_rb); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fma8(x[u], z[u]);
+  }
+  for (; b < b1; ++b) fma8(*(const uint4*)(hp + (size_t)b * h_rb), *(const uint16_t*)(zp + (size_t)b * z_rb));
+  // sum over the 32 rows of equal hi: row bits 0, 1 = unit bits 0, 1; row bits 2, 3 = unit bits 3, 4; row bit 4 = unit bits 5 and 2
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = acc[e];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 36, 64);
+    acc[e] = v;
+  }
+  zsum += __shfl_xor(zsum, 1, 64); zsum += __shfl_xor(zsum, 2, 64); zsum += __shfl_xor(zsum, 8, 64); zsum += __shfl_xor(zsum, 16, 64);
+  zsum += __shfl_xor(zsum, 36, 64);
+  if (row == 0) {
+    float* slab = slabs + (size_t)slice * I * ldc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) slab[(size_t)(cb * 16 + 4 * hi + 8 * (e >> 2) + (e & 3)) * ldc] = acc[e];
+    if (bias_slabs && cb == 0 && hi == 0) bias_slabs[slice] = zsum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // row-major <-> fragment-major (bf16): one thread per 16-byte unit
 __global__ __launch_bounds__(256) void to_fm_kernel(int rows, int cols, const uint16_t* __restrict__ src, int ld_src, char* __restrict__ dst,
                                                     int ld_dst, int col0_dst) {
@@ -575,5 +676,26 @@ int mip360_launch_grad_weight_fm(hipStream_t st, int M, int I, int O, const void
   else
     hipLaunchKernelGGL(grad_weight_fm_kernel<false>, grid, dim3(512), GNBUF * GCHUNK, st, M, I, O, (const char*)H, ldh, (const char*)dZ, lddz, ksplit,
                        slabs, ldc, bias_slabs);
+  return 0;
+}
+
+int mip360_launch_rowdot_fm(hipStream_t st, int M, int K, const void* A, int lda, const void* w, const float* bias, int act, float act_param,
+                            float* out, int ldo) {
+  using namespace mip360fm;
+  if (M <= 0 || M % 32 || K <= 0 || K % 16 || lda % 16 || act < 0 || act > 2) return 1;
+  const dim3 grid((M / 32 + 3) / 4), block(256);
+  if (act == 2) hipLaunchKernelGGL(rowdot_fm_kernel<2>, grid, block, 0, st, M, K, (const char*)A, lda, (const uint16_t*)w, bias, act_param, out, ldo);
+  else if (act == 1) hipLaunchKernelGGL(rowdot_fm_kernel<1>, grid, block, 0, st, M, K, (const char*)A, lda, (const uint16_t*)w, bias, act_param, out, ldo);
+  else hipLaunchKernelGGL(rowdot_fm_kernel<0>, grid, block, 0, st, M, K, (const char*)A, lda, (const uint16_t*)w, bias, act_param, out, ldo);
+  return 0;
+}
+
+int mip360_launch_grad_weight_col_fm(hipStream_t st, int M, int I, const void* H, int ldh, const void* dZ, int lddz, int zcol, int ksplit,
+                                     float* slabs, int ldc, float* bias_slabs) {
+  using namespace mip360fm;
+  if (M <= 0 || M % 32 || I <= 0 || I % 16 || ldh % 16 || lddz % 16 || zcol < 0 || zcol >= lddz || ksplit < 1) return 1;
+  const int waves = (I / 16) * ksplit;
+  hipLaunchKernelGGL(grad_weight_col_fm_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, M, I, (const char*)H, ldh, (const char*)dZ, lddz, zcol,
+                     ksplit, slabs, ldc, bias_slabs);
   return 0;
 }

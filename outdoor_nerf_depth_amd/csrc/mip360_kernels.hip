@@ -237,18 +237,23 @@ __device__ __forceinline__ float safe_sin_fast(float x) {
   return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
 }
 
-template <bool BF16>
-__global__ __launch_bounds__(256) void cast_encode_kernel(
+// MODE 0: float32 rows, 1: bf16 rows (row-major), 2: bf16 in the fragment-major layout of mip360_fm.hip -- a workgroup of
+// 704 threads owns one 32-row block (thread t: row t / 21, basis t % 21), assembles its 32 blocks of 1 KiB in LDS and writes
+// them out whole (enc = the tensor's base + the block offset of its first column, ld = the tensor's columns)
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 704 : 256) void cast_encode_kernel(
     int n, int S, const float* __restrict__ tdist, const float* __restrict__ origins,
     const float* __restrict__ directions, const float* __restrict__ radii, const float* __restrict__ basis_t,
     void* __restrict__ enc, int ld) {
+  constexpr bool BF16 = MODE != 0, FM = MODE == 2;
   const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  const int sub = lane / MIP360_N_BASIS, j = lane - sub * MIP360_N_BASIS;
-  const int64_t row_raw = (int64_t)wave_g * 3 + sub;
+  const int sub = FM ? (int)threadIdx.x / MIP360_N_BASIS : lane / MIP360_N_BASIS;
+  const int j = FM ? (int)threadIdx.x - sub * MIP360_N_BASIS : lane - sub * MIP360_N_BASIS;
+  const int64_t row_raw = FM ? (int64_t)blockIdx.x * 32 + sub : (int64_t)wave_g * 3 + sub;
   const int64_t rows = (int64_t)n * S;
-  const bool live = sub < 3 && row_raw < rows;
+  const bool live = (FM ? sub < 32 : sub < 3) && row_raw < rows;
   const int64_t row = live ? row_raw : rows - 1;                 // idle lanes compute a valid row and store nothing
-  if ((int64_t)wave_g * 3 >= rows) return;
+  if (!FM && (int64_t)wave_g * 3 >= rows) return;
   const int ray = (int)(row / S), smp = (int)(row - (int64_t)ray * S);
   const float t0 = tdist[(size_t)ray * (S + 1) + smp], t1 = tdist[(size_t)ray * (S + 1) + smp + 1];
   const float d[3] = {directions[ray * 3], directions[ray * 3 + 1], directions[ray * 3 + 2]};
@@ -310,9 +315,14 @@ __global__ __launch_bounds__(256) void cast_encode_kernel(
   // bf16 rows feeding a GEMM (ld >= 512 columns, 16-byte aligned): the 21-lane pieces of a row are 42-byte runs of
   // 2-byte stores, so the wave's 3 rows (1 KiB each incl. the zero padding 504..511) are assembled in LDS and leave
   // as 16 bytes per lane (3 wave-stores instead of 24 partial ones)
-  __shared__ __attribute__((aligned(16))) __bf16 rows_lds[4][3][MIP360_IPE_LD];
-  const bool staged = BF16 && ld >= MIP360_IPE_LD && (ld & 7) == 0 && (((uintptr_t)enc) & 15) == 0;
+  __shared__ __attribute__((aligned(16))) __bf16 rows_lds[FM ? 8 : 4][FM ? 4 : 3][MIP360_IPE_LD];   // (FM: 32 blocks x 1 KiB x ... = 32 KiB, used flat)
+  const bool staged = !FM && BF16 && ld >= MIP360_IPE_LD && (ld & 7) == 0 && (((uintptr_t)enc) & 15) == 0;
   const int wave_l = threadIdx.x >> 6;
+  // FM: element (r, col) of the row block -> block col / 16, unit 8 (r >> 2) + 4 (hi ^ (r >> 4)) + (r & 3), element t
+  auto fm_at = [&](int r, int col) -> __bf16* {
+    const int f = col & 15, hi = (f >> 2) & 1, t = 4 * (f >> 3) + (f & 3);
+    return &rows_lds[0][0][0] + (col >> 4) * 512 + (8 * (r >> 2) + 4 * (hi ^ (r >> 4)) + (r & 3)) * 8 + t;
+  };
 #pragma unroll
   for (int k = 0; k < ND; ++k) {
     const float sc = (float)(1 << k);
@@ -321,7 +331,10 @@ __global__ __launch_bounds__(256) void cast_encode_kernel(
     const float es = !live ? 0.f : damp * (BF16 ? safe_sin_fast(sm) : safe_sin(sm));
     const float ec = !live ? 0.f : damp * (BF16 ? safe_sin_fast(sm + 1.5707963267948966f) : safe_sin(sm + 1.5707963267948966f));
     if (!live) continue;
-    if (staged) {
+    if (FM) {
+      *fm_at(sub, k * MIP360_N_BASIS + j) = (__bf16)es;
+      *fm_at(sub, HALF + k * MIP360_N_BASIS + j) = (__bf16)ec;
+    } else if (staged) {
       rows_lds[wave_l][sub][k * MIP360_N_BASIS + j] = (__bf16)es;
       rows_lds[wave_l][sub][HALF + k * MIP360_N_BASIS + j] = (__bf16)ec;
     } else if (BF16) {
@@ -333,6 +346,14 @@ __global__ __launch_bounds__(256) void cast_encode_kernel(
       e[k * MIP360_N_BASIS + j] = es;
       e[HALF + k * MIP360_N_BASIS + j] = ec;
     }
+  }
+  if (FM) {
+    if (live && j < MIP360_IPE_LD - 2 * HALF) *fm_at(sub, 2 * HALF + j) = (__bf16)0.f;
+    __syncthreads();
+    char* dst = (char*)enc + (size_t)blockIdx.x * (size_t)(ld >> 4) * 1024;
+    const char* src = (const char*)&rows_lds[0][0][0];
+    for (int u = threadIdx.x; u < 32 * 64; u += 704) *(uint4*)(dst + (size_t)u * 16) = *(const uint4*)(src + (size_t)u * 16);
+    return;
   }
   if (staged) {
     if (live && j < MIP360_IPE_LD - 2 * HALF) rows_lds[wave_l][sub][2 * HALF + j] = (__bf16)0.f;
@@ -728,8 +749,9 @@ void mip360_launch_cast_encode(hipStream_t st, int n, int S, const float* td, co
   const int64_t rows = (int64_t)n * S;
   const int64_t waves = (rows + 2) / 3;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (bf16) hipLaunchKernelGGL(cast_encode_kernel<true>, dim3(grid), dim3(256), 0, st, n, S, td, o, d, radii, basis_t, enc, ld);
-  else hipLaunchKernelGGL(cast_encode_kernel<false>, dim3(grid), dim3(256), 0, st, n, S, td, o, d, radii, basis_t, enc, ld);
+  if (bf16 == 2) hipLaunchKernelGGL(cast_encode_kernel<2>, dim3((unsigned)(((int64_t)n * S + 31) / 32)), dim3(704), 0, st, n, S, td, o, d, radii, basis_t, enc, ld);
+  else if (bf16) hipLaunchKernelGGL(cast_encode_kernel<1>, dim3(grid), dim3(256), 0, st, n, S, td, o, d, radii, basis_t, enc, ld);
+  else hipLaunchKernelGGL(cast_encode_kernel<0>, dim3(grid), dim3(256), 0, st, n, S, td, o, d, radii, basis_t, enc, ld);
 }
 void mip360_launch_render(hipStream_t st, int n, int S, const float* density, const float* rgbs, const float* td,
                           const float* dirs, int opaque, float bg, float* w, float* rgb, float* acc, float* dm, float* depth) {

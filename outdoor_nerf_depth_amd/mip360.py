@@ -50,6 +50,8 @@ SYMBOLS = {
     'mip360_linear_fm': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
     'mip360_grad_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                         C.c_float, _fp]),
+    'mip360_rowdot_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_float, _fp, C.c_int]),
+    'mip360_grad_weight_col_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                           C.c_float, _fp]),
@@ -155,6 +157,16 @@ def cast_encode(tdist, origins, directions, radii, basis_t, out=None, bf16=True,
     return out
 
 
+def cast_encode_fm(tdist, origins, directions, radii, basis_t, out, col0, ld):
+    """cast_encode straight into columns [col0, col0 + 512) of the fm tensor `out` (ld columns)"""
+    tdist = _f32(tdist)
+    n, S = tdist.shape[0], tdist.shape[1] - 1
+    _check(lib().mip360_cast_encode(_stream(), n, S, _p(tdist), _p(_f32(origins)), _p(_f32(directions)),
+                                    _p(_f32(radii).reshape(-1)), _p(basis_t), C.c_void_p(out.data_ptr() + (col0 // 16) * 1024), 2, ld),
+           'mip360_cast_encode')
+    return out
+
+
 def linear(a, w, bias, act=0, act_param=0.0, out_bf16=None, out_f32=None, m=None, n=None, k=None, aux=None):
     """act(A W^T + b): a [M, lda] bf16 (k leading columns used), w [N, ldw] bf16.  act 4: multiply by (aux > 0)."""
     m = a.shape[0] if m is None else m
@@ -190,6 +202,53 @@ def linear_masked(a, w, out_bf16, mask, ldmask, m=None, n=None, k=None):
     ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
     _check(lib().mip360_linear_masked_bf16(_stream(), m, n, k, _p(a), ld(a), _p(w), ld(w), _p(out_bf16), ld(out_bf16), _p(mask),
                                            int(ldmask)), 'mip360_linear_masked_bf16')
+
+
+# ---- fragment-major ("fm") activations of the wide layers (include/mip360_hip.h, csrc/mip360_fm.hip) ------------------
+# MIP360_NO_FM=1 keeps every layer on the row-major kernels (A/B runs); shapes the fm kernels do not take fall back too.
+USE_FM = os.environ.get('MIP360_NO_FM') is None
+
+
+def fm_ok(rows, width):
+    return USE_FM and rows % 256 == 0 and width % 256 == 0
+
+
+def _fm_ptr(buf, col0=0):
+    """column col0 (a multiple of 16) of an fm tensor: its blocks follow the row block's earlier columns"""
+    return C.c_void_p(buf.data_ptr() + (col0 // 16) * 1024)
+
+
+def fm_buffer(rows, ld, device):
+    return torch.empty(rows * ld, dtype=torch.bfloat16, device=device)
+
+
+def to_fm(x, out=None, ld=None, col0=0, rows=None, cols=None):
+    """row-major bf16 [rows, cols] -> columns [col0, col0 + cols) of an fm tensor with ld columns"""
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    ld = cols if ld is None else ld
+    if out is None:
+        out = fm_buffer(rows, ld, x.device)
+    _check(lib().mip360_to_fm(_stream(), rows, cols, _p(x), x.stride(0), _p(out), ld, col0), 'mip360_to_fm')
+    return out
+
+
+def from_fm(buf, rows, cols, ld=None, col0=0, out=None):
+    ld = cols if ld is None else ld
+    if out is None:
+        out = torch.empty(rows, cols, dtype=torch.bfloat16, device=buf.device)
+    _check(lib().mip360_from_fm(_stream(), rows, cols, _p(buf), ld, col0, _p(out), out.stride(0)), 'mip360_from_fm')
+    return out
+
+
+def fm_mask_buffer(m, n, device):
+    return torch.empty(lib().mip360_fm_mask_bytes(int(m), int(n)), dtype=torch.uint8, device=device)
+
+
+def linear_fm(a, w, bias, act, m, n, k, out, mask, lda=None, ldw=None, ldc=None, a_col0=0, out_col0=0):
+    """act 0: A W^T + b; 1: relu(.) and the bit mask; 2: (A W^T) masked -- all operands fm."""
+    _check(lib().mip360_linear_fm(_stream(), m, n, k, _fm_ptr(a, a_col0), lda or k, _p(w), ldw or k, _p(bias), int(act),
+                                  _fm_ptr(out, out_col0), ldc or n, _p(mask)), 'mip360_linear_fm')
 
 
 def render_level(density, rgb_samples, tdist, directions, opaque_background=True, bg_rgb=1.0):
@@ -449,11 +508,23 @@ class TrainableMLP(object):
         self.wb = {}                                                                         # backward operands
         for t in range(1, D):
             self.wb[t] = bf(self.in_pad[t], W)
-        self.head_k = (BOTTLENECK + 64) if not cfg['disable_rgb'] else 64        # a multiple of 64: the persistent ping-pong GEMM
+        # a multiple of 64 (the persistent row-major GEMM); the fm GEMM needs K >= 128
+        self.head_k = (BOTTLENECK + 64) if not cfg['disable_rgb'] else (128 if USE_FM else 64)
         self.wb['heads'] = bf(W, self.head_k)                    # [K_bottleneck | K_density | 0], or [K_density | 0]
         if not cfg['disable_rgb']:
             self.wb[D + 2] = bf(BOTTLENECK + DIR_LD, VIEW_WIDTH)
             self.wb[D + 3] = bf(VIEW_WIDTH, 32)
+        # fm copies of the wide layers' operands: forward [W, in_pad], backward [W (first W inputs), W], heads [W, head_k],
+        # and the bottleneck head's forward operand [256, W]
+        self.w_fm, self.wb_fm = {}, {}
+        if USE_FM and W % 256 == 0:
+            for t in range(D):
+                self.w_fm[t] = fm_buffer(W, self.in_pad[t], self.device)
+            for t in range(1, D):
+                self.wb_fm[t] = fm_buffer(W, W, self.device)
+            self.wb_fm['heads'] = fm_buffer(W, self.head_k, self.device)
+            if not cfg['disable_rgb']:
+                self.w_fm[D + 1] = fm_buffer(BOTTLENECK, W, self.device)
         self.repack()
 
     def kernel(self, t, buf=None):
@@ -482,6 +553,13 @@ class TrainableMLP(object):
             elif t in (D + 2, D + 3):
                 bwd, ldb = self.wb[t], self.wb[t].shape[1]
             _check(L.mip360_pack_weight(_stream(), i, o, _p(k), _p(self.w[t]), self.in_pad[t], _p(bwd), ldb), 'mip360_pack_weight')
+        for t, buf in self.w_fm.items():
+            to_fm(self.w[t], out=buf)
+        for t, buf in self.wb_fm.items():
+            if t == 'heads':
+                to_fm(self.wb['heads'], out=buf)
+            else:
+                to_fm(self.wb[t], out=buf, rows=self.W, cols=self.W)
 
     def state(self):
         return [(self.kernel(t).clone(), self.bias(t).clone()) for t in range(len(self.shapes))]
@@ -574,9 +652,113 @@ def mlp_forward_train(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
     return density[:, 0], rgb, saved
 
 
+def mlp_forward_train_fm(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
+    """mlp_forward_train with the wide layers in the fm layout: enc_buf is an fm tensor [rows, W + 512] whose columns
+    [W, W + 512) cast_encode_fm filled; every trunk activation stays fm (the next layer's DMA copies its blocks), the view
+    branch (27- / 128-column operands) runs on the row-major kernels behind one from_fm of the 256-column bottleneck."""
+    W, D = tm.W, tm.depth
+    dev = enc_buf.device
+    ld_enc = W + IPE_LD
+    saved = dict(fm=True, enc_buf=enc_buf, H=[], inputs=[], masks=[])
+    x, x_col0, x_ld, x_k = enc_buf, W, ld_enc, IPE_LD
+    for i in range(D):
+        skip_out = (i % SKIP_LAYER == 0 and i > 0)
+        out, out_ld = (enc_buf, ld_enc) if skip_out else (fm_buffer(rows, W, dev), W)
+        mask = fm_mask_buffer(rows, W, dev)
+        linear_fm(x, tm.w_fm[i], tm.b[i], 1, rows, W, x_k, out, mask, lda=x_ld, ldw=tm.in_pad[i], ldc=out_ld, a_col0=x_col0)
+        saved['inputs'].append((x, x_col0, x_ld, x_k))
+        saved['H'].append((out, out_ld))
+        saved['masks'].append(mask)
+        x, x_col0, x_ld, x_k = (enc_buf, 0, ld_enc, W + IPE_LD) if skip_out else (out, 0, W, W)
+    saved['trunk'] = (x, x_col0, x_ld, x_k)
+    density = torch.empty(rows, 1, device=dev)
+    _check(lib().mip360_rowdot_fm(_stream(), rows, x_k, _fm_ptr(x, x_col0), x_ld, _p(tm.w[D]), _p(tm.b[D]), 2, DENSITY_BIAS,
+                                  _p(density), 1), 'mip360_rowdot_fm')
+    saved['density'] = density
+    rgb = None
+    if not tm.cfg['disable_rgb']:
+        bott = fm_buffer(rows, BOTTLENECK, dev)
+        linear_fm(x, tm.w_fm[D + 1], tm.b[D + 1], 0, rows, BOTTLENECK, x_k, bott, None, lda=x_ld, ldw=x_k, a_col0=x_col0)
+        view_in = torch.empty(rows, BOTTLENECK + DIR_LD, dtype=torch.bfloat16, device=dev)
+        from_fm(bott, rows, BOTTLENECK, out=view_in)
+        _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0),
+                                       BOTTLENECK, DIR_LD), 'mip360_dir_encode')
+        h = torch.empty(rows, VIEW_WIDTH, dtype=torch.bfloat16, device=dev)
+        linear(view_in, tm.w[D + 2], tm.b[D + 2], act=1, out_bf16=h, m=rows, n=VIEW_WIDTH, k=BOTTLENECK + DIR_LD)
+        rgb = torch.empty(rows, 3, device=dev)
+        linear(h, tm.w[D + 3], tm.b[D + 3], act=3, act_param=RGB_PADDING, out_f32=rgb, m=rows, n=3, k=VIEW_WIDTH)
+        saved.update(view_in=view_in, h=h, rgb=rgb)
+    return density[:, 0], rgb, saved
+
+
+def _grad_weight_fm(h, h_col0, ldh, dz, lddz, m, n_in, n_out, out, scratch, bias_out, rows_out=None):
+    """d kernel = H^T dZ from fm operands (n_in, n_out multiples of 256) into out [rows_out <= n_in, n_out]"""
+    tiles = (n_in // 256) * (n_out // 256)
+    ksplit = int(max(1, min(256, (256 + tiles - 1) // tiles, m // 32)))
+    if ksplit >= 8:
+        ksplit = (ksplit // 8) * 8
+    need = ksplit * (n_in * n_out + n_out)
+    if scratch[0] is None or scratch[0].numel() < need:
+        scratch[0] = torch.empty(need, device=h.device)
+    buf = scratch[0]
+    rows_out = n_in if rows_out is None else rows_out
+    _check(lib().mip360_grad_weight_fm(_stream(), m, n_in, n_out, _fm_ptr(h, h_col0), ldh, _p(dz), lddz, ksplit, _p(buf), None, n_out,
+                                       1.0, _p(bias_out)), 'mip360_grad_weight_fm')
+    _check(lib().mip360_grad_weight_reduce(_stream(), rows_out, n_in, n_out, ksplit, _p(buf), _p(out), n_out, 1.0, _p(bias_out)),
+           'mip360_grad_weight_reduce')
+
+
+def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
+    """mlp_backward on the fm tensors mlp_forward_train_fm saved."""
+    W, D = tm.W, tm.depth
+    dev = tm.device
+    G = tm.grads
+    bf = lambda c: torch.empty(rows, c, dtype=torch.bfloat16, device=dev)
+    nerf = not tm.cfg['disable_rgb']
+    trunk, t_col0, t_ld, trunk_k = saved['trunk']
+    heads = bf(tm.head_k)                                            # row-major: written by the head / view-branch kernels
+    raw_col = BOTTLENECK if nerf else 0
+    d_pre = bf(32) if nerf else None
+    _check(lib().mip360_head_backward(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)),
+                                      _p(saved.get('rgb')), _p(_f32(g_rgb).reshape(-1, 3)) if nerf else None, RGB_PADDING,
+                                      _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
+    if nerf:
+        h, view_in = saved['h'], saved['view_in']
+        _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G))
+        d_hz = bf(VIEW_WIDTH)
+        linear(d_pre, tm.wb[D + 3], None, act=4, out_bf16=d_hz, m=rows, n=VIEW_WIDTH, k=32, aux=h)
+        _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, tm.kernel(D + 2, G), scratch, tm.bias(D + 2, G),
+                     rows_out=BOTTLENECK + DIR_DIM)
+        linear(d_hz, tm.wb[D + 2], None, act=0, out_bf16=heads, m=rows, n=BOTTLENECK, k=VIEW_WIDTH)     # -> heads[:, :256]
+    heads_fm = to_fm(heads)                                          # [rows, head_k]
+    if nerf:
+        _grad_weight_fm(trunk, t_col0, t_ld, heads_fm, tm.head_k, rows, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch,
+                        tm.bias(D + 1, G))
+    # density head: d kernel[i] = sum_m trunk[m][i] d_raw[m]
+    ks = 256
+    need = ks * (trunk_k + 1)
+    if scratch[0] is None or scratch[0].numel() < need:
+        scratch[0] = torch.empty(need, device=dev)
+    _check(lib().mip360_grad_weight_col_fm(_stream(), rows, trunk_k, _fm_ptr(trunk, t_col0), t_ld, _p(heads_fm), tm.head_k, raw_col,
+                                           min(ks, rows // 32), _p(scratch[0]), _p(tm.kernel(D, G)), 1.0, _p(tm.bias(D, G))),
+           'mip360_grad_weight_col_fm')
+    # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
+    dz = fm_buffer(rows, W, dev)
+    linear_fm(heads_fm, tm.wb_fm['heads'], None, 2, rows, W, tm.head_k, dz, saved['masks'][D - 1])
+    for i in reversed(range(D)):
+        x, x_col0, x_ld, x_k = saved['inputs'][i]
+        _grad_weight_fm(x, x_col0, x_ld, dz, W, rows, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G), rows_out=tm.shapes[i][0])
+        if i > 0:
+            nxt = fm_buffer(rows, W, dev)
+            linear_fm(dz, tm.wb_fm[i], None, 2, rows, W, W, nxt, saved['masks'][i - 1])
+            dz = nxt
+
+
 def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch, side_stream=None):
     """Parameter gradients of one MLP into tm.grads (oracle: mip360_oracle.mlp_backward).  g_density [rows] f32,
     g_rgb [rows, 3] f32 or None."""
+    if saved.get('fm'):
+        return mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch)
     W, D = tm.W, tm.depth
     dev = tm.device
     G = tm.grads
@@ -664,10 +846,15 @@ class Mip360Trainer(object):
                                     None if jitter01 is None else jitter01[lvl])
             tm = self.prop if is_prop else self.nerf
             rows = n * ns
-            enc_buf = torch.empty(rows, tm.W + IPE_LD, dtype=torch.bfloat16, device=dev)
-            cast_encode(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, out=enc_buf[:, tm.W:],
-                        ld=tm.W + IPE_LD)
-            density, rgb, saved = mlp_forward_train(tm, enc_buf, rows, rays['viewdirs'], n, ns)
+            if fm_ok(rows, tm.W) and tm.w_fm:
+                enc_buf = fm_buffer(rows, tm.W + IPE_LD, dev)
+                cast_encode_fm(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, enc_buf, tm.W, tm.W + IPE_LD)
+                density, rgb, saved = mlp_forward_train_fm(tm, enc_buf, rows, rays['viewdirs'], n, ns)
+            else:
+                enc_buf = torch.empty(rows, tm.W + IPE_LD, dtype=torch.bfloat16, device=dev)
+                cast_encode(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, out=enc_buf[:, tm.W:],
+                            ld=tm.W + IPE_LD)
+                density, rgb, saved = mlp_forward_train(tm, enc_buf, rows, rays['viewdirs'], n, ns)
             density = density.reshape(n, ns)
             rgb_s = rgb.reshape(n, ns, 3) if rgb is not None else None
             r = render_level(density, rgb_s, tdist, rays['directions'], True, c['bg_rgb'])
