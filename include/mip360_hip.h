@@ -172,6 +172,14 @@ int mip360_rowdot_fm(void* stream, int m, int k, const void* a_fm, int lda, cons
                      float act_param, float* out, int ldo);
 int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,
                               int ksplit, float* slabs, float* grad_kernel, float scale, float* grad_bias);
+/* c_fm[m][n] = bf16(z[m] * w[n]) where bit (m, n) of `mask` is set (z bf16 [m], w bf16 [n]): mip360_linear_fm act 2 for a
+ * one-column operand -- the PropMLP's dZ of the last trunk layer (its only head is the density column).
+ * mip360_grad_weight_col_fm with lddz == 1 reads z from such a plain vector. */
+int mip360_outer_masked_fm(void* stream, int m, int n, const void* z_bf16, const void* w_bf16, const void* mask, void* c_fm, int ldc);
+/* mip360_pack_weight (below) that also writes the fm operand copies: fwd_fm [n_out, ld_fwd_fm] = kernel^T, bwd_fm element
+ * (i, bwd_col0 + o) for i < bwd_rows; either may be NULL; padding is never written (zero the buffers once). */
+int mip360_pack_weight_fm(void* stream, int n_in, int n_out, const float* kernel, void* fwd_bf16, int ld_fwd, void* bwd_bf16, int ld_bwd,
+                          void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0);
 /* mip360_grad_weight_bf16 (below) with both operands in fm layout; n_in, n_out multiples of 256, m of 32.  Same slab
  * contract: grad_kernel == NULL leaves the sums to mip360_grad_weight_reduce. */
 int mip360_grad_weight_fm(void* stream, int m, int n_in, int n_out, const void* h_fm, int ldh, const void* dz_fm, int lddz,

@@ -52,7 +52,9 @@ void mip360_launch_sumsq(hipStream_t st, int64_t n, const float* g, float* parti
 void mip360_launch_clip_mult(hipStream_t st, int n_partial, const float* partial, float max_norm, float* out);
 void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, float* m, float* v, const float* gmult, float lr,
                         float b1, float b2, float eps, float bc1, float bc2);
-void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd);
+void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd,
+                               void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0);
+int mip360_launch_outer_masked_fm(hipStream_t st, int M, int N, const void* z, const void* w, const void* mask, void* out, int ldc);
 void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width);
 
 namespace {
@@ -328,8 +330,25 @@ int mip360_pack_weight(void* stream, int n_in, int n_out, const float* kernel, v
                        int ld_bwd) {
   REQUIRE(n_in > 0 && n_out > 0 && kernel && (fwd_bf16 || bwd_bf16), "arguments");
   REQUIRE((!fwd_bf16 || ld_fwd >= n_in) && (!bwd_bf16 || ld_bwd >= n_out), "leading dimensions");
-  mip360_launch_pack_weight((hipStream_t)stream, n_in, n_out, kernel, fwd_bf16, ld_fwd, bwd_bf16, ld_bwd);
+  mip360_launch_pack_weight((hipStream_t)stream, n_in, n_out, kernel, fwd_bf16, ld_fwd, bwd_bf16, ld_bwd, nullptr, 0, nullptr, 0, 0, 0);
   return check_launch("pack_weight");
+}
+
+int mip360_pack_weight_fm(void* stream, int n_in, int n_out, const float* kernel, void* fwd_bf16, int ld_fwd, void* bwd_bf16, int ld_bwd,
+                          void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0) {
+  REQUIRE(n_in > 0 && n_out > 0 && kernel, "arguments");
+  REQUIRE((!fwd_bf16 || ld_fwd >= n_in) && (!bwd_bf16 || ld_bwd >= n_out), "leading dimensions");
+  REQUIRE((!fwd_fm || (ld_fwd_fm >= n_in && ld_fwd_fm % 16 == 0)) && (!bwd_fm || (ld_bwd_fm >= bwd_col0 + n_out && ld_bwd_fm % 16 == 0 && bwd_col0 >= 0)),
+          "fm leading dimensions (multiples of 16)");
+  mip360_launch_pack_weight((hipStream_t)stream, n_in, n_out, kernel, fwd_bf16, ld_fwd, bwd_bf16, ld_bwd, fwd_fm, ld_fwd_fm, bwd_fm, ld_bwd_fm,
+                            bwd_rows, bwd_col0);
+  return check_launch("pack_weight_fm");
+}
+
+int mip360_outer_masked_fm(void* stream, int m, int n, const void* z_bf16, const void* w_bf16, const void* mask, void* c_fm, int ldc) {
+  REQUIRE(z_bf16 && w_bf16 && mask && c_fm && ldc >= n, "non-null pointers, ldc >= n");
+  REQUIRE(mip360_launch_outer_masked_fm((hipStream_t)stream, m, n, z_bf16, w_bf16, mask, c_fm, ldc) == 0, "m, n multiples of 256, ldc of 16");
+  return check_launch("outer_masked_fm");
 }
 
 }  // extern "C"

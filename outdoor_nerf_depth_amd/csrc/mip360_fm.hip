@@ -536,10 +536,11 @@ __global__ __launch_bounds__(256) void grad_weight_col_fm_kernel(int M, int I, c
   unit_to_row_hi(lane, row, hi);
   const int64_t rbs = M / 32, per = (rbs + ksplit - 1) / ksplit;
   const int64_t b0 = (int64_t)slice * per, b1 = b0 + per < rbs ? b0 + per : rbs;
-  const size_t h_rb = (size_t)(ldh >> 4) * 1024, z_rb = (size_t)(lddz >> 4) * 1024;
+  const size_t h_rb = (size_t)(ldh >> 4) * 1024, z_rb = lddz == 1 ? 64 : (size_t)(lddz >> 4) * 1024;
   const int zf = zcol & 15;
   const char* hp = H + (size_t)cb * 1024 + lane * 16;
-  const char* zp = dZ + (size_t)(zcol >> 4) * 1024 + unit_of(row, (zf >> 2) & 1) * 16 + 2 * (4 * (zf >> 3) + (zf & 3));
+  // lddz == 1: dZ is a plain bf16 vector [M]
+  const char* zp = lddz == 1 ? dZ + 2 * row : dZ + (size_t)(zcol >> 4) * 1024 + unit_of(row, (zf >> 2) & 1) * 16 + 2 * (4 * (zf >> 3) + (zf & 3));
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, zsum = 0.f;
   auto fma8 = [&](const uint4 x, const uint16_t zr) {
     const float z = __builtin_bit_cast(float, (uint32_t)zr << 16);
@@ -575,6 +576,49 @@ __global__ __launch_bounds__(256) void grad_weight_col_fm_kernel(int M, int I, c
 #pragma unroll
     for (int e = 0; e < 8; ++e) slab[(size_t)(cb * 16 + 4 * hi + 8 * (e >> 2) + (e & 3)) * ldc] = acc[e];
     if (bias_slabs && cb == 0 && hi == 0) bias_slabs[slice] = zsum;
+  }
+}
+
+// dZ of the last trunk layer when the only head is the density column (PropMLP): out[m][n] = bf16(z[m] w[n]) where the mask
+// bit of (m, n) is set -- what linear_fm<2> computes from a one-column operand, without the GEMM.  A wave owns the 128 x 64
+// sub-tile whose mask words it reads (same lane <-> element map as linear_fm_kernel's epilogue).
+__global__ __launch_bounds__(512) void outer_masked_fm_kernel(int M, int N, const uint16_t* __restrict__ z, const uint16_t* __restrict__ w,
+                                                              const u32x4* __restrict__ mask, char* __restrict__ out, int ldc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = N >> 8;
+  const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int row, hi;
+  unit_to_row_hi(lane, row, hi);                                // (the stores below use lane = unit; the mask is indexed by the GEMM's lane)
+  const int glane = row + 32 * hi;
+  const u32x4 mw = mask[((size_t)tile * 8 + wave) * 64 + glane];
+  float wv[2][2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint16_t* wp = w + tn * 256 + wn * 64 + j * 32 + half * 16 + 4 * hi;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) wv[j][half][t] = __builtin_bit_cast(float, (uint32_t)wp[(t & 3) + 8 * (t >> 2)] << 16);
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rb = tm * 8 + wm * 4 + i;
+    const float zv = __builtin_bit_cast(float, (uint32_t)z[rb * 32 + row] << 16);
+    char* ob = out + ((size_t)rb * (ldc >> 4) + tn * 16 + wn * 4) * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2 f = {zv * wv[j][half][2 * q], zv * wv[j][half][2 * q + 1]};
+          uint32_t v = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+          v &= ((mw[i] >> (8 * j + 4 * half + q)) & 0x00010001u) * 0xFFFFu;
+          pk[q] = v;
+        }
+        *(uint4*)(ob + (j * 2 + half) * 1024) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      }
   }
 }
 
@@ -693,9 +737,17 @@ int mip360_launch_rowdot_fm(hipStream_t st, int M, int K, const void* A, int lda
 int mip360_launch_grad_weight_col_fm(hipStream_t st, int M, int I, const void* H, int ldh, const void* dZ, int lddz, int zcol, int ksplit,
                                      float* slabs, int ldc, float* bias_slabs) {
   using namespace mip360fm;
-  if (M <= 0 || M % 32 || I <= 0 || I % 16 || ldh % 16 || lddz % 16 || zcol < 0 || zcol >= lddz || ksplit < 1) return 1;
+  if (M <= 0 || M % 32 || I <= 0 || I % 16 || ldh % 16 || (lddz != 1 && lddz % 16) || zcol < 0 || zcol >= lddz || ksplit < 1) return 1;
   const int waves = (I / 16) * ksplit;
   hipLaunchKernelGGL(grad_weight_col_fm_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, M, I, (const char*)H, ldh, (const char*)dZ, lddz, zcol,
                      ksplit, slabs, ldc, bias_slabs);
+  return 0;
+}
+
+int mip360_launch_outer_masked_fm(hipStream_t st, int M, int N, const void* z, const void* w, const void* mask, void* out, int ldc) {
+  using namespace mip360fm;
+  if (M <= 0 || N <= 0 || M % 256 || N % 256 || ldc % 16) return 1;
+  hipLaunchKernelGGL(outer_masked_fm_kernel, dim3((M / 256) * (N / 256)), dim3(512), 0, st, M, N, (const uint16_t*)z, (const uint16_t*)w,
+                     (const u32x4*)mask, (char*)out, ldc);
   return 0;
 }

@@ -315,14 +315,13 @@ __global__ __launch_bounds__(MODE == 2 ? 704 : 256) void cast_encode_kernel(
   // bf16 rows feeding a GEMM (ld >= 512 columns, 16-byte aligned): the 21-lane pieces of a row are 42-byte runs of
   // 2-byte stores, so the wave's 3 rows (1 KiB each incl. the zero padding 504..511) are assembled in LDS and leave
   // as 16 bytes per lane (3 wave-stores instead of 24 partial ones)
-  __shared__ __attribute__((aligned(16))) __bf16 rows_lds[FM ? 8 : 4][FM ? 4 : 3][MIP360_IPE_LD];   // (FM: 32 blocks x 1 KiB x ... = 32 KiB, used flat)
+  // (FM: 32 rows of 512 + 4 elements -- consecutive rows start 2 banks apart, so the 8-byte reads of the copy-out, one row per
+  // lane, are conflict-free; used flat)
+  __shared__ __attribute__((aligned(16))) __bf16 rows_lds[FM ? 33 : 4][FM ? 1 : 3][MIP360_IPE_LD];
   const bool staged = !FM && BF16 && ld >= MIP360_IPE_LD && (ld & 7) == 0 && (((uintptr_t)enc) & 15) == 0;
   const int wave_l = threadIdx.x >> 6;
-  // FM: element (r, col) of the row block -> block col / 16, unit 8 (r >> 2) + 4 (hi ^ (r >> 4)) + (r & 3), element t
-  auto fm_at = [&](int r, int col) -> __bf16* {
-    const int f = col & 15, hi = (f >> 2) & 1, t = 4 * (f >> 3) + (f & 3);
-    return &rows_lds[0][0][0] + (col >> 4) * 512 + (8 * (r >> 2) + 4 * (hi ^ (r >> 4)) + (r & 3)) * 8 + t;
-  };
+  constexpr int FM_ROW = MIP360_IPE_LD + 4;                       // staged row stride (elements)
+  auto fm_at = [&](int r, int col) -> __bf16* { return &rows_lds[0][0][0] + r * FM_ROW + col; };
 #pragma unroll
   for (int k = 0; k < ND; ++k) {
     const float sc = (float)(1 << k);
@@ -350,9 +349,15 @@ __global__ __launch_bounds__(MODE == 2 ? 704 : 256) void cast_encode_kernel(
   if (FM) {
     if (live && j < MIP360_IPE_LD - 2 * HALF) *fm_at(sub, 2 * HALF + j) = (__bf16)0.f;
     __syncthreads();
+    // unit v of block cb = (row, hi): columns 16 cb + {4 hi + 0..3, 8 + 4 hi + 0..3} of the staged row
     char* dst = (char*)enc + (size_t)blockIdx.x * (size_t)(ld >> 4) * 1024;
-    const char* src = (const char*)&rows_lds[0][0][0];
-    for (int u = threadIdx.x; u < 32 * 64; u += 704) *(uint4*)(dst + (size_t)u * 16) = *(const uint4*)(src + (size_t)u * 16);
+    for (int u = threadIdx.x; u < 32 * 64; u += 704) {
+      const int cb = u >> 6, v = u & 63;
+      const int r = ((v >> 3) << 2) | (v & 3), hi = ((v >> 2) & 1) ^ (r >> 4);
+      const __bf16* src = fm_at(r, cb * 16 + 4 * hi);
+      const uint2 a = *(const uint2*)src, b = *(const uint2*)(src + 8);
+      *(uint4*)(dst + (size_t)u * 16) = make_uint4(a.x, a.y, b.x, b.y);
+    }
     return;
   }
   if (staged) {

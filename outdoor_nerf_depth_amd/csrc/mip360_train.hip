@@ -507,14 +507,24 @@ __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __res
 }
 // f32 [rows, cols] parameter (flax kernel [in, out]) -> bf16 copies: fwd [out, in_pad] (transposed, zero padded) and
 // bwd [in_pad?]: the kernel as stored, [in, out_pad], both K-contiguous for the NT dense-layer kernel
+// element (r, c) of an fm tensor with ld columns (mip360_fm.hip), in elements
+__device__ __forceinline__ size_t fm_elem(int r, int c, int ld) {
+  const int row = r & 31, f = c & 15, hi = (f >> 2) & 1;
+  return ((size_t)(r >> 5) * (ld >> 4) + (c >> 4)) * 512 + (size_t)(8 * (row >> 2) + 4 * (hi ^ (row >> 4)) + (row & 3)) * 8 + 4 * (f >> 3) + (f & 3);
+}
+// ... and the fm copies the fragment-major kernels read: fwd_fm [n_out, ld_fwd_fm] (element (o, i)), bwd_fm [rows, ld_bwd_fm]
+// (element (i, bwd_col0 + o) for i < bwd_rows); their zero padding is the caller's (written once)
 __global__ void pack_weight_kernel(int n_in, int n_out, const float* __restrict__ k, __bf16* __restrict__ fwd, int ld_fwd,
-                                   __bf16* __restrict__ bwd, int ld_bwd) {
+                                   __bf16* __restrict__ bwd, int ld_bwd, __bf16* __restrict__ fwd_fm, int ld_fwd_fm,
+                                   __bf16* __restrict__ bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)n_in * n_out) return;
   const int i = (int)(e / n_out), o = (int)(e - (int64_t)i * n_out);
   const __bf16 v = (__bf16)k[e];
   if (fwd) fwd[(size_t)o * ld_fwd + i] = v;
   if (bwd) bwd[(size_t)i * ld_bwd + o] = v;
+  if (fwd_fm) fwd_fm[fm_elem(o, i, ld_fwd_fm)] = v;
+  if (bwd_fm && i < bwd_rows) bwd_fm[fm_elem(i, bwd_col0 + o, ld_bwd_fm)] = v;
 }
 
 }  // namespace mip360
@@ -577,8 +587,9 @@ void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, flo
                         float b1, float b2, float eps, float bc1, float bc2) {
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, gmult, lr, b1, b2, eps, bc1, bc2);
 }
-void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd) {
+void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd,
+                               void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0) {
   const int64_t n = (int64_t)n_in * n_out;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_in, n_out, k, (__bf16*)fwd, ld_fwd,
-                     (__bf16*)bwd, ld_bwd);
+                     (__bf16*)bwd, ld_bwd, (__bf16*)fwd_fm, ld_fwd_fm, (__bf16*)bwd_fm, ld_bwd_fm, bwd_rows, bwd_col0);
 }

@@ -52,6 +52,8 @@ SYMBOLS = {
                                         C.c_float, _fp]),
     'mip360_rowdot_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_float, _fp, C.c_int]),
     'mip360_grad_weight_col_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp]),
+    'mip360_outer_masked_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int]),
+    'mip360_pack_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                           C.c_float, _fp]),
@@ -508,8 +510,8 @@ class TrainableMLP(object):
         self.wb = {}                                                                         # backward operands
         for t in range(1, D):
             self.wb[t] = bf(self.in_pad[t], W)
-        # a multiple of 64 (the persistent row-major GEMM); the fm GEMM needs K >= 128
-        self.head_k = (BOTTLENECK + 64) if not cfg['disable_rgb'] else (128 if USE_FM else 64)
+        # a multiple of 64 (the persistent row-major GEMM)
+        self.head_k = (BOTTLENECK + 64) if not cfg['disable_rgb'] else 64
         self.wb['heads'] = bf(W, self.head_k)                    # [K_bottleneck | K_density | 0], or [K_density | 0]
         if not cfg['disable_rgb']:
             self.wb[D + 2] = bf(BOTTLENECK + DIR_LD, VIEW_WIDTH)
@@ -518,13 +520,14 @@ class TrainableMLP(object):
         # and the bottleneck head's forward operand [256, W]
         self.w_fm, self.wb_fm = {}, {}
         if USE_FM and W % 256 == 0:
+            fmz = lambda r, c: torch.zeros(r * c, dtype=torch.bfloat16, device=self.device)     # (the packing never writes padding)
             for t in range(D):
-                self.w_fm[t] = fm_buffer(W, self.in_pad[t], self.device)
+                self.w_fm[t] = fmz(W, self.in_pad[t])
             for t in range(1, D):
-                self.wb_fm[t] = fm_buffer(W, W, self.device)
-            self.wb_fm['heads'] = fm_buffer(W, self.head_k, self.device)
+                self.wb_fm[t] = fmz(W, W)
+            self.wb_fm['heads'] = fmz(W, self.head_k)
             if not cfg['disable_rgb']:
-                self.w_fm[D + 1] = fm_buffer(BOTTLENECK, W, self.device)
+                self.w_fm[D + 1] = fmz(BOTTLENECK, W)
         self.repack()
 
     def kernel(self, t, buf=None):
@@ -552,14 +555,18 @@ class TrainableMLP(object):
                 bwd, ldb = self.wb['heads'], self.head_k
             elif t in (D + 2, D + 3):
                 bwd, ldb = self.wb[t], self.wb[t].shape[1]
-            _check(L.mip360_pack_weight(_stream(), i, o, _p(k), _p(self.w[t]), self.in_pad[t], _p(bwd), ldb), 'mip360_pack_weight')
-        for t, buf in self.w_fm.items():
-            to_fm(self.w[t], out=buf)
-        for t, buf in self.wb_fm.items():
-            if t == 'heads':
-                to_fm(self.wb['heads'], out=buf)
-            else:
-                to_fm(self.wb[t], out=buf, rows=self.W, cols=self.W)
+            fwd_fm, bwd_fm, ld_bwd_fm, bwd_rows, bwd_col0 = self.w_fm.get(t), None, 0, 0, 0
+            if self.wb_fm:
+                if 1 <= t < D:
+                    bwd_fm, ld_bwd_fm, bwd_rows = self.wb_fm[t], self.W, self.W
+                elif t == D:
+                    bwd_fm, ld_bwd_fm, bwd_rows = self.wb_fm['heads'], self.head_k, self.W
+                    bwd_col0 = BOTTLENECK if not self.cfg['disable_rgb'] else 0
+                elif t == D + 1:
+                    bwd_fm, ld_bwd_fm, bwd_rows = self.wb_fm['heads'], self.head_k, self.W
+            _check(L.mip360_pack_weight_fm(_stream(), i, o, _p(k), _p(self.w[t]), self.in_pad[t], _p(bwd), ldb, _p(fwd_fm),
+                                           self.in_pad[t] if fwd_fm is not None else 0, _p(bwd_fm), ld_bwd_fm, bwd_rows, bwd_col0),
+                   'mip360_pack_weight_fm')
 
     def state(self):
         return [(self.kernel(t).clone(), self.bias(t).clone()) for t in range(len(self.shapes))]
@@ -716,13 +723,26 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
     bf = lambda c: torch.empty(rows, c, dtype=torch.bfloat16, device=dev)
     nerf = not tm.cfg['disable_rgb']
     trunk, t_col0, t_ld, trunk_k = saved['trunk']
-    heads = bf(tm.head_k)                                            # row-major: written by the head / view-branch kernels
-    raw_col = BOTTLENECK if nerf else 0
-    d_pre = bf(32) if nerf else None
-    _check(lib().mip360_head_backward(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)),
-                                      _p(saved.get('rgb')), _p(_f32(g_rgb).reshape(-1, 3)) if nerf else None, RGB_PADDING,
-                                      _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
-    if nerf:
+    ks = min(256, rows // 32)                                        # row slices of the density head's column-dot kernel
+    if scratch[0] is None or scratch[0].numel() < ks * (trunk_k + 1):
+        scratch[0] = torch.empty(ks * (trunk_k + 1), device=dev)
+    dz = fm_buffer(rows, W, dev)
+    if not nerf:
+        # the density column is the only head: d_raw as a plain bf16 vector, dZ of the last trunk layer as a masked outer product
+        d_raw = torch.empty(rows, dtype=torch.bfloat16, device=dev)
+        _check(lib().mip360_head_backward(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)), None, None,
+                                          RGB_PADDING, _p(d_raw), 1, 0, 1, None), 'mip360_head_backward')
+        _check(lib().mip360_grad_weight_col_fm(_stream(), rows, trunk_k, _fm_ptr(trunk, t_col0), t_ld, _p(d_raw), 1, 0, ks, _p(scratch[0]),
+                                               _p(tm.kernel(D, G)), 1.0, _p(tm.bias(D, G))), 'mip360_grad_weight_col_fm')
+        _check(lib().mip360_outer_masked_fm(_stream(), rows, W, _p(d_raw), _p(tm.w[D]), _p(saved['masks'][D - 1]), _p(dz), W),
+               'mip360_outer_masked_fm')
+    else:
+        heads = bf(tm.head_k)                                        # row-major: written by the head / view-branch kernels
+        raw_col = BOTTLENECK
+        d_pre = bf(32)
+        _check(lib().mip360_head_backward(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)),
+                                          _p(saved.get('rgb')), _p(_f32(g_rgb).reshape(-1, 3)), RGB_PADDING,
+                                          _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
         h, view_in = saved['h'], saved['view_in']
         _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G))
         d_hz = bf(VIEW_WIDTH)
@@ -730,21 +750,16 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
         _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, tm.kernel(D + 2, G), scratch, tm.bias(D + 2, G),
                      rows_out=BOTTLENECK + DIR_DIM)
         linear(d_hz, tm.wb[D + 2], None, act=0, out_bf16=heads, m=rows, n=BOTTLENECK, k=VIEW_WIDTH)     # -> heads[:, :256]
-    heads_fm = to_fm(heads)                                          # [rows, head_k]
-    if nerf:
+        heads_fm = to_fm(heads)                                      # [rows, head_k]
         _grad_weight_fm(trunk, t_col0, t_ld, heads_fm, tm.head_k, rows, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch,
                         tm.bias(D + 1, G))
-    # density head: d kernel[i] = sum_m trunk[m][i] d_raw[m]
-    ks = 256
-    need = ks * (trunk_k + 1)
-    if scratch[0] is None or scratch[0].numel() < need:
-        scratch[0] = torch.empty(need, device=dev)
-    _check(lib().mip360_grad_weight_col_fm(_stream(), rows, trunk_k, _fm_ptr(trunk, t_col0), t_ld, _p(heads_fm), tm.head_k, raw_col,
-                                           min(ks, rows // 32), _p(scratch[0]), _p(tm.kernel(D, G)), 1.0, _p(tm.bias(D, G))),
-           'mip360_grad_weight_col_fm')
-    # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
-    dz = fm_buffer(rows, W, dev)
-    linear_fm(heads_fm, tm.wb_fm['heads'], None, 2, rows, W, tm.head_k, dz, saved['masks'][D - 1])
+        if scratch[0].numel() < ks * (trunk_k + 1):
+            scratch[0] = torch.empty(ks * (trunk_k + 1), device=dev)
+        # density head: d kernel[i] = sum_m trunk[m][i] d_raw[m]
+        _check(lib().mip360_grad_weight_col_fm(_stream(), rows, trunk_k, _fm_ptr(trunk, t_col0), t_ld, _p(heads_fm), tm.head_k, raw_col, ks,
+                                               _p(scratch[0]), _p(tm.kernel(D, G)), 1.0, _p(tm.bias(D, G))), 'mip360_grad_weight_col_fm')
+        # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
+        linear_fm(heads_fm, tm.wb_fm['heads'], None, 2, rows, W, tm.head_k, dz, saved['masks'][D - 1])
     for i in reversed(range(D)):
         x, x_col0, x_ld, x_k = saved['inputs'][i]
         _grad_weight_fm(x, x_col0, x_ld, dz, W, rows, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G), rows_out=tm.shapes[i][0])
