@@ -254,52 +254,79 @@ __global__ __launch_bounds__(MODE == 2 ? 704 : 256) void cast_encode_kernel(
   const bool live = (FM ? sub < 32 : sub < 3) && row_raw < rows;
   const int64_t row = live ? row_raw : rows - 1;                 // idle lanes compute a valid row and store nothing
   if (!FM && (int64_t)wave_g * 3 >= rows) return;
-  const int ray = (int)(row / S), smp = (int)(row - (int64_t)ray * S);
-  const float t0 = tdist[(size_t)ray * (S + 1) + smp], t1 = tdist[(size_t)ray * (S + 1) + smp + 1];
-  const float d[3] = {directions[ray * 3], directions[ray * 3 + 1], directions[ray * 3 + 2]};
-  const float o[3] = {origins[ray * 3], origins[ray * 3 + 1], origins[ray * 3 + 2]};
-  const float br = radii[ray];
-  // conical_frustum_to_gaussian, stable form (render.py:64-73)
-  const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
-  const float denom = fmaxf(EPS, 3.f * mu * mu + hw * hw);
-  const float t_mean = mu + (2.f * mu * hw * hw) / denom;
-  const float hw4 = hw * hw * hw * hw;
-  const float t_var = (hw * hw) / 3.f - (4.f / 15.f) * hw4 * (12.f * mu * mu - hw * hw) / (denom * denom);
-  float r_var = (mu * mu) / 4.f + (5.f / 12.f) * hw * hw - (4.f / 15.f) * hw4 / denom;
-  r_var *= br * br;
-  // lift_gaussian, diag = False (render.py:21-42)
-  const float dms = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  float mean[3], cov[3][3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    mean[a] = d[a] * t_mean + o[a];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const float d_outer = d[a] * d[b];
-      const float null_outer = (a == b ? 1.f : 0.f) - d[a] * (d[b] / dms);
-      cov[a][b] = t_var * d_outer + r_var * null_outer;
+  // per-row quantities: contracted mean cm, Jacobian J of the contraction, lifted covariance cov
+  auto row_math = [&](int64_t row, float (&cm)[3], float (&J)[3][3], float (&cov)[3][3]) {
+    const int ray = (int)(row / S), smp = (int)(row - (int64_t)ray * S);
+    const float t0 = tdist[(size_t)ray * (S + 1) + smp], t1 = tdist[(size_t)ray * (S + 1) + smp + 1];
+    const float d[3] = {directions[ray * 3], directions[ray * 3 + 1], directions[ray * 3 + 2]};
+    const float o[3] = {origins[ray * 3], origins[ray * 3 + 1], origins[ray * 3 + 2]};
+    const float br = radii[ray];
+    // conical_frustum_to_gaussian, stable form (render.py:64-73)
+    const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
+    const float denom = fmaxf(EPS, 3.f * mu * mu + hw * hw);
+    const float t_mean = mu + (2.f * mu * hw * hw) / denom;
+    const float hw4 = hw * hw * hw * hw;
+    const float t_var = (hw * hw) / 3.f - (4.f / 15.f) * hw4 * (12.f * mu * mu - hw * hw) / (denom * denom);
+    float r_var = (mu * mu) / 4.f + (5.f / 12.f) * hw * hw - (4.f / 15.f) * hw4 / denom;
+    r_var *= br * br;
+    // lift_gaussian, diag = False (render.py:21-42)
+    const float dms = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float mean[3];
+  #pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mean[a] = d[a] * t_mean + o[a];
+  #pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const float d_outer = d[a] * d[b];
+        const float null_outer = (a == b ? 1.f : 0.f) - d[a] * (d[b] / dms);
+        cov[a][b] = t_var * d_outer + r_var * null_outer;
+      }
     }
-  }
-  // contract + its Jacobian (coord.py:21-27, track_linearize :39-60)
-  const float m2 = fmaxf(EPS, mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
-  float cm[3], J[3][3];
-  if (m2 <= 1.f) {
+    // contract + its Jacobian (coord.py:21-27, track_linearize :39-60)
+    const float m2 = fmaxf(EPS, mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+    if (m2 <= 1.f) {
+  #pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        cm[a] = mean[a];
+  #pragma unroll
+        for (int b = 0; b < 3; ++b) J[a][b] = a == b ? 1.f : 0.f;
+      }
+    } else {
+      const float r = sqrtf(m2);
+      const float s = (2.f * r - 1.f) / m2;
+      const float ds = (1.f - r) / (m2 * m2);
+  #pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        cm[a] = s * mean[a];
+  #pragma unroll
+        for (int b = 0; b < 3; ++b) J[a][b] = (a == b ? s : 0.f) + 2.f * ds * mean[a] * mean[b];
+      }
+    }
+  };
+  float cm[3], J[3][3], cov[3][3];
+  if (FM) {
+    // one thread per row does the row's arithmetic (its 21 basis lanes would each repeat it), the others pick it up from LDS
+    __shared__ float rowq[32][21];
+    if (threadIdx.x < 32) {
+      const int64_t r = (int64_t)blockIdx.x * 32 + threadIdx.x;
+      row_math(r < rows ? r : rows - 1, cm, J, cov);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        rowq[threadIdx.x][a] = cm[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { rowq[threadIdx.x][3 + 3 * a + b] = J[a][b]; rowq[threadIdx.x][12 + 3 * a + b] = cov[a][b]; }
+      }
+    }
+    __syncthreads();
+    const int rs = sub < 32 ? sub : 31;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      cm[a] = mean[a];
+      cm[a] = rowq[rs][a];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) J[a][b] = a == b ? 1.f : 0.f;
+      for (int b = 0; b < 3; ++b) { J[a][b] = rowq[rs][3 + 3 * a + b]; cov[a][b] = rowq[rs][12 + 3 * a + b]; }
     }
   } else {
-    const float r = sqrtf(m2);
-    const float s = (2.f * r - 1.f) / m2;
-    const float ds = (1.f - r) / (m2 * m2);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      cm[a] = s * mean[a];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) J[a][b] = (a == b ? s : 0.f) + 2.f * ds * mean[a] * mean[b];
-    }
+    row_math(row, cm, J, cov);
   }
   // lift_and_diagonalize (coord.py:131-135): mean . b_j and b_j^T (J cov J^T) b_j = (J^T b_j)^T cov (J^T b_j)
   const float bj[3] = {basis_t[j], basis_t[MIP360_N_BASIS + j], basis_t[2 * MIP360_N_BASIS + j]};

@@ -518,7 +518,7 @@ class TrainableMLP(object):
             self.wb[D + 3] = bf(VIEW_WIDTH, 32)
         # fm copies of the wide layers' operands: forward [W, in_pad], backward [W (first W inputs), W], heads [W, head_k],
         # and the bottleneck head's forward operand [256, W]
-        self.w_fm, self.wb_fm = {}, {}
+        self.w_fm, self.wb_fm, self.rm_stale = {}, {}, False
         if USE_FM and W % 256 == 0:
             fmz = lambda r, c: torch.zeros(r * c, dtype=torch.bfloat16, device=self.device)     # (the packing never writes padding)
             for t in range(D):
@@ -539,10 +539,18 @@ class TrainableMLP(object):
         a = int(self.offsets[2 * t + 1])
         return (self.flat if buf is None else buf)[a:a + self.shapes[t][1]]
 
-    def repack(self):
-        """float32 master -> bf16 operand copies (after every Adam step)."""
+    def ensure_rm(self):
+        """the row-major copies of the wide layers (skipped by repack(lazy=True)) before a row-major kernel reads them"""
+        if self.rm_stale:
+            self.repack()
+
+    def repack(self, lazy=False):
+        """float32 master -> bf16 operand copies (after every Adam step).  lazy: with the fm copies in use, the row-major
+        ones of the wide layers (nobody reads them on the fm path) are left stale until ensure_rm()."""
         D = self.depth
         L = lib()
+        skip_rm = bool(lazy and self.w_fm)
+        self.rm_stale = skip_rm
         for t, (i, o) in enumerate(self.shapes):
             k = self.kernel(t)
             bwd, ldb = None, 0
@@ -564,7 +572,12 @@ class TrainableMLP(object):
                     bwd_col0 = BOTTLENECK if not self.cfg['disable_rgb'] else 0
                 elif t == D + 1:
                     bwd_fm, ld_bwd_fm, bwd_rows = self.wb_fm['heads'], self.head_k, self.W
-            _check(L.mip360_pack_weight_fm(_stream(), i, o, _p(k), _p(self.w[t]), self.in_pad[t], _p(bwd), ldb, _p(fwd_fm),
+            fwd = self.w[t]
+            if skip_rm and (t < D or t == D + 1):                # (the density head's vector and the view branch stay current)
+                fwd, bwd = None, None
+            elif skip_rm and t == D:
+                bwd = None
+            _check(L.mip360_pack_weight_fm(_stream(), i, o, _p(k), _p(fwd), self.in_pad[t], _p(bwd), ldb, _p(fwd_fm),
                                            self.in_pad[t] if fwd_fm is not None else 0, _p(bwd_fm), ld_bwd_fm, bwd_rows, bwd_col0),
                    'mip360_pack_weight_fm')
 
@@ -626,6 +639,7 @@ def _grad_bias(dz, n_out, out, scratch):
 
 def mlp_forward_train(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
     """mlp_forward keeping what the backward needs (every layer's bf16 output, the view-branch input and hidden state)."""
+    tm.ensure_rm()
     W, D = tm.W, tm.depth
     dev = enc_buf.device
     bf = lambda c: torch.empty(rows, c, dtype=torch.bfloat16, device=dev)
@@ -774,6 +788,7 @@ def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch, side_stream=None):
     g_rgb [rows, 3] f32 or None."""
     if saved.get('fm'):
         return mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch)
+    tm.ensure_rm()
     W, D = tm.W, tm.depth
     dev = tm.device
     G = tm.grads
@@ -895,7 +910,7 @@ class Mip360Trainer(object):
                'mip360_clip_multiplier')
         _check(L.mip360_adam_step(_stream(), n, _p(tm.flat), _p(tm.grads), _p(tm.mu), _p(tm.nu), _p(self.clip[k]), self.step,
                                   lr, 0.9, 0.999, self.adam_eps), 'mip360_adam_step')
-        tm.repack()
+        tm.repack(lazy=True)
 
     def apply_gradients(self):
         """Both MLPs, on the caller's stream (NerfMLP first, like the pmean order of the step)."""
