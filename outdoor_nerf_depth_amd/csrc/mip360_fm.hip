@@ -34,6 +34,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __host__ __device__ __forceinline__ uint32_t unit_of(int row, int hi) { return 8u * (row >> 2) + 4u * (hi ^ (row >> 4)) + (row & 3); }
 
@@ -218,16 +220,20 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
         uint32_t pk[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-          float v0 = acc[i][j][2 * p], v1 = acc[i][j][2 * p + 1];
-          if (ACT == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          const f32x2 f = {v0, v1};
+          const f32x2 f = {acc[i][j][2 * p], acc[i][j][2 * p + 1]};
           uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
           if (ACT == 1) {
-            w &= 0x7FFF7FFFu;                                    // (-0 -> +0)
-            const uint32_t nz = ((w & 0xFFFFu) ? 1u : 0u) | ((w >> 16) ? 0x10000u : 0u);
+            // ReLU on the packed pair: a negative bf16 (or -0) is a negative int16 -> v_pk_max_i16 with 0; non-zero flag per
+            // half: v_pk_min_u16 with 1
+            w = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), (s16x2){0, 0}));
+            uint32_t nz;                                           // (asm: the compiler turns min(max(x, 0), 1) into compares and selects)
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(w), "v"(0x00010001u));
             word |= nz << (8 * j + p);
           }
-          if (ACT == 2) w &= ((mw[i] >> (8 * j + p)) & 0x00010001u) * 0xFFFFu;
+          if (ACT == 2) {                                        // halves times their mask bit (v_pk_mul_lo_u16)
+            const uint32_t m = (mw[i] >> (8 * j + p)) & 0x00010001u;
+            w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, w) * __builtin_bit_cast(u16x2, m));
+          }
           pk[p] = w;
         }
         const u32x4 lo = {pk[0], pk[1], pk[2], pk[3]}, hi4 = {pk[4], pk[5], pk[6], pk[7]};
