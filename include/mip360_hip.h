@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MIP360_ABI_VERSION 4
+#define MIP360_ABI_VERSION 5
 #define MIP360_OK 0
 #define MIP360_ERR_ARG 1
 #define MIP360_ERR_HIP 2
@@ -58,7 +58,9 @@ int mip360_resample(void* stream, int n_rays, int m_in, const float* sdist_in, c
  *   integrated_pos_enc(., ., 0, 12)                           coord.py:103-128
  * tdist [n, S+1]; origins, directions [n,3]; radii [n]; basis_t [3, 21] row-major.
  * enc [n*S, ld]: float32 (out_bf16 = 0) or bfloat16 (out_bf16 = 1); columns 504..min(ld, 512)-1 are zero-filled (K
- * padding of the first dense layer); ld may be larger when enc is a column window of a wider row (the skip buffer). */
+ * padding of the first dense layer); ld may be larger when enc is a column window of a wider row (the skip buffer).
+ * out_bf16 = 2: bfloat16 in the fragment-major layout below -- enc = the fm tensor's base + 1024 * (first column / 16)
+ * bytes, ld = the tensor's columns (a multiple of 16), n * S a multiple of 32; bit-identical values. */
 int mip360_cast_encode(void* stream, int n_rays, int n_samples, const float* tdist,
                        const float* origins, const float* directions, const float* radii,
                        const float* basis_t, void* enc, int out_bf16, int ld);

@@ -302,3 +302,38 @@ def test_fragment_major_saved_tensor_layout_is_a_bijection():
         for q in range(4):
             want = (2 * j + (q & 1)) * 16 + 8 * (q >> 1)
             assert [addr(j, 4 * q + e, 16) for e in range(4)] == [want + 2 * e for e in range(4)]
+
+
+def test_mip360_fm_unit_order_is_conflict_free_for_both_read_patterns():
+    """csrc/mip360_fm.hip: unit(row, hi) = 8 (row >> 2) + 4 (hi ^ (row >> 4)) + (row & 3).  (a) ds_read_b128 by lane (row = l & 31,
+    hi = l >> 5) is serviced in the four 16-lane groups of MI355X_MICROARCH.md "LDS": each must touch 64 distinct banks
+    (bank = (byte / 4) % 64).  (b) the weight-gradient kernel's ds_read_b64_tr_b16 is serviced in two 32-lane groups; its lane
+    address (blocks 1152 B apart, both k-steps, both reads of a fragment) must do the same.  (c) the four pieces of a
+    [4 rows x 16 columns] patch are the 8 units of the rows' group: 128 contiguous bytes."""
+    unit = lambda row, hi: 8 * (row >> 2) + 4 * (hi ^ (row >> 4)) + (row & 3)
+    assert sorted(unit(r, h) for r in range(32) for h in range(2)) == list(range(64))
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for g in groups:
+        banks = set()
+        for l in g:
+            byte = unit(l & 31, l >> 5) * 16
+            banks |= {(byte // 4 + d) % 64 for d in range(4)}
+        assert len(banks) == 64, g
+    BLKP = 1152
+    for kk in range(2):
+        for second in range(2):
+            for half in range(2):                                  # lanes 0-31, 32-63
+                banks = []
+                for lane in range(32 * half, 32 * half + 32):
+                    g, a16 = lane >> 4, lane & 15
+                    off = (g & 1) * BLKP + kk * 512 + (g >> 1) * 256 + 64 * ((a16 & 1) ^ kk) + 16 * (a16 >> 2) + 8 * ((a16 >> 1) & 1)
+                    off += 128 * second
+                    # the address is the 8-byte piece (row, quad q = a16 & 3) of the block: unit(row, q & 1) * 16 + 8 * (q >> 1)
+                    row = 16 * kk + 8 * (g >> 1) + 4 * second + (a16 >> 2)
+                    assert off - (g & 1) * BLKP == unit(row, a16 & 1) * 16 + 8 * ((a16 >> 1) & 1)
+                    banks += [(off // 4) % 64, (off // 4 + 1) % 64]
+                assert len(set(banks)) == 64, (kk, second, half)
+    for quad_of_rows in range(8):
+        units = sorted(unit(4 * quad_of_rows + i, h) for i in range(4) for h in range(2))
+        assert units == list(range(8 * quad_of_rows, 8 * quad_of_rows + 8))
