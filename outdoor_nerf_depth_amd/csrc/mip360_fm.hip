@@ -51,6 +51,25 @@ __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
+#ifndef FM_GLDS_MODE
+#define FM_GLDS_MODE 0
+#endif
+// probes: M0 left clobbered (no save / restore); two blocks per M0 value through the instruction offset
+__device__ __forceinline__ void glds16_m0(const void* sbase, uint32_t voff, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+}
+__device__ __forceinline__ void glds16_pair(const void* sbase, uint32_t voff, uint32_t lds_abs) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+               :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+}
 __device__ __forceinline__ uint64_t uniform64(const void* p) {
   const uint64_t b = (uint64_t)(uintptr_t)p;
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
@@ -78,7 +97,14 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   constexpr int SLOT = Cfg::SLOT;
   // VMEM instructions of one epilogue + preload (older than the DMA issued after it): output stores, mask store / load, bias loads
   constexpr int NE = ACT == 0 ? 16 + 2 : ACT == 1 ? 16 + 1 + 2 : 16 + 1;
-  constexpr int AHEAD = Cfg::AHEAD, VM_STEADY = (AHEAD - 1) * 4, VM_PEEL = VM_STEADY + NE;
+  #if defined(FM_EXP_HALFDMA)
+  constexpr int DMA_PER = 2;
+#elif defined(FM_EXP_NODMA)
+  constexpr int DMA_PER = 0;
+#else
+  constexpr int DMA_PER = 4;
+#endif
+  constexpr int AHEAD = Cfg::AHEAD, VM_STEADY = (AHEAD - 1) * DMA_PER, VM_PEEL = VM_STEADY + NE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, grp = wm;            // group 0 = waves 0-3 = tile rows 0-127
   const int tiles_n = N >> 8, tiles_m = M >> 8, tiles = tiles_m * tiles_n;
@@ -112,10 +138,25 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   };
   auto issue = [&]() {
     const uint32_t d = lds0 + islot + (uint32_t)wave * 2048u;
+#if defined(FM_EXP_HALFDMA)
+    glds16(iA, voff, d);
+    glds16(iA + 1024, voff, d + 1024u);
+#elif defined(FM_EXP_NODMA)
+    (void)d;
+#elif FM_GLDS_MODE == 2
+    glds16_pair(iA, voff, d);
+    glds16_pair(iW, voff, d + Cfg::WOFF);
+#elif FM_GLDS_MODE == 1
+    glds16_m0(iA, voff, d);
+    glds16_m0(iA + 1024, voff, d + 1024u);
+    glds16_m0(iW, voff, d + Cfg::WOFF);
+    glds16_m0(iW + 1024, voff, d + Cfg::WOFF + 1024u);
+#else
     glds16(iA, voff, d);
     glds16(iA + 1024, voff, d + 1024u);
     glds16(iW, voff, d + Cfg::WOFF);
     glds16(iW + 1024, voff, d + Cfg::WOFF + 1024u);
+#endif
     islot = islot == (Cfg::NSLOT - 1) * SLOT ? 0u : islot + SLOT;
     iA += 2048; iW += 2048;
     if (++ih == nh) { ih = 0; ++it; set_issue_tile(it < T ? it : 0); }   // past the last tile: re-loads of tile 0 into free slots keep the counts uniform
@@ -123,6 +164,9 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
 
   bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
   f32x16 acc[4][2];
+#ifdef FM_EXP_NOREAD
+#define FM_READ(s_) { (void)(s_); }
+#else
 #define FM_READ(s_)                                                                                                    \
   {                                                                                                                    \
     const uint32_t pa = pa0 + (s_), pb = pb0 + (s_);                                                                   \
@@ -134,18 +178,29 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
                    "=&v"(fa1[0]), "=&v"(fa1[1]), "=&v"(fa1[2]), "=&v"(fa1[3]), "=&v"(fb1[0]), "=&v"(fb1[1])             \
                  : "v"(pa), "v"(pb) : "memory");                                                                       \
   }
+#endif
 #define FM_LGKM0()                                                                                                     \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
                : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fa1[0]),      \
                  "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fb1[0]), "+v"(fb1[1]) :: "memory")
+#ifdef FM_EXP_NOMFMA
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, x_, y_, z_) (c_)
+#endif
+#ifdef FM_SETPRIO
+#define FM_PRIO(x_) __builtin_amdgcn_s_setprio(x_)
+#else
+#define FM_PRIO(x_) (void)0
+#endif
 #define FM_MUL()                                                                                                       \
   {                                                                                                                    \
+    FM_PRIO(1);                                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                       \
+    FM_PRIO(0);                                                                                                        \
   }
 #define FM_MUL_FIRST()                                                                                                 \
   {                                                                                                                    \
