@@ -377,6 +377,12 @@ class PackedMLP(object):
             assert k.shape[0] % 32 == 0, (i, k.shape)
             self.w.append(torch.from_numpy(np.ascontiguousarray(k.T)).to(self.device).to(torch.bfloat16).contiguous())
             self.b.append(torch.from_numpy(np.asarray(b, np.float32)).to(self.device))
+        # fm copies of the wide layers' operands (trunk, bottleneck head) for mlp_forward_fm
+        self.w_fm = {}
+        if USE_FM and W % 256 == 0:
+            for i in list(range(depth)) + ([] if cfg['disable_rgb'] else [depth + 1]):
+                self.w_fm[i] = to_fm(self.w[i])
+        self.mask_scratch = None
 
 
 def mlp_forward(pk, enc_buf, rows, viewdirs=None, n_rays=None, n_samples=None):
@@ -403,6 +409,44 @@ def mlp_forward(pk, enc_buf, rows, viewdirs=None, n_rays=None, n_samples=None):
         return density[:, 0], None
     view_in = torch.empty(rows, BOTTLENECK + DIR_LD, dtype=torch.bfloat16, device=dev)
     linear(x, pk.w[depth + 1], pk.b[depth + 1], act=0, out_bf16=view_in, m=rows, n=BOTTLENECK, k=x_k)
+    _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0), BOTTLENECK,
+                                   DIR_LD), 'mip360_dir_encode')
+    h = torch.empty(rows, VIEW_WIDTH, dtype=torch.bfloat16, device=dev)
+    linear(view_in, pk.w[depth + 2], pk.b[depth + 2], act=1, out_bf16=h, m=rows, n=VIEW_WIDTH, k=BOTTLENECK + DIR_LD)
+    rgb = torch.empty(rows, 3, device=dev)
+    linear(h, pk.w[depth + 3], pk.b[depth + 3], act=3, act_param=RGB_PADDING, out_f32=rgb, m=rows, n=3, k=VIEW_WIDTH)
+    return density[:, 0], rgb
+
+
+def mlp_forward_fm(pk, enc_buf, rows, viewdirs=None, n_rays=None, n_samples=None):
+    """mlp_forward with the trunk in the fm layout (enc_buf: fm tensor [rows, W + 512], columns [W, W + 512) from
+    cast_encode_fm); the ReLU bit masks of the layers go to one scratch buffer nobody reads."""
+    cfg = pk.cfg
+    W, depth = cfg['net_width'], cfg['net_depth']
+    dev = enc_buf.device
+    ld_enc = W + IPE_LD
+    nbytes = lib().mip360_fm_mask_bytes(int(rows), int(W))
+    if pk.mask_scratch is None or pk.mask_scratch.numel() < nbytes:
+        pk.mask_scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ping = [fm_buffer(rows, W, dev) for _ in range(2)]
+    x, x_col0, x_ld, x_k, nxt = enc_buf, W, ld_enc, IPE_LD, 0
+    for i in range(depth):
+        skip_out = (i % SKIP_LAYER == 0 and i > 0)
+        out, out_ld = (enc_buf, ld_enc) if skip_out else (ping[nxt], W)
+        linear_fm(x, pk.w_fm[i], pk.b[i], 1, rows, W, x_k, out, pk.mask_scratch, lda=x_ld, ldw=pk.w[i].shape[1], ldc=out_ld, a_col0=x_col0)
+        if skip_out:
+            x, x_col0, x_ld, x_k = enc_buf, 0, ld_enc, W + IPE_LD
+        else:
+            x, x_col0, x_ld, x_k, nxt = out, 0, W, W, nxt ^ 1
+    density = torch.empty(rows, 1, device=dev)
+    _check(lib().mip360_rowdot_fm(_stream(), rows, x_k, _fm_ptr(x, x_col0), x_ld, _p(pk.w[depth]), _p(pk.b[depth]), 2, DENSITY_BIAS,
+                                  _p(density), 1), 'mip360_rowdot_fm')
+    if cfg['disable_rgb']:
+        return density[:, 0], None
+    bott = fm_buffer(rows, BOTTLENECK, dev)
+    linear_fm(x, pk.w_fm[depth + 1], pk.b[depth + 1], 0, rows, BOTTLENECK, x_k, bott, None, lda=x_ld, ldw=x_k, a_col0=x_col0)
+    view_in = torch.empty(rows, BOTTLENECK + DIR_LD, dtype=torch.bfloat16, device=dev)
+    from_fm(bott, rows, BOTTLENECK, out=view_in)
     _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0), BOTTLENECK,
                                    DIR_LD), 'mip360_dir_encode')
     h = torch.empty(rows, VIEW_WIDTH, dtype=torch.bfloat16, device=dev)
@@ -448,10 +492,15 @@ class Mip360Model(object):
             pk = self.prop if is_prop else self.nerf
             W = pk.cfg['net_width']
             rows = n * ns
-            enc_buf = torch.empty(rows, W + IPE_LD, dtype=torch.bfloat16, device=dev)
-            cast_encode(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, out=enc_buf[:, W:],
-                        ld=W + IPE_LD)
-            density, rgb = mlp_forward(pk, enc_buf, rows, rays['viewdirs'], n, ns)
+            if fm_ok(rows, W) and pk.w_fm:
+                enc_buf = fm_buffer(rows, W + IPE_LD, dev)
+                cast_encode_fm(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, enc_buf, W, W + IPE_LD)
+                density, rgb = mlp_forward_fm(pk, enc_buf, rows, rays['viewdirs'], n, ns)
+            else:
+                enc_buf = torch.empty(rows, W + IPE_LD, dtype=torch.bfloat16, device=dev)
+                cast_encode(tdist, rays['origins'], rays['directions'], rays['radii'], self.basis_t, out=enc_buf[:, W:],
+                            ld=W + IPE_LD)
+                density, rgb = mlp_forward(pk, enc_buf, rows, rays['viewdirs'], n, ns)
             density = density.reshape(n, ns)
             rgb_s = rgb.reshape(n, ns, 3) if rgb is not None else None
             r = render_level(density, rgb_s, tdist, rays['directions'], True, c['bg_rgb'])

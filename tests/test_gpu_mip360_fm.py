@@ -314,3 +314,23 @@ def test_trainer_takes_the_same_steps_on_both_paths(M, monkeypatch):
     assert np.isfinite(losses['fm']).all() and np.isfinite(losses['rm']).all()
     np.testing.assert_allclose(losses['fm'], losses['rm'], rtol=3e-2, atol=1e-4)
     assert losses['fm'][-1, 1] < losses['fm'][0, 1]                                 # the data term goes down
+
+
+def test_model_forward_on_both_paths(M, monkeypatch):
+    """Mip360Model.forward (inference: no masks kept) with the trunk fm against the row-major kernels: renderings to bf16 grade."""
+    from outdoor_nerf_depth_amd import mip360 as mod
+    rs = np.random.RandomState(9)
+    n = 64
+    rays = {k: T(v) for k, v in _rays(rs, n).items()}
+    prs = np.random.RandomState(1)
+    pp, pn = O.init_mlp_params(O.PROP_CFG, prs), O.init_mlp_params(O.NERF_CFG, prs)
+    out = {}
+    for kind in ('fm', 'rm'):
+        monkeypatch.setattr(mod, 'USE_FM', kind == 'fm')
+        model = mod.Mip360Model(pp, pn, dev())
+        assert bool(model.nerf.w_fm) == (kind == 'fm')
+        rend, hist = model.forward(rays, train_frac=0.5)
+        out[kind] = (N(rend[-1]['rgb']), N(rend[-1]['distance_mean']), N(hist[-1]['weights']))
+    np.testing.assert_allclose(out['fm'][0], out['rm'][0], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(out['fm'][1], out['rm'][1], rtol=2e-2, atol=1e-3)
+    np.testing.assert_allclose(out['fm'][2], out['rm'][2], rtol=0, atol=5e-3)
