@@ -902,7 +902,10 @@ class Mip360Trainer(object):
         self.step = 0
         self.overlap_update = True
         self._update_stream = torch.cuda.Stream(device=self.device)
+        self._prop_stream = torch.cuda.Stream(device=self.device)
+        self.concurrent_prop_backward = True       # proposal levels' backward on its own stream (False: after the NeRF level's)
         self.scratch = [None, None]
+        self.scratch_prop = [None, None]
         self.partials = torch.empty(2, 256, device=self.device)
         self.clip = torch.empty(2, 2, device=self.device)
 
@@ -980,10 +983,38 @@ class Mip360Trainer(object):
             [p['weights'] for p in props], depth_loss_type=self.depth_loss_type, lambda_depth=self.lambda_depth,
             dm_prop=[p['distance_mean'] for p in props] if self.depth_loss_type else None, tdist_nerf=nerf['tdist'],
             tdist_prop=[p['tdist'] for p in props], directions=rays['directions'], depth_sigma=self.depth_sigma)
-        # NeRF level
-        gd, grgbs = render_level_backward(nerf['density'], nerf['rgb_s'], nerf['tdist'], rays['directions'], g_wn, g_rgb, g_dm,
-                                          True, self.cfg['bg_rgb'])
-        mlp_backward(self.nerf, nerf['saved'], nerf['rows'], gd, grgbs, self.scratch)
+        def prop_backward():
+            # proposal levels share the PropMLP: gradients add up
+            acc = None
+            for k, p in enumerate(props):
+                gd, _ = render_level_backward(p['density'], None, p['tdist'], rays['directions'], g_wp[k], None,
+                                              g_dmp[k] if g_dmp else None, True, self.cfg['bg_rgb'])
+                mlp_backward(self.prop, p['saved'], p['rows'], gd, None, self.scratch_prop)
+                acc = self.prop.grads.clone() if acc is None else acc.add_(self.prop.grads)
+            self.prop.grads.copy_(acc)
+
+        def nerf_backward():
+            gd, grgbs = render_level_backward(nerf['density'], nerf['rgb_s'], nerf['tdist'], rays['directions'], g_wn, g_rgb, g_dm,
+                                              True, self.cfg['bg_rgb'])
+            mlp_backward(self.nerf, nerf['saved'], nerf['rows'], gd, grgbs, self.scratch)
+
+        if self.concurrent_prop_backward:
+            # The proposal levels' backward depends on the losses only (stop-gradient between the levels, models.py:210-214), not
+            # on the NeRF level's: it runs on its own stream next to the NerfMLP's backward GEMMs and fills their tails.
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record()
+            self._prop_stream.wait_event(ev)
+            with torch.cuda.stream(self._prop_stream):
+                prop_backward()
+                self._apply_one(1, self.prop)
+                prop_done = torch.cuda.Event()
+                prop_done.record()
+            nerf_backward()
+            self._apply_one(0, self.nerf)
+            main.wait_event(prop_done)
+            return sc
+        nerf_backward()
         # the NerfMLP's update (all-reduce, norm, clip, Adam, 12 re-pack launches: 0.2 ms of short kernels) runs on a
         # side stream under the proposal levels' backward GEMMs; joined at the end of the step
         side = self._update_stream if self.overlap_update else None
@@ -995,14 +1026,7 @@ class Mip360Trainer(object):
                 self._apply_one(0, self.nerf)
                 done = torch.cuda.Event()
                 done.record()
-        # proposal levels share the PropMLP: gradients add up
-        acc = None
-        for k, p in enumerate(props):
-            gd, _ = render_level_backward(p['density'], None, p['tdist'], rays['directions'], g_wp[k], None,
-                                          g_dmp[k] if g_dmp else None, True, self.cfg['bg_rgb'])
-            mlp_backward(self.prop, p['saved'], p['rows'], gd, None, self.scratch)
-            acc = self.prop.grads.clone() if acc is None else acc.add_(self.prop.grads)
-        self.prop.grads.copy_(acc)
+        prop_backward()
         if side is not None:
             self._apply_one(1, self.prop)
             torch.cuda.current_stream().wait_event(done)
