@@ -5,6 +5,8 @@ level 0 draws stratified depths, level 1 re-samples from level 0's (detached) we
 has its own net, its own Adam state and its own gradient all-reduce (DDP averages gradients,
 :323); the depth term is added when --use_depth (:486-493).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -74,6 +76,8 @@ class NerfppTrainer(object):
         # sampling + forward; the main stream waits for it right before the level's streams are used again, i.e. at
         # the same level of the next step.  overlap_allreduce=False keeps everything on the caller's stream.
         self.update_stream = torch.cuda.Stream(device=self.device) if overlap_allreduce else None
+        self.level_streams = [torch.cuda.Stream(device=self.device) for _ in range(len(self.cascade_samples))] if overlap_allreduce else None
+        self.concurrent_backward = True     # level 0's backward on its own stream under level 1's forward (False: inline)
         self._pending = {}                # level -> event recorded after its update on the side stream
         # diagnostic (bench.py, N > 1): when a list, every _update_end appends a (before, after) timing-event pair around
         # the main stream's wait for the side-stream update -- the part of [slab sum, all-reduce, Adam, re-pack] that the
@@ -235,6 +239,24 @@ class NerfppTrainer(object):
                 rows[ae_idx, 2] = 1.0
                 self._ae_grad[m] = rows
                 self.last_autoexpo[m] = ae.scale_shift(ae_idx)
+            if self.concurrent_backward and m + 1 < len(self.engines) and ae is None and ev is None and self.update_stream is not None:
+                # Level 1 needs level 0's FORWARD only (its weights, detached: ddp_train_nerf.py:452-457): level 0's backward, weight
+                # gradients and update run on their own stream under level 1's sampling and forward (HBM-bound weight gradients
+                # next to the forward kernels).  Measured: -1.1 % per step; the last level's backward under the NEXT step's
+                # level 0 as well: no further gain (+-0.5 %).  _update_end(m) / flush() order later readers.
+                stream = self.level_streams[m]
+                fwd_done = torch.cuda.Event()
+                fwd_done.record()
+                stream.wait_event(fwd_done)
+                for t in [g_rgb, g_depth, g_w, ray_o, ray_d, far, fg_z, bg_z, batch['rgb'], depth_sup] + list(ret.values()):
+                    if torch.is_tensor(t):
+                        t.record_stream(stream)               # (allocated on this stream, read on the level's)
+                with torch.cuda.stream(stream):
+                    eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS],
+                                 defer_reduce=True)
+                    self._update_begin(m)
+                scalars.append(sc)
+                continue
             eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS],
                          events=ev['bwd'] if ev else None, defer_reduce=True)
             scalars.append(sc)

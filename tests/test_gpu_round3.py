@@ -183,14 +183,17 @@ def test_saved_activations_in_the_workspace_match_the_oracle(ops, precision):
     tol = dict(rtol=2e-2, atol=2e-2) if precision == 1 else dict(rtol=3e-5, atol=3e-5)
     for net, key in ((0, 'fg'), (1, 'bg')):
         c = cache[key]
+        # (the oracle flips the background network's input rows along S like ddp_model.py:116-117; the kernels keep a ray's
+        # samples in bg_z order and composite them back to front: the saved rows are the oracle's, reversed per ray)
+        order = (lambda a: a.reshape(n, S, -1)[:, ::-1].reshape(n * S, -1)) if net == 1 else (lambda a: a)
         for l in range(8):
             got = N(eng.saved_tensor(net, 1 + l))
             if precision == 2:
                 got = got + N(eng.saved_tensor(net, 1 + l, plane=1))          # hi + lo
-            want = np.maximum(c['pre'][l], 0)
+            want = order(np.maximum(c['pre'][l], 0))
             assert got.shape == want.shape == (n * S, 256)
             np.testing.assert_allclose(got, want, err_msg='net %d H%d' % (net, l), **tol)
         g = N(eng.saved_tensor(net, 10))
         if precision == 2:
             g = g + N(eng.saved_tensor(net, 10, plane=1))
-        np.testing.assert_allclose(g, c['g'], err_msg='net %d G' % net, **tol)
+        np.testing.assert_allclose(g, order(c['g']), err_msg='net %d G' % net, **tol)
