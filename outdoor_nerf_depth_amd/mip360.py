@@ -904,10 +904,27 @@ class Mip360Trainer(object):
         self._update_stream = torch.cuda.Stream(device=self.device)
         self._prop_stream = torch.cuda.Stream(device=self.device)
         self.concurrent_prop_backward = True       # proposal levels' backward on its own stream (False: after the NeRF level's)
+        # defer_update: train_step returns with the parameter updates still running on their streams -- the NerfMLP's under the
+        # next step's proposal levels (which read the PropMLP only).  The next step orders itself behind them; anything else that
+        # reads parameters, moments or gradients calls flush() first (as with NerfppTrainer).  Off: every step ends joined.
+        self.defer_update = False
+        self._pending = {}                         # 'prop' / 'nerf' -> event after that MLP's update
+        self._keep_alive = None                    # the previous step's tensors the side streams may still be reading
         self.scratch = [None, None]
         self.scratch_prop = [None, None]
         self.partials = torch.empty(2, 256, device=self.device)
         self.clip = torch.empty(2, 2, device=self.device)
+
+    def _join(self, which):
+        ev = self._pending.pop(which, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def flush(self):
+        """Order the caller's stream behind the parameter updates of the last step (defer_update)."""
+        self._join('prop')
+        self._join('nerf')
+        self._keep_alive = None
 
     def forward(self, rays, train_frac, jitter01, training=True):
         c = self.cfg
@@ -927,6 +944,7 @@ class Mip360Trainer(object):
             sdist, tdist = resample(sdist, weights, dilation if lvl > 0 else 0.0, anneal, ns, rays['near'], rays['far'],
                                     None if jitter01 is None else jitter01[lvl])
             tm = self.prop if is_prop else self.nerf
+            self._join('prop' if is_prop else 'nerf')            # (deferred update of the previous step)
             rows = n * ns
             if fm_ok(rows, tm.W) and tm.w_fm:
                 enc_buf = fm_buffer(rows, tm.W + IPE_LD, dev)
@@ -972,6 +990,8 @@ class Mip360Trainer(object):
     def train_step(self, rays, rgb_gt, depth_sup, jitter01=None):
         """rays / rgb_gt [n,3] / depth_sup [n] on the device.  Returns the scalars tensor of mip360_losses."""
         self.step += 1
+        self._join('prop')                         # the previous step's proposal backward has left its tensors
+        self._keep_alive = None
         train_frac = float(np.clip((self.step - 1) / (self.max_steps - 1), 0, 1))          # train.py: step / max_steps
         if jitter01 is None:
             n = rays['origins'].shape[0]
@@ -1011,6 +1031,17 @@ class Mip360Trainer(object):
                 prop_done = torch.cuda.Event()
                 prop_done.record()
             nerf_backward()
+            if self.defer_update:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._update_stream.wait_event(ev)
+                with torch.cuda.stream(self._update_stream):
+                    self._apply_one(0, self.nerf)
+                    nerf_done = torch.cuda.Event()
+                    nerf_done.record()
+                self._pending = {'prop': prop_done, 'nerf': nerf_done}
+                self._keep_alive = (lv, g_wp, g_dmp, rays, jitter01)
+                return sc
             self._apply_one(0, self.nerf)
             main.wait_event(prop_done)
             return sc
@@ -1072,11 +1103,13 @@ def benchmark_step(device, n_rays=4096, steps=10, warmup=3, forward_only=False, 
     gt = T(rs.rand(n, 3).astype(np.float32))
     sup = T(np.where(rs.rand(n) < .5, rs.uniform(1, 6, n), 0).astype(np.float32))
     tr = Mip360Trainer(prop, nerf, device, world_size=world_size)
+    tr.defer_update = True                      # updates pipelined under the next step; tr.flush() belongs to the timed region
     macs = lambda sh: sum(i * o for i, o in sh)
     fwd_flop = 2.0 * (2 * 64 * macs(mlp_shapes(PROP_CFG)) + 32 * macs(mlp_shapes(NERF_CFG)))
     step = (lambda: tr.forward(rays, 0.5, None)) if forward_only else (lambda: tr.train_step(rays, gt, sup))
     for _ in range(warmup):
         step()
+    tr.flush()
     torch.cuda.synchronize(device)
     if world_size > 1:
         import torch.distributed as dist
@@ -1084,6 +1117,7 @@ def benchmark_step(device, n_rays=4096, steps=10, warmup=3, forward_only=False, 
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    tr.flush()
     torch.cuda.synchronize(device)
     if world_size > 1:
         dist.barrier()

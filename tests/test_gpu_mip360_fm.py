@@ -334,3 +334,27 @@ def test_model_forward_on_both_paths(M, monkeypatch):
     np.testing.assert_allclose(out['fm'][0], out['rm'][0], rtol=0, atol=5e-3)
     np.testing.assert_allclose(out['fm'][1], out['rm'][1], rtol=2e-2, atol=1e-3)
     np.testing.assert_allclose(out['fm'][2], out['rm'][2], rtol=0, atol=5e-3)
+
+
+def test_deferred_updates_and_concurrent_backward_change_no_bit(M):
+    """Mip360Trainer options that only move work between streams: proposal backward on its own stream (default) vs after the NeRF
+    level's; updates joined at the end of every step (default) vs pipelined under the next step (defer_update + flush()).
+    Parameters and Adam moments after three steps are bit-identical."""
+    rs = np.random.RandomState(5)
+    n = 64
+    rays = {k: T(v) for k, v in _rays(rs, n).items()}
+    gt = T(rs.rand(n, 3).astype(np.float32))
+    sup = T((0.5 + rs.rand(n)).astype(np.float32))
+    jit = [[T(np.random.RandomState(10 * s + l).rand(n).astype(np.float32)) for l in range(3)] for s in range(3)]
+    finals = []
+    for concurrent, defer in ((True, False), (False, False), (True, True)):
+        prs = np.random.RandomState(7)
+        tr = M.Mip360Trainer(O.init_mlp_params(O.PROP_CFG, prs), O.init_mlp_params(O.NERF_CFG, prs), dev(), max_steps=1000)
+        tr.concurrent_prop_backward, tr.defer_update = concurrent, defer
+        for s in range(3):
+            tr.train_step(rays, gt, sup, jitter01=jit[s])
+        tr.flush()
+        finals.append([N(t) for t in (tr.nerf.flat, tr.prop.flat, tr.nerf.mu, tr.prop.nu)])
+    for other in finals[1:]:
+        for a, b in zip(finals[0], other):
+            np.testing.assert_array_equal(a, b)
