@@ -182,7 +182,8 @@ def run_mode(args, precision, rank, world, device, batches):
     K, W = args.steps, args.warmup
     # live kernel taps: HIP events recorded by the library around the level-1 kernel groups (both nets), on the
     # launch stream, inside the timed region.  An event record costs ~6 us of queue time, so only every TAP-th
-    # timed step carries them (>= 3 tapped steps) and level 0 is not tapped.
+    # timed step carries them (>= 3 tapped steps) and level 0 is not tapped.  A tapped step runs level 0's backward inline
+    # instead of under level 1's forward (NerfppTrainer.concurrent_backward: ~1 % of a step), so a tap times its group alone.
     mk = lambda: torch.cuda.Event(enable_timing=True)
     TAP = max(1, min(4, K // 3))
     tapped = [i for i in range(K) if i % TAP == 0]

@@ -239,11 +239,12 @@ class NerfppTrainer(object):
                 rows[ae_idx, 2] = 1.0
                 self._ae_grad[m] = rows
                 self.last_autoexpo[m] = ae.scale_shift(ae_idx)
-            if self.concurrent_backward and m + 1 < len(self.engines) and ae is None and ev is None and self.update_stream is not None:
+            if self.concurrent_backward and m + 1 < len(self.engines) and ae is None and events is None and self.update_stream is not None:
                 # Level 1 needs level 0's FORWARD only (its weights, detached: ddp_train_nerf.py:452-457): level 0's backward, weight
                 # gradients and update run on their own stream under level 1's sampling and forward (HBM-bound weight gradients
                 # next to the forward kernels).  Measured: -1.1 % per step; the last level's backward under the NEXT step's
-                # level 0 as well: no further gain (+-0.5 %).  _update_end(m) / flush() order later readers.
+                # level 0 as well: no further gain (+-0.5 %).  _update_end(m) / flush() order later readers.  A step that carries
+                # event taps runs inline, so that a tap times its kernel group alone on the GPU.
                 stream = self.level_streams[m]
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
