@@ -358,3 +358,27 @@ def test_deferred_updates_and_concurrent_backward_change_no_bit(M):
     for other in finals[1:]:
         for a, b in zip(finals[0], other):
             np.testing.assert_array_equal(a, b)
+
+
+def test_row_counts_the_fm_kernels_do_not_take_fall_back_to_row_major(M, monkeypatch):
+    """33 rays x 64 / 32 samples = 2112 / 1056 rows: not multiples of 256, so every level runs on the row-major kernels although
+    the fm operand copies exist -- bit-identical to a trainer built with USE_FM off, and the lazily skipped row-major weight
+    copies are refreshed before those kernels read them (the second and third step would diverge otherwise)."""
+    from outdoor_nerf_depth_amd import mip360 as mod
+    rs = np.random.RandomState(8)
+    n = 33
+    rays = {k: T(v) for k, v in _rays(rs, n).items()}
+    gt = T(rs.rand(n, 3).astype(np.float32))
+    sup = T((0.5 + rs.rand(n)).astype(np.float32))
+    jit = [T(rs.rand(n).astype(np.float32)) for _ in range(3)]
+    finals = []
+    for use_fm in (True, False):
+        monkeypatch.setattr(mod, 'USE_FM', use_fm)
+        prs = np.random.RandomState(7)
+        tr = mod.Mip360Trainer(O.init_mlp_params(O.PROP_CFG, prs), O.init_mlp_params(O.NERF_CFG, prs), dev(), max_steps=1000)
+        assert bool(tr.nerf.w_fm) == use_fm
+        hist = [N(tr.train_step(rays, gt, sup, jitter01=jit)) for _ in range(3)]
+        assert np.isfinite(hist).all()
+        finals.append((N(tr.nerf.flat), N(tr.prop.flat)))
+    np.testing.assert_array_equal(finals[0][0], finals[1][0])
+    np.testing.assert_array_equal(finals[0][1], finals[1][1])
