@@ -159,7 +159,7 @@ int mip360_linear_masked_bf16(void* stream, int m, int n, int k, const void* a, 
  *   mip360_to_fm / mip360_from_fm : row-major bf16 [rows, cols] (row stride ld_src / ld_dst elements) <-> columns
  *       [col0, col0 + cols) of an fm tensor with ld columns.
  *   mip360_linear_fm : C = act(A W^T + b); A [m, k], W [n, k], C [m, n] all fm; m, n multiples of 256, k a multiple of
- *       32 (>= 128).  act 0: bias only; 1: ReLU, and one bit per output (non-zero) to `mask` (mip360_fm_mask_bytes
+ *       32 (>= 160).  act 0: bias only; 1: ReLU, and one bit per output (non-zero) to `mask` (mip360_fm_mask_bytes
  *       bytes); 2: no bias, outputs whose bit in `mask` (written by an act-1 call with the same m, n) is clear are
  *       zeroed -- the dX chain.  The bias is added by the matrix cores as bf16 hi + lo (2^-17 relative). */
 int mip360_to_fm(void* stream, int rows, int cols, const void* src_bf16, int ld_src, void* dst_fm, int ld_dst, int col0_dst);

@@ -237,7 +237,7 @@ int mip360_linear_fm(void* stream, int m, int n, int k, const void* a_fm, int ld
   REQUIRE(a_fm && w_fm && c_fm, "non-null operands and output");
   REQUIRE(lda >= k && ldw >= k && ldc >= n, "leading dimensions >= k / n");
   REQUIRE(mip360_launch_linear_fm((hipStream_t)stream, m, n, k, a_fm, lda, w_fm, ldw, bias, act, c_fm, ldc, mask) == 0,
-          "m, n multiples of 256; k a multiple of 32, >= 128; leading dimensions multiples of 16; act 0 / 1 need bias, 1 / 2 the mask");
+          "m, n multiples of 256; k a multiple of 32, >= 160; leading dimensions multiples of 16; act 0 / 1 need bias, 1 / 2 the mask");
   return check_launch("linear_fm");
 }
 

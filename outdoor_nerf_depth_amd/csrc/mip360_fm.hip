@@ -127,7 +127,7 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, grp = wm;            // group 0 = waves 0-3 = tile rows 0-127
   const int tiles_n = N >> 8, tiles_m = M >> 8, tiles = tiles_m * tiles_n;
-  const int nh = K >> 5;                                        // half-steps (32 k-elements) per tile, >= 4
+  const int nh = K >> 5;                                        // half-steps (32 k-elements) per tile, > AHEAD
   const int T = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)fm_smem;
   const int row = lane & 31, hi = lane >> 5;
@@ -341,47 +341,65 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   // Schedule (x = half-step counted over all tiles of the workgroup):
   //   group 0: [MUL(x), wait] | [read(x + 1), DMA(x + 5)]          group 1: [read(x), DMA(x + 4), wait] | [MUL(x)]
   // "wait" = own DMA of half-step x + 1 has landed (3 younger half-steps of 4 instructions may be out; + NE while the
-  // epilogue's instructions are younger than it, i.e. for the first three half-steps of a tile; the first tile's were
-  // awaited by the prologue; with a 4-slot ring: 2 younger half-steps, two peeled half-steps).  The barrier after it publishes x + 1 to both groups one phase before they read it.
+  // epilogue's instructions are younger than it, i.e. for the first AHEAD half-steps of a tile -- the DMA of the phase that holds
+  // the epilogue is issued ahead of its stores; the first tile's first AHEAD - 1 were awaited by the prologue).  The barrier after it publishes x + 1 to both groups one phase before they read it.
+  // The wait of half-step AHEAD - 1 of a tile targets the first DMA issued after the tile switch: behind the previous tile's
+  // epilogue in every tile but the first (whose prologue did not cover it).
+#define FM_VM_LASTPEEL() { if (t > 0) { FM_VMCNT(VM_PEEL); } else { FM_VMCNT(VM_STEADY); } }
   if (grp == 0) {
     FM_READ(cs); issue(); FM_LGKM0(); cs = next_slot(cs);
     FM_PHASE_END();
     for (int t = 0; t < T; ++t) {
-#define FM_G0_STEP(MUL_, VM_, TAIL_)                                                                                   \
+#define FM_G0_STEP(MUL_, WAIT_)                                                                                        \
       MUL_;                                                                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
-      FM_VMCNT(VM_);                                                                                                   \
+      WAIT_;                                                                                                           \
       FM_PHASE_END();                                                                                                  \
-      TAIL_;                                                                                                           \
       FM_READ(cs); issue(); FM_LGKM0(); cs = next_slot(cs);                                                            \
       FM_PHASE_END();
-      FM_G0_STEP(FM_MUL_FIRST(), VM_PEEL, (void)0);
-      FM_G0_STEP(FM_MUL(), VM_PEEL, (void)0);
-      if constexpr (AHEAD == 4) { FM_G0_STEP(FM_MUL(), VM_PEEL, (void)0); }
-      for (int h = AHEAD - 1; h < nh - 1; ++h) { FM_G0_STEP(FM_MUL(), VM_STEADY, (void)0); }
-      FM_G0_STEP({ FM_MUL(); bias_mfma(); }, VM_STEADY, { epilogue(t); preload(t + 1); });
+      // the last half-step of a tile: the DMA of this phase is issued BEFORE the epilogue's stores (it is then older than they
+      // are: one more half-step before a wait needs them retired)
+#define FM_G0_LAST(WAIT_)                                                                                              \
+      FM_MUL(); bias_mfma();                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      WAIT_;                                                                                                           \
+      FM_PHASE_END();                                                                                                  \
+      issue(); epilogue(t); preload(t + 1);                                                                            \
+      FM_READ(cs); FM_LGKM0(); cs = next_slot(cs);                                                                     \
+      FM_PHASE_END();
+      FM_G0_STEP(FM_MUL_FIRST(), FM_VMCNT(VM_PEEL));
+      FM_G0_STEP(FM_MUL(), FM_VMCNT(VM_PEEL));
+      if constexpr (AHEAD == 4) { FM_G0_STEP(FM_MUL(), FM_VMCNT(VM_PEEL)); }
+      FM_G0_STEP(FM_MUL(), FM_VM_LASTPEEL());
+      for (int h = AHEAD; h < nh - 1; ++h) { FM_G0_STEP(FM_MUL(), FM_VMCNT(VM_STEADY)); }
+      FM_G0_LAST(FM_VMCNT(VM_STEADY));
     }
   } else {
     FM_PHASE_END();
     for (int t = 0; t < T; ++t) {
-#define FM_G1_STEP(MUL_, VM_)                                                                                          \
-      FM_READ(cs); issue(); FM_LGKM0(); cs = next_slot(cs);                                                            \
-      FM_VMCNT(VM_);                                                                                                   \
+#define FM_G1_STEP(ISSUE_, MUL_, WAIT_)                                                                                \
+      FM_READ(cs); ISSUE_; FM_LGKM0(); cs = next_slot(cs);                                                             \
+      WAIT_;                                                                                                           \
       FM_PHASE_END();                                                                                                  \
       MUL_;                                                                                                            \
       FM_PHASE_END();
-      FM_G1_STEP(FM_MUL_FIRST(), VM_PEEL);
-      FM_G1_STEP(FM_MUL(), VM_PEEL);
-      if constexpr (AHEAD == 4) { FM_G1_STEP(FM_MUL(), VM_PEEL); }
-      for (int h = AHEAD - 1; h < nh - 1; ++h) { FM_G1_STEP(FM_MUL(), VM_STEADY); }
-      FM_G1_STEP({ FM_MUL(); bias_mfma(); }, VM_STEADY);
+      // (the first half-step's DMA of every tile but the first was issued ahead of the previous tile's epilogue, below)
+      FM_G1_STEP({ if (t == 0) issue(); }, FM_MUL_FIRST(), FM_VMCNT(VM_PEEL));
+      FM_G1_STEP(issue(), FM_MUL(), FM_VMCNT(VM_PEEL));
+      if constexpr (AHEAD == 4) { FM_G1_STEP(issue(), FM_MUL(), FM_VMCNT(VM_PEEL)); }
+      FM_G1_STEP(issue(), FM_MUL(), FM_VM_LASTPEEL());
+      for (int h = AHEAD; h < nh - 1; ++h) { FM_G1_STEP(issue(), FM_MUL(), FM_VMCNT(VM_STEADY)); }
+      FM_G1_STEP(issue(), { FM_MUL(); bias_mfma(); }, FM_VMCNT(VM_STEADY));
+      issue();
       epilogue(t);
       preload(t + 1);
     }
   }
   FM_VMCNT(0);
 #undef FM_G0_STEP
+#undef FM_G0_LAST
 #undef FM_G1_STEP
+#undef FM_VM_LASTPEEL
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -746,11 +764,11 @@ static int fm_n_cu() {
   return n_cu;
 }
 
-// M, N multiples of 256; K a multiple of 32, >= 128; lda / ldw / ldc multiples of 16 (columns of the fm tensors)
+// M, N multiples of 256; K a multiple of 32, >= 160 (more half-steps than the ring is deep); lda / ldw / ldc multiples of 16
 int mip360_launch_linear_fm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                             int act, void* C, int ldc, void* mask) {
   using namespace mip360fm;
-  if (M <= 0 || N <= 0 || M % 256 || N % 256 || K % 32 || K < 128 || lda % 16 || ldw % 16 || ldc % 16) return 1;
+  if (M <= 0 || N <= 0 || M % 256 || N % 256 || K % 32 || K < 32 * (Cfg::NSLOT) || lda % 16 || ldw % 16 || ldc % 16) return 1;
   if ((act == 2 && !mask) || (act != 2 && !bias) || (act == 1 && !mask) || act < 0 || act > 2) return 1;
   static bool attr_set = false;
   if (!attr_set) {

@@ -71,7 +71,7 @@ def test_to_fm_from_fm_follow_the_documented_formula(M):
 
 
 # ------------------------------------------------------------------------------------------------------------ dense layers
-@pytest.mark.parametrize('m,n,k', [(256, 256, 128), (512, 512, 320), (1024, 256, 512), (66 * 256, 256, 256), (2048, 1024, 1536)])
+@pytest.mark.parametrize('m,n,k', [(256, 256, 160), (512, 512, 320), (1024, 256, 512), (66 * 256, 256, 256), (2048, 1024, 1536)])
 def test_linear_fm_against_float64(M, m, n, k):
     """(66 * 256 rows x 1 column tile: more tiles than one round of workgroups on any grid <= 64 -- the ring runs across
     tile boundaries; 2048 x 1024 x 1536: the skip layer's shape)"""
@@ -116,11 +116,11 @@ def test_linear_fm_column_windows_of_wider_tensors(M):
 def test_linear_fm_rejects_shapes_it_does_not_take(M):
     x = torch.zeros(256 * 256, dtype=torch.bfloat16, device=dev())
     b = torch.zeros(256, device=dev())
-    for (m, n, k) in [(255, 256, 128), (256, 128, 128), (256, 256, 96), (256, 256, 144)]:
+    for (m, n, k) in [(255, 256, 160), (256, 128, 160), (256, 256, 128), (256, 256, 176)]:
         with pytest.raises(M.Mip360Error):
             M.linear_fm(x, x, b, 0, m, n, k, x, None)
     with pytest.raises(M.Mip360Error):
-        M.linear_fm(x, x, b, 1, 256, 256, 128, x, None)           # ReLU needs somewhere to put the mask
+        M.linear_fm(x, x, b, 1, 256, 256, 160, x, None)           # ReLU needs somewhere to put the mask
 
 
 # ------------------------------------------------------------------------------------------------------------ gradients
@@ -183,7 +183,7 @@ def test_outer_masked_fm_equals_the_gemm_it_replaces(M):
     """PropMLP: dZ of the last trunk layer = mask * (d_raw (x) w_density): bit for bit what mip360_linear_fm act 2 gives for an
     operand whose only non-zero column is d_raw."""
     rs = np.random.RandomState(4)
-    m, n, k = 1024, 256, 128
+    m, n, k = 1024, 256, 160
     act = round_bf16(rs.randn(m, n).astype(np.float32))
     mask = M.fm_mask_buffer(m, n, dev())
     ident = np.zeros((n, n), np.float32)
