@@ -329,6 +329,11 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
     }
   };
 
+#ifdef FM_STAGGER
+  // probe: the workgroups of an XCD start in four classes FM_STAGGER x 3.4 us apart, so that their tile switches (4 MB of dirty
+  // lines per XCD when they coincide) do not
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * FM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   // ---- prologue: half-steps 0 .. AHEAD-1 and the first tile's side data, synchronously
   set_issue_tile(0);
 #pragma unroll
