@@ -27,6 +27,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// hipFuncSetAttribute is per device: remember which devices of this process have had it applied (one bit per device id)
+#include <atomic>
+static inline bool first_launch_on_this_device(std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (done.fetch_or(bit) & bit) == 0;
+}
+
 namespace mip360fm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -775,12 +784,11 @@ int mip360_launch_linear_fm(hipStream_t st, int M, int N, int K, const void* A, 
   using namespace mip360fm;
   if (M <= 0 || N <= 0 || M % 256 || N % 256 || K % 32 || K < 32 * (Cfg::NSLOT) || lda % 16 || ldw % 16 || ldc % 16) return 1;
   if ((act == 2 && !mask) || (act != 2 && !bias) || (act == 1 && !mask) || act < 0 || act > 2) return 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (first_launch_on_this_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)linear_fm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     (void)hipFuncSetAttribute((const void*)linear_fm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     (void)hipFuncSetAttribute((const void*)linear_fm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    attr_set = true;
   }
   const int tiles = (M / 256) * (N / 256), n_cu = fm_n_cu();
   const dim3 grid(tiles < n_cu ? tiles : n_cu), block(512);
@@ -814,11 +822,10 @@ int mip360_launch_grad_weight_fm(hipStream_t st, int M, int I, int O, const void
                                  float* slabs, int ldc, float* bias_slabs) {
   using namespace mip360fm;
   if (M <= 0 || M % 32 || I <= 0 || O <= 0 || I % 256 || O % 256 || ldh % 16 || lddz % 16 || ksplit < 1) return 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (first_launch_on_this_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)grad_weight_fm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GNBUF * GCHUNK);
     (void)hipFuncSetAttribute((const void*)grad_weight_fm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GNBUF * GCHUNK);
-    attr_set = true;
   }
   const dim3 grid((I / 256) * (O / 256) * ksplit);
   if (M / 32 / ksplit >= 96)                       // measured: ping-pong wins from ~100 chunks per slice (131072 rows / 16: -8 %), loses below (32 chunks: +10 %)

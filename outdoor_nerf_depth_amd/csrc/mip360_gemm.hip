@@ -16,6 +16,15 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// hipFuncSetAttribute is per device: remember which devices of this process have had it applied (one bit per device id)
+#include <atomic>
+static inline bool first_launch_on_this_device(std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (done.fetch_or(bit) & bit) == 0;
+}
+
 namespace mip360 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -797,11 +806,10 @@ static void launch_ring(hipStream_t st, int M, int N, int K, const void* A, int 
                         float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux, void* mask, int ldmask) {
   using namespace mip360;
   using Cfg = RingCfg<WM, WN, FM, FN, NBUF>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (first_launch_on_this_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)linear_bf16_ring_kernel<ACT, WM, WN, FM, FN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               Cfg::LDS);
-    attr_set = true;
   }
   const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
   hipLaunchKernelGGL((linear_bf16_ring_kernel<ACT, WM, WN, FM, FN, NBUF>), dim3(tiles), dim3(Cfg::NT), Cfg::LDS, st, M, N, K,
@@ -813,10 +821,9 @@ template <int ACT>
 static void launch_pp64(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* W, int ldw, const float* bias,
                         float act_param, void* C16, int ldc, float* C32, int ldc32, const void* aux, int ldaux, void* mask, int ldmask) {
   using namespace mip360;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (first_launch_on_this_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)linear_bf16_pp64_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PP64Cfg::LDS);
-    attr_set = true;
   }
   static int n_cu = 0;
   if (n_cu == 0) {

@@ -52,6 +52,19 @@ constexpr JobTable build_jobs(bool full) {
   }
   return jt;
 }
+// The narrow kernel deals a chunk's 1 KiB blocks (DMA wave-instructions) round-robin to its 8 waves and instantiates its
+// main loop per count c_w = ceil((n_total - wave) / 8) in 1 .. CMAX: every wave must own at least one block (c_w == 0 would
+// fall into the largest instantiation and issue DMAs past the operand) and at most CMAX = 4 P.
+constexpr bool narrow_jobs_fit_the_dma_deal() {
+  const JobTable jt = build_jobs(false);
+  for (int net = 0; net < N_NET; ++net)
+    for (int k = 0; k < jt.count[net]; ++k) {
+      const int blocks = (jt.jobs[net][k].n_o + jt.jobs[net][k].n_i) / 16;      // per plane; P planes scale both bounds
+      if (blocks < 8 || blocks > 32) return false;
+    }
+  return true;
+}
+static_assert(narrow_jobs_fit_the_dma_deal(), "narrow dW job: 8 <= (n_o + n_i) / 16 <= 32 blocks per plane");
 __constant__ JobTable c_full = build_jobs(true);
 __constant__ JobTable c_narrow = build_jobs(false);
 

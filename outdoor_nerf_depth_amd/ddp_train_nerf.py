@@ -219,7 +219,11 @@ def save_checkpoint(path, trainer, global_step):
     import torch
     from .model import state_dict_from_flat, adam_state_dict
     trainer.flush()
-    trainer.check_cameras()                       # never write (and later auto-reload) a checkpoint of a poisoned run
+    # never write (and later auto-reload) a checkpoint of a poisoned run.  Under data parallelism the bad-ray count is summed
+    # over ranks, so a check on rank 0 alone would raise here while the other ranks block in the next step's gradient
+    # all-reduce: there the training loop runs check_cameras() on EVERY rank right before this call
+    if trainer.world_size == 1:
+        trainer.check_cameras()
     to_save = OrderedDict()
     for m, eng in enumerate(trainer.engines):
         to_save['net_%d' % m] = OrderedDict((k, v.clone().cpu()) for k, v in
@@ -443,7 +447,9 @@ def ddp_train_nerf(rank, args):
                             writer.add_scalar('test_' + name, vals[-1], global_step)
                         logger.info('test_%s: %s' % (name, vals[-1]))
 
-        if rank == 0 and (global_step % args.i_weights == 0 and global_step > 0):   # :642-652
+        if global_step % args.i_weights == 0 and global_step > 0:   # :642-652
+            trainer.check_cameras()               # every rank, so that all raise together: never write (and later auto-reload) a checkpoint of a poisoned run
+        if rank == 0 and (global_step % args.i_weights == 0 and global_step > 0):
             save_checkpoint(os.path.join(exp_dir, 'model_{:06d}.pth'.format(global_step)), trainer, global_step)
 
     trainer.flush()                               # the last step's level-1 update is applied lazily under DP

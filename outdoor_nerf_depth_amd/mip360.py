@@ -897,6 +897,21 @@ class Mip360Trainer(object):
         if depth_loss_type not in DEPTH_TYPES:
             raise ValueError('depth_loss_type %r: mse / l1 (train_utils.py:108-119) or kl / urf (internal/depth_loss.py)' % depth_loss_type)
         self.max_steps, self.lambda_depth, self.depth_loss_type = max_steps, lambda_depth, depth_loss_type
+        if depth_loss_type in ('kl', 'urf'):
+            # upstream's `loss.sum(-2) * depth_mask` (internal/depth_loss.py:27,64) sums over RAYS and then broadcasts a
+            # [n_samples] vector against the [n_rays] mask: it only type-checks for n_rays == n_samples on every level (or one
+            # ray).  Say so when the trainer is built instead of on the first step.
+            counts = {self.cfg['num_prop_samples'], self.cfg['num_nerf_samples']}
+            if len(counts) != 1:
+                raise Mip360Error(
+                    "depth_loss_type %r with num_prop_samples=%d / num_nerf_samples=%d: upstream's loss.sum(-2) * depth_mask "
+                    "(internal/depth_loss.py:27,64) broadcasts [n_samples] against [n_rays], so it needs the same sample count "
+                    "on every level and batches of exactly that many rays (with configs/360.gin's 64 / 64 / 32 the reference "
+                    "itself raises for every batch size but 1).  Use mse / l1, or equal sample counts."
+                    % (depth_loss_type, self.cfg['num_prop_samples'], self.cfg['num_nerf_samples']))
+            self._klurf_rays = counts.pop()
+        else:
+            self._klurf_rays = None
         self.depth_sigma = depth_sigma * depth_scale                      # train_utils.py:123
         self.world_size, self.grad_max_norm, self.adam_eps = world_size, grad_max_norm, adam_eps
         self.step = 0
@@ -989,6 +1004,10 @@ class Mip360Trainer(object):
 
     def train_step(self, rays, rgb_gt, depth_sup, jitter01=None):
         """rays / rgb_gt [n,3] / depth_sup [n] on the device.  Returns the scalars tensor of mip360_losses."""
+        if self._klurf_rays is not None and rays['origins'].shape[0] not in (1, self._klurf_rays):
+            raise Mip360Error("depth_loss_type %r: batches must hold exactly %d rays (= the per-level sample count) or 1 -- "
+                              "upstream's loss.sum(-2) * depth_mask broadcast (internal/depth_loss.py:27,64); got %d"
+                              % (self.depth_loss_type, self._klurf_rays, rays['origins'].shape[0]))
         self.step += 1
         self._join('prop')                         # the previous step's proposal backward has left its tensors
         self._keep_alive = None
@@ -1103,33 +1122,45 @@ def benchmark_step(device, n_rays=4096, steps=10, warmup=3, forward_only=False, 
     gt = T(rs.rand(n, 3).astype(np.float32))
     sup = T(np.where(rs.rand(n) < .5, rs.uniform(1, 6, n), 0).astype(np.float32))
     tr = Mip360Trainer(prop, nerf, device, world_size=world_size)
-    tr.defer_update = True                      # updates pipelined under the next step; tr.flush() belongs to the timed region
     macs = lambda sh: sum(i * o for i, o in sh)
     fwd_flop = 2.0 * (2 * 64 * macs(mlp_shapes(PROP_CFG)) + 32 * macs(mlp_shapes(NERF_CFG)))
     step = (lambda: tr.forward(rays, 0.5, None)) if forward_only else (lambda: tr.train_step(rays, gt, sup))
-    for _ in range(warmup):
-        step()
-    tr.flush()
-    torch.cuda.synchronize(device)
-    if world_size > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    tr.flush()
-    torch.cuda.synchronize(device)
-    if world_size > 1:
-        dist.barrier()
-    dt = (time.perf_counter() - t0) / steps
-    if world_size > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def timed(defer):
+        # defer = False: Mip360Trainer's default (every step ends joined) -- the headline `value`; True: the parameter
+        # updates pipelined under the next step (tr.flush() belongs to the timed region), reported beside it and labelled
+        tr.defer_update = defer
+        for _ in range(warmup):
+            step()
+        tr.flush()
+        torch.cuda.synchronize(device)
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        tr.flush()
+        torch.cuda.synchronize(device)
+        if world_size > 1:
+            dist.barrier()
+        dt_ = (time.perf_counter() - t0) / steps
+        if world_size > 1:
+            t = torch.tensor([dt_], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_
+    dt = timed(False)
+    dt_deferred = None if forward_only else timed(True)
+    tr.defer_update = False
     n = n_rays * world_size
     flop = fwd_flop * (1 if forward_only else 3) * n
     return {'workload': 'MipNeRF-360 configs/360.gin shape, %d rays/step, %s, depth_loss_type=mse on distance_mean, synthetic rays'
                         % (n_rays, 'forward' if forward_only else 'train step'),
             'n_gpus': world_size, 'rays_per_gpu': n_rays, 'value': n / dt, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt, 'steps': steps, 'dense_tflops': flop / dt / 1e12,
             'frac_of_bf16_mfma_peak': flop / dt / 2.5e15 / world_size, 'fwd_gflop_per_ray': fwd_flop / 1e9,
+            'update_mode': 'joined at the end of every step (Mip360Trainer default)',
+            'deferred_updates': None if dt_deferred is None else {
+                'value': n / dt_deferred, 'ms_per_step': 1e3 * dt_deferred,
+                'note': 'defer_update=True: updates pipelined under the next step, flush() inside the timed region (opt-in mode)'},
             'dtype': 'bf16 MFMA operands, f32 accumulate / f32 master weights'}

@@ -472,7 +472,130 @@ def gen_autoexpo():
     save('autoexpo', **arrs)
 
 
+class _ReplayRand(object):
+    """Feed prescribed uniforms to the reference's own perturb_samples / sample_pdf (they call torch.rand_like / torch.rand,
+    ddp_train_nerf.py:75,104) in the order the training loop consumes them."""
+    def __init__(self, tensors):
+        self.q = list(tensors)
+    def __enter__(self):
+        self.saved = (torch.rand_like, torch.rand)
+        def nxt(shape, dtype):
+            t = self.q.pop(0)
+            assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+            return t.to(dtype)
+        torch.rand_like = lambda x, **kw: nxt(x.shape, x.dtype)
+        torch.rand = lambda *sh, **kw: nxt(sh[0] if len(sh) == 1 and not isinstance(sh[0], int) else sh, torch.get_default_dtype())
+        return self
+    def __exit__(self, *a):
+        torch.rand_like, torch.rand = self.saved
+        assert not self.q, 'unconsumed uniforms'
+
+
+def ref_render_frame(nets, rays, cascade, dtype=torch.float32, chunk=1024):
+    """The per-chunk body of render_single_image (ddp_train_nerf.py:156-221: deterministic sampling, no perturbation) with
+    the reference's own intersect_sphere / sample_pdf / NerfNet.forward; its rank split and torch.distributed gather are
+    left out.  Returns the last level's rgb [n,3] and depth [n]."""
+    outs = []
+    n = rays['ray_o'].shape[0]
+    for s in range(0, n, chunk):
+        ray_o, ray_d = T(rays['ray_o'][s:s + chunk]).to(dtype), T(rays['ray_d'][s:s + chunk]).to(dtype)
+        min_depth = T(rays['min_depth'][s:s + chunk]).to(dtype)
+        N = ray_o.shape[0]
+        ret = None
+        for m, net in enumerate(nets):
+            S = cascade[m]
+            if m == 0:
+                far = R.intersect_sphere(ray_o, ray_d)
+                step = (far - min_depth) / (S - 1)
+                fg = torch.stack([min_depth + i * step for i in range(S)], dim=-1)
+                bg = torch.linspace(0., 1., S).view(1, S).expand(N, S).to(dtype)
+            else:
+                fgw = ret['fg_weights'].clone().detach()[..., 1:-1]
+                fs = R.sample_pdf(bins=.5 * (fg[..., 1:] + fg[..., :-1]), weights=fgw, N_samples=S, det=True)
+                fg, _ = torch.sort(torch.cat((fg, fs.to(dtype)), dim=-1))
+                bgw = ret['bg_weights'].clone().detach()[..., 1:-1]
+                bs = R.sample_pdf(bins=.5 * (bg[..., 1:] + bg[..., :-1]), weights=bgw, N_samples=S, det=True)
+                bg, _ = torch.sort(torch.cat((bg, bs.to(dtype)), dim=-1))
+            with torch.no_grad():
+                ret = net(ray_o, ray_d, far, fg, bg)
+        outs.append((ret['rgb'].double().numpy(), ret['depth'].double().numpy()))
+    return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
+
+
+def gen_trajectory(dtypes=(torch.float32, torch.float64)):
+    """the imported reference's training loop (ddp_train_nerf.py:417-498) on the BASELINE config-1
+    scene -- one 64x64 frame, --cascade_samples 32,64, N_rand 256, 200 steps -- rgb-only and with the gt / mse depth
+    term, on replayed batches and uniforms (tests/trajectory_common.py: seeds only).  Stored: the logged scalars every 25
+    steps (level loss, rgb loss, in-loop PSNR = mse2psnr(rgb_loss), utils.py:31), their mean over the last 25 steps, and the
+    frame rendered at the end with deterministic sampling (render_single_image) with its PSNR against the image.  The float64 run
+    of the same reference code gives the noise floor of the float32 reference itself."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import trajectory_common as TC
+    smp = TC.sampler()
+    full = {k: np.ascontiguousarray(v, np.float32) for k, v in smp.get_all().items() if isinstance(v, np.ndarray)}
+    arrs = {}
+    import time
+    for mode in TC.MODES:
+        for dtype in dtypes:
+            tag = '%s.%s' % (mode, 'f32' if dtype == torch.float32 else 'f64')
+            nets = [n.to(dtype) for n in make_levels(2)]
+            optims = [torch.optim.Adam(n.parameters(), lr=5e-4) for n in nets]
+            logs = {k: [] for k in ('loss0', 'loss1', 'rgb0', 'rgb1', 'depth0', 'depth1')}
+            tail = []
+            t0 = time.time()
+            for step in range(1, TC.N_STEPS + 1):
+                b, uni = TC.step_batch(smp, step), TC.step_uniforms(step)
+                bt = {k: T(v).to(dtype) for k, v in b.items()}
+                N = bt['ray_o'].shape[0]
+                row = {}
+                with _ReplayRand([T(uni[k]) for k in ('t_fg', 't_bg', 'u_fg', 'u_bg')]):
+                    for m in range(2):                                      # :432-498
+                        S = TC.CASCADE[m]
+                        if m == 0:
+                            far = R.intersect_sphere(bt['ray_o'], bt['ray_d'])
+                            near = bt['min_depth']
+                            stp = (far - near) / (S - 1)
+                            fg = torch.stack([near + i * stp for i in range(S)], dim=-1)
+                            fg = R.perturb_samples(fg)
+                            bg = torch.linspace(0., 1., S).view(1, S).expand(N, S).to(dtype)
+                            bg = R.perturb_samples(bg)
+                        else:
+                            fgw = ret['fg_weights'].clone().detach()[..., 1:-1]
+                            fs = R.sample_pdf(bins=.5 * (fg[..., 1:] + fg[..., :-1]), weights=fgw, N_samples=S, det=False)
+                            fg, _ = torch.sort(torch.cat((fg, fs), dim=-1))
+                            bgw = ret['bg_weights'].clone().detach()[..., 1:-1]
+                            bs = R.sample_pdf(bins=.5 * (bg[..., 1:] + bg[..., :-1]), weights=bgw, N_samples=S, det=False)
+                            bg, _ = torch.sort(torch.cat((bg, bs), dim=-1))
+                        optims[m].zero_grad()
+                        ret, loss, rgb_loss, depth_loss = ref_level_step(nets[m], bt, far, fg, bg, mode, TC.LAMBDA_DEPTH, 0.)
+                        optims[m].step()
+                        row['loss%d' % m], row['rgb%d' % m] = loss.item(), rgb_loss.item()
+                        row['depth%d' % m] = depth_loss.item() if depth_loss is not None else 0.0
+                if step % TC.LOG_EVERY == 0:
+                    for k in logs:
+                        logs[k].append(row[k])
+                    print(tag, step, row, '%.0f s' % (time.time() - t0), flush=True)
+                if step > TC.N_STEPS - TC.LOG_EVERY:
+                    tail.append([row['rgb0'], row['rgb1']])
+            for k, v in logs.items():
+                arrs['%s.%s' % (tag, k)] = np.array(v, np.float64)
+            arrs['%s.tail_rgb_mse' % tag] = np.array(tail, np.float64)
+            rgb, depth = ref_render_frame(nets, full, TC.CASCADE, dtype)
+            mse = float(np.mean((rgb - full['rgb'].astype(np.float64)) ** 2))
+            arrs['%s.render_mse' % tag] = np.float64(mse)
+            arrs['%s.render_psnr' % tag] = np.float64(RU.mse2psnr(mse))
+            if dtype == torch.float32:
+                arrs['%s.render_rgb' % tag] = rgb.astype(np.float32)
+                arrs['%s.render_depth' % tag] = depth.astype(np.float32)
+            print(tag, 'render psnr', arrs['%s.render_psnr' % tag], flush=True)
+    save('trajectory', **arrs)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':      # ~30 min of CPU: on request only
+        torch.set_num_threads(8)
+        gen_trajectory()
+        sys.exit(0)
     gen_sampling()
     gen_embed()
     gen_depth2pts()
