@@ -23,7 +23,7 @@ SOURCES = {
     'nerfpp_optim.hip': ['-ffp-contract=off'],      # Adam rounds like torch
     'nerfpp_api.hip': [],
 }
-HEADERS = ['nerfpp_common.h', 'nerfpp_kernels.h', 'probe_env.h', os.path.join('..', '..', 'include', 'nerfpp_hip.h')]
+HEADERS = ['nerfpp_common.h', 'nerfpp_kernels.h', 'probe_env.h', 'nerfpp_mlp_probes.h', os.path.join('..', '..', 'include', 'nerfpp_hip.h')]
 # SURVEY 8 f-4 (MipNeRF-360 path): its own shared object and C ABI (include/mip360_hip.h)
 OUT_MIP360 = os.path.join(PKG, 'libmip360_hip.so')
 SOURCES_MIP360 = {
@@ -33,7 +33,7 @@ SOURCES_MIP360 = {
     'mip360_train.hip': [],
     'mip360_api.hip': [],
 }
-HEADERS_MIP360 = ['probe_env.h', os.path.join('..', '..', 'include', 'mip360_hip.h')]
+HEADERS_MIP360 = ['probe_env.h', 'mip360_gemm_probes.h', 'mip360_fm_probes.h', os.path.join('..', '..', 'include', 'mip360_hip.h')]
 
 
 def _stale(target, deps):

@@ -60,50 +60,37 @@ __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
-#ifndef FM_GLDS_MODE
-#define FM_GLDS_MODE 0
+}  // namespace mip360fm
+// Experiment switches (component removal, DMA issue forms, store cache policies, ring depth, start-up stagger) exist only
+// in diagnostic builds: -DNERFPP_PROBES takes their variants from mip360_fm_probes.h (tools/probes/mip360_variant.sh); the
+// shipped library sees the constants, the one DMA issue form and the one store policy below.
+#ifdef NERFPP_PROBES
+#include "mip360_fm_probes.h"
+#else
+namespace mip360fm { namespace probe {
+constexpr int NSLOT = 5;               // LDS ring slots of 32 KiB
+constexpr int NSTORE = 16;             // output stores per wave and tile
+constexpr int DMA_PER = 4;             // DMA wave-instructions per wave and half-step
+constexpr int STAGGER = 0;
+constexpr bool NOREAD = false, NOMFMA = false, SETPRIO = false;
+__device__ __forceinline__ void issue_half_step(const char* iA, const char* iW, uint32_t voff, uint32_t d, uint32_t woff) {
+  glds16(iA, voff, d);
+  glds16(iA + 1024, voff, d + 1024u);
+  glds16(iW, voff, d + woff);
+  glds16(iW + 1024, voff, d + woff + 1024u);
+}
+}}  // namespace mip360fm::probe
+#define FM_ST " nt"                    // cache policy of the output stores (measured best: -0.8 % per step)
 #endif
-// probes: M0 left clobbered (no save / restore); two blocks per M0 value through the instruction offset
-__device__ __forceinline__ void glds16_m0(const void* sbase, uint32_t voff, uint32_t lds_abs) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
-  const uint64_t b = (uint64_t)(uintptr_t)sbase;
-  const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
-}
-__device__ __forceinline__ void glds16_pair(const void* sbase, uint32_t voff, uint32_t lds_abs) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
-  const uint64_t b = (uint64_t)(uintptr_t)sbase;
-  const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
-               :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
-}
+namespace mip360fm {
 __device__ __forceinline__ uint64_t uniform64(const void* p) {
   const uint64_t b = (uint64_t)(uintptr_t)p;
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
 }
 
-#ifndef FM_NSLOT
-#define FM_NSLOT 5
-#endif
-#ifndef FM_ST_FLAVOR
-#define FM_ST_FLAVOR 1        // cache policy of the output stores: 0 default, 1 nt (measured best: -0.8 % per step), 2 sc1, 3 sc0 sc1, 4 sc1 nt
-#endif
-#if FM_ST_FLAVOR == 1
-#define FM_ST " nt"
-#elif FM_ST_FLAVOR == 2
-#define FM_ST " sc1"
-#elif FM_ST_FLAVOR == 3
-#define FM_ST " sc0 sc1"
-#elif FM_ST_FLAVOR == 4
-#define FM_ST " sc1 nt"
-#else
-#define FM_ST ""
-#endif
 struct Cfg {
-  static constexpr int SLOT = 32768, NSLOT = FM_NSLOT, WOFF = 16384, LDS = SLOT * NSLOT;
+  static constexpr int SLOT = 32768, NSLOT = probe::NSLOT, WOFF = 16384, LDS = SLOT * NSLOT;
   static constexpr int AHEAD = NSLOT - 1;           // the fragment-read phase of half-step x issues the DMA of x + AHEAD
 };
 static_assert(Cfg::AHEAD == 3 || Cfg::AHEAD == 4, "ring depth 4 or 5");
@@ -119,19 +106,9 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
                       const float* __restrict__ bias, char* __restrict__ C, int ldc, u32x4* __restrict__ mask) {
   constexpr int SLOT = Cfg::SLOT;
   // VMEM instructions of one epilogue + preload (older than the DMA issued after it): output stores, mask store / load, bias loads
-#ifdef FM_EXP_NOSTORE
-  constexpr int NSTORE = 0;
-#else
-  constexpr int NSTORE = 16;
-#endif
+  constexpr int NSTORE = probe::NSTORE;
   constexpr int NE = ACT == 0 ? NSTORE + 2 : ACT == 1 ? NSTORE + 1 + 2 : NSTORE + 1;
-  #if defined(FM_EXP_HALFDMA)
-  constexpr int DMA_PER = 2;
-#elif defined(FM_EXP_NODMA)
-  constexpr int DMA_PER = 0;
-#else
-  constexpr int DMA_PER = 4;
-#endif
+  constexpr int DMA_PER = probe::DMA_PER;
   constexpr int AHEAD = Cfg::AHEAD, VM_STEADY = (AHEAD - 1) * DMA_PER, VM_PEEL = VM_STEADY + NE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, grp = wm;            // group 0 = waves 0-3 = tile rows 0-127
@@ -166,25 +143,7 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
   };
   auto issue = [&]() {
     const uint32_t d = lds0 + islot + (uint32_t)wave * 2048u;
-#if defined(FM_EXP_HALFDMA)
-    glds16(iA, voff, d);
-    glds16(iA + 1024, voff, d + 1024u);
-#elif defined(FM_EXP_NODMA)
-    (void)d;
-#elif FM_GLDS_MODE == 2
-    glds16_pair(iA, voff, d);
-    glds16_pair(iW, voff, d + Cfg::WOFF);
-#elif FM_GLDS_MODE == 1
-    glds16_m0(iA, voff, d);
-    glds16_m0(iA + 1024, voff, d + 1024u);
-    glds16_m0(iW, voff, d + Cfg::WOFF);
-    glds16_m0(iW + 1024, voff, d + Cfg::WOFF + 1024u);
-#else
-    glds16(iA, voff, d);
-    glds16(iA + 1024, voff, d + 1024u);
-    glds16(iW, voff, d + Cfg::WOFF);
-    glds16(iW + 1024, voff, d + Cfg::WOFF + 1024u);
-#endif
+    probe::issue_half_step(iA, iW, voff, d, Cfg::WOFF);
     islot = islot == (Cfg::NSLOT - 1) * SLOT ? 0u : islot + SLOT;
     iA += 2048; iW += 2048;
     if (++ih == nh) { ih = 0; ++it; set_issue_tile(it < T ? it : 0); }   // past the last tile: re-loads of tile 0 into free slots keep the counts uniform
@@ -192,11 +151,8 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
 
   bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
   f32x16 acc[4][2];
-#ifdef FM_EXP_NOREAD
-#define FM_READ(s_) { (void)(s_); }
-#else
 #define FM_READ(s_)                                                                                                    \
-  {                                                                                                                    \
+  if constexpr (!probe::NOREAD) {                                                                                      \
     const uint32_t pa = pa0 + (s_), pb = pb0 + (s_);                                                                   \
     asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:2048\n\tds_read_b128 %2, %12 offset:4096\n\t"    \
                  "ds_read_b128 %3, %12 offset:6144\n\tds_read_b128 %4, %13\n\tds_read_b128 %5, %13 offset:2048\n\t"     \
@@ -206,28 +162,21 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
                    "=&v"(fa1[0]), "=&v"(fa1[1]), "=&v"(fa1[2]), "=&v"(fa1[3]), "=&v"(fb1[0]), "=&v"(fb1[1])             \
                  : "v"(pa), "v"(pb) : "memory");                                                                       \
   }
-#endif
 #define FM_LGKM0()                                                                                                     \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
                : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fa1[0]),      \
                  "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fb1[0]), "+v"(fb1[1]) :: "memory")
-#ifdef FM_EXP_NOMFMA
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, x_, y_, z_) (c_)
-#endif
-#ifdef FM_SETPRIO
-#define FM_PRIO(x_) __builtin_amdgcn_s_setprio(x_)
-#else
-#define FM_PRIO(x_) (void)0
-#endif
+#define FM_MFMA(a_, b_, c_) (probe::NOMFMA ? (c_) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0))
+#define FM_PRIO(x_) { if constexpr (probe::SETPRIO) __builtin_amdgcn_s_setprio(x_); }
 #define FM_MUL()                                                                                                       \
   {                                                                                                                    \
     FM_PRIO(1);                                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);                       \
+        acc[i][j] = FM_MFMA(fb0[j], fa0[i], acc[i][j]);                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                       \
+        acc[i][j] = FM_MFMA(fb1[j], fa1[i], acc[i][j]);                                                                 \
     FM_PRIO(0);                                                                                                        \
   }
 #define FM_MUL_FIRST()                                                                                                 \
@@ -235,10 +184,10 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], zero, 0, 0, 0);                            \
+        acc[i][j] = FM_MFMA(fb0[j], fa0[i], zero);                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                       \
+        acc[i][j] = FM_MFMA(fb1[j], fa1[i], acc[i][j]);                                                                 \
   }
 #define FM_VMCNT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #define FM_PHASE_END()                                                                                                 \
@@ -320,14 +269,11 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
           pk[p] = w;
         }
         const u32x4 lo = {pk[0], pk[1], pk[2], pk[3]}, hi4 = {pk[4], pk[5], pk[6], pk[7]};
-#ifndef FM_EXP_NOSTORE
-        if (j == 0)
+        if constexpr (probe::NSTORE == 0) asm volatile("" ::"v"(u16), "v"(lo), "v"(hi4), "s"(cb));
+        else if (j == 0)
           asm volatile("global_store_dwordx4 %0, %1, %3" FM_ST "\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024" FM_ST "\n\ts_nop 1" ::"v"(u16), "v"(lo), "v"(hi4), "s"(cb) : "memory");
         else
           asm volatile("global_store_dwordx4 %0, %1, %3 offset:2048" FM_ST "\n\tglobal_store_dwordx4 %0, %2, %3 offset:3072" FM_ST "\n\ts_nop 1" ::"v"(u16), "v"(lo), "v"(hi4), "s"(cb) : "memory");
-#else
-        asm volatile("" ::"v"(u16), "v"(lo), "v"(hi4), "s"(cb));
-#endif
       }
       mout[i] = word;
     }
@@ -338,11 +284,8 @@ void linear_fm_kernel(int M, int N, int K, const char* __restrict__ A, int lda, 
     }
   };
 
-#ifdef FM_STAGGER
-  // probe: the workgroups of an XCD start in four classes FM_STAGGER x 3.4 us apart, so that their tile switches (4 MB of dirty
-  // lines per XCD when they coincide) do not
-  for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * FM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
+  if constexpr (probe::STAGGER > 0)       // (probes: start-up classes 3.4 us apart per XCD)
+    for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * probe::STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   // ---- prologue: half-steps 0 .. AHEAD-1 and the first tile's side data, synchronously
   set_issue_tile(0);
 #pragma unroll

@@ -25,6 +25,14 @@ static inline bool first_launch_on_this_device(std::atomic<uint64_t>& done) {
   return (done.fetch_or(bit) & bit) == 0;
 }
 
+// Component-removal switches of the ping-pong GEMM (timing experiments, garbage results) exist only in diagnostic builds:
+// -DNERFPP_PROBES takes them from mip360_gemm_probes.h (MIP360_EXP_NODMA / NOLDS / NOMFMA); the shipped library has none.
+#ifdef NERFPP_PROBES
+#include "mip360_gemm_probes.h"
+#else
+namespace mip360 { namespace probe { constexpr bool NODMA = false, NOLDS = false, NOMFMA = false; } }
+#endif
+
 namespace mip360 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -368,9 +376,7 @@ void linear_bf16_ring_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
   const int nk = K / RBK;
   auto issue = [&](int kt) {
     if (kt >= nk) return;
-#ifdef MIP360_EXP_NODMA
-    if (kt >= NBUF) return;
-#endif
+    if constexpr (probe::NODMA) { if (kt >= NBUF) return; }
     const uint32_t slot = (uint32_t)(kt % NBUF) * STAGE;
 #pragma unroll
     for (int q = 0; q < QW; ++q) glds16_asm(gsrc[q] + (size_t)kt * RBK * 2, lds0 + slot + ldst[q]);
@@ -504,15 +510,12 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
   const int wt = tid & (Cfg::NTR - 1), piece = wt % PIECES, rgroup = wt / PIECES;
   bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
   f32x16 acc[FM][FN];
-#ifdef MIP360_EXP_NOLDS
-#define PP64_READ6(fa, fb, pa, pb) {}
-#else
 #define PP64_READ6(fa, fb, pa, pb)                                                                                     \
-  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:4096\n\tds_read_b128 %2, %6 offset:8192\n\t"         \
-               "ds_read_b128 %3, %6 offset:12288\n\tds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:4096"            \
-               : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fa[2]), "=&v"(fa[3]), "=&v"(fb[0]), "=&v"(fb[1])                    \
-               : "v"(pa), "v"(pb) : "memory");
-#endif
+  if constexpr (!probe::NOLDS)                                                                                         \
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:4096\n\tds_read_b128 %2, %6 offset:8192\n\t"       \
+                 "ds_read_b128 %3, %6 offset:12288\n\tds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:4096"          \
+                 : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fa[2]), "=&v"(fa[3]), "=&v"(fb[0]), "=&v"(fb[1])                  \
+                 : "v"(pa), "v"(pb) : "memory");
   // fragments of one half step (A slot / W slot byte offsets sa_ / sb_, half HH): the 12 reads are issued first, then DMA_
   // (its issue time overlaps the reads' latency), then the wait
 #define PP64_LOAD(sa_, sb_, HH, DMA_)                                                                                  \
@@ -524,11 +527,8 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
                  : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fa1[0]),    \
                    "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fb1[0]), "+v"(fb1[1]) :: "memory");                  \
   }
-#ifdef MIP360_EXP_NOMFMA
-#define PP64_MULTIPLY() {}
-#else
 #define PP64_MULTIPLY()                                                                                                \
-  {                                                                                                                    \
+  if constexpr (!probe::NOMFMA) {                                                                                      \
     _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                                     \
       _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                   \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);                       \
@@ -536,7 +536,6 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
       _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                   \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                       \
   }
-#endif
 #define PP64_PHASE_END()                                                                                               \
   __builtin_amdgcn_sched_barrier(0);                                                                                   \
   __builtin_amdgcn_s_barrier();
@@ -595,17 +594,13 @@ void linear_bf16_pp64_kernel(int M, int N, int K, const __bf16* __restrict__ A, 
     const uint32_t dstA = lds0 + (uint32_t)(32 * wave * 128), dstW = dstA + WBASE;
     auto issue_a = [&](int st, uint32_t slot_bytes) {
       if (st >= ns) return;
-#if defined(MIP360_EXP_NODMA)
-      if (st >= 2) return;
-#endif
+      if constexpr (probe::NODMA) { if (st >= 2) return; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) glds16_saddr(baseA + (size_t)q * 8 * lda * 2 + (size_t)st * 128, voffA[q & 1], dstA + slot_bytes + q * 1024);
     };
     auto issue_w = [&](int st, uint32_t slot_bytes) {
       if (st >= ns) return;
-#if defined(MIP360_EXP_NODMA)
-      if (st >= 2) return;
-#endif
+      if constexpr (probe::NODMA) { if (st >= 2) return; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) glds16_saddr(baseW + (size_t)q * 8 * ldw * 2 + (size_t)st * 128, voffW[q & 1], dstW + slot_bytes + q * 1024);
     };

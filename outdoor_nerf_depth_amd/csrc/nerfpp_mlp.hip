@@ -34,6 +34,27 @@
 #include "nerfpp_common.h"
 #include "nerfpp_kernels.h"
 
+// Experiment switches (component removal, store cache policies, tile sizes: DESIGN.md sections 6-6.3) exist only in
+// diagnostic builds: -DNERFPP_PROBES pulls their variants in from nerfpp_mlp_probes.h (tools/probes/variant.sh).  The
+// shipped translation units see the constants and the one store flavour below and nothing else.
+#ifdef NERFPP_PROBES
+#include "nerfpp_mlp_probes.h"
+#else
+namespace nerfpp { namespace probe {
+constexpr int DBG = 0;                 // component-removal bits (probes only)
+constexpr bool NO_DMA = false, NO_MFMA = false;
+constexpr int LDS_PREFETCH = 4;        // weight fragments in flight ahead of the MFMA that consumes them
+constexpr int HOOK_ORDER = 1;          // saves issued after a block's MFMAs by every wave
+constexpr int WAVES_P1 = 8;            // waves per workgroup of the bf16 kernels (256-sample tiles)
+__device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ vv = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(vv, (u32x4_*)gptr);
+}
+__device__ __forceinline__ void kernel_prologue(float*) {}
+}}  // namespace nerfpp::probe
+#endif
+
 namespace nerfpp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -84,9 +105,7 @@ struct WeightPipe {
     ++next_issue;
     slot_issue = slot_issue + 1 == NBUF ? 0 : slot_issue + 1;
     if (blk >= nblk) return;
-#ifdef NERFPP_DBG_NO_DMA
-    return;                                   // timing experiment only: no weight traffic (garbage results)
-#endif
+    if constexpr (probe::NO_DMA) return;
     const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
     if constexpr (MODE == PIPE_ROLES) {
       if (wave != 0) return;                                   // the loader wave issues the whole block
@@ -136,6 +155,7 @@ struct WeightPipe {
 template <int P>
 __device__ __forceinline__ void mfma_p(f32x16& acc, const char* lfrag, const Frag<P>& b) {
   const bf16x8 a_hi = *(const bf16x8*)(lfrag);
+  if constexpr (probe::NO_MFMA) { asm volatile("" ::"v"(a_hi)); return; }
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.v[0], acc, 0, 0, 0);
   if constexpr (P == 2) {
     const bf16x8 a_lo = *(const bf16x8*)(lfrag + FRAG_BYTES);
@@ -144,9 +164,6 @@ __device__ __forceinline__ void mfma_p(f32x16& acc, const char* lfrag, const Fra
   }
 }
 
-#ifndef NERFPP_LDS_PREFETCH
-#define NERFPP_LDS_PREFETCH 4
-#endif
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 #define HOOK(...) [&](int blk) __attribute__((always_inline)) { __VA_ARGS__; }
 #define IC(n) std::integral_constant<int, (n)>{}
@@ -168,21 +185,18 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
     // opposite ends (0), so that one always had MFMAs to issue while the other waited on LDS; with direct register stores
     // there is nothing to wait for and "after the MFMAs" for every wave (1) measures 1.4 % faster in the forward
     // (0.633 vs 0.642 ms at N_rand 1024), "before" (2) the same as (0).
-#ifndef NERFPP_HOOK_ORDER
-#define NERFPP_HOOK_ORDER 1
-#endif
-    if (NERFPP_HOOK_ORDER == 2 || (NERFPP_HOOK_ORDER == 0 && pipe.wave >= 4)) hook(blk);
+    if (probe::HOOK_ORDER == 2 || (probe::HOOK_ORDER == 0 && pipe.wave >= 4)) hook(blk);
 #pragma unroll
     for (int kl = 0; kl < KPB; ++kl) {
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob)
         mfma_p<P>(acc[ob], l + (kl * NOB + ob) * P * FRAG_BYTES, b[blk * KPB + kl]);
     }
-    if (NERFPP_HOOK_ORDER == 1 || (NERFPP_HOOK_ORDER == 0 && pipe.wave < 4)) hook(blk);
-    if constexpr (P == 1 && NERFPP_LDS_PREFETCH > 0) {
-      // shape the block's schedule: NERFPP_LDS_PREFETCH weight fragments in flight ahead of the MFMA
+    if (probe::HOOK_ORDER == 1 || (probe::HOOK_ORDER == 0 && pipe.wave < 4)) hook(blk);
+    if constexpr (P == 1 && probe::LDS_PREFETCH > 0) {
+      // shape the block's schedule: LDS_PREFETCH weight fragments in flight ahead of the MFMA
       // that consumes them (LDS latency is ~2-4 MFMA slots; the default schedule keeps only 1-2 ahead)
-      constexpr int D = NERFPP_LDS_PREFETCH, N = NOB * KPB;
+      constexpr int D = probe::LDS_PREFETCH, N = NOB * KPB;
 #pragma unroll
       for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
@@ -337,39 +351,7 @@ __device__ __forceinline__ void lds_wave_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
-// NERFPP_DBG (diagnostic builds only): bit 0 drops the activation stores, bit 1 the
-// LDS transposes too, bit 2 uses plain instead of non-temporal stores, bit 4 drops the loader hand-off,
-// bit 5 folds every activation store into a 2 MiB window of out_raw (forward kernel; no HBM write traffic),
-// bit 6 keeps the LDS reads and address math of the saves but drops the store instructions
-#ifndef NERFPP_DBG
-#define NERFPP_DBG 0
-#endif
-#if (NERFPP_DBG & 32)
-__device__ char* dbg_sink;      // timing experiment: every activation store folded into a 2 MiB window of out_raw
-#endif
-__device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) {
-  if constexpr ((NERFPP_DBG & 1) != 0) return;
-#if (NERFPP_DBG & 32)
-  gptr = dbg_sink + ((uintptr_t)gptr & 0x1FFFF0);
-#endif
-#if (NERFPP_DBG & 64)
-  asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(gptr));   // keep the LDS reads + address math, drop the store
-  return;
-#endif
-  if constexpr ((NERFPP_DBG & 4) != 0) { *(uint4*)gptr = v; return; }                                     // plain (temporal) store
-  const u32x4 vv = {v.x, v.y, v.z, v.w};
-#if defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 1      // probes: cache-policy variants of the activation stores
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gptr), "v"(vv) : "memory");
-#elif defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(gptr), "v"(vv) : "memory");
-#elif defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 3
-  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(gptr), "v"(vv) : "memory");
-#elif defined(NERFPP_STORE_FLAVOR) && NERFPP_STORE_FLAVOR == 4
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(gptr), "v"(vv) : "memory");
-#else
-  __builtin_nontemporal_store(vv, (u32x4*)gptr);
-#endif
-}
+__device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) { probe::store16(gptr, v); }
 
 // Saved tensors are FRAGMENT-MAJOR (nerfpp_common.h, "saved tensors"): the 16 bytes lane (j, hi) holds of chunk c of a
 // wave's 32-row tile go to byte ((tile32 * (ld / 16) + c) * 1024 + (2 j + hi) * 16) of the tensor (hi plane, then the
@@ -396,7 +378,7 @@ __device__ __forceinline__ void store_chunk(__bf16* base, size_t plane, int ld, 
 }
 template <int NCH, int P>
 __device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, const Frag<P> (&h)[NCH]) {
-  if constexpr ((NERFPP_DBG & 2) != 0) return;
+  if constexpr ((probe::DBG & 2) != 0) return;
   // Scheduling fences on both sides: the LDS-staged save this replaces was a fence by construction (wave barriers);
   // without one the scheduler starts the next stage's accumulator set while this stage's is still being converted and
   // stored (the split-bf16 backward went from 371 to 512 registers + spills).
@@ -410,13 +392,13 @@ __device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, s
 // conflict-free 16-byte accesses) and helper waves write it out after the next barrier --------------------------------
 template <int NCH>
 __device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<1> (&h)[NCH]) {
-  if constexpr ((NERFPP_DBG & (2 | 16)) != 0) return;
+  if constexpr ((probe::DBG & (2 | 16)) != 0) return;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) *(uint4*)(region + (c * 64 + lane) * 16) = *(const uint4*)&h[c].v[0];
 }
 // chunks [c0, c0 + n) of the loader's tile (tile rows row0 .. row0 + 31): region -> HBM
 __device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, int ld, size_t row0, int c0, int n) {
-  if constexpr ((NERFPP_DBG & 16) != 0) return;
+  if constexpr ((probe::DBG & 16) != 0) return;
 #pragma unroll 4
   for (int c = c0; c < c0 + n; ++c) store_nt16(frag_addr(base, ld, row0, c, lane), *(const uint4*)(region + (c * 64 + lane) * 16));
 }
@@ -595,10 +577,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;          // this wave's first tile row
   const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
-#if (NERFPP_DBG & 32)
-  if (threadIdx.x == 0) dbg_sink = (char*)a.out_raw;
-  __syncthreads();
-#endif
+  probe::kernel_prologue(a.out_raw);
   const bool tail = wrow0 + 32 > (size_t)a.rows;                            // wave-uniform
   char* region = smem + LD::REGION;
   char* pe_stash = smem + LD::STASH + wave * (KPE * P * 1024);
@@ -659,7 +638,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
       if (loader) {
         if (blk == 0) handoff_write<16>(region, lane, frags);
       } else {
-        if constexpr ((NERFPP_DBG & 2) == 0) {
+        if constexpr ((probe::DBG & 2) == 0) {
           if (blk < 8) {
             store_chunk<P>(base, 0, 256, wrow0, lane, 2 * blk, frags[2 * blk]);
             store_chunk<P>(base, 0, 256, wrow0, lane, 2 * blk + 1, frags[2 * blk + 1]);
@@ -828,7 +807,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
       if (loader) {
         if (blk == 0) handoff_write<NCH>(region, lane, frags);
       } else {
-        if constexpr ((NERFPP_DBG & 2) == 0) {
+        if constexpr ((probe::DBG & 2) == 0) {
           if (2 * blk < NCH) {
             store_chunk<P>(base, 0, ld, wrow0, lane, 2 * blk, frags[2 * blk]);
             store_chunk<P>(base, 0, ld, wrow0, lane, 2 * blk + 1, frags[2 * blk + 1]);
@@ -922,10 +901,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
 
 using namespace nerfpp;
 
-#ifndef NERFPP_WAVES_P1
-#define NERFPP_WAVES_P1 8
-#endif
-#define MLP_WAVES(P) ((P) == 1 ? NERFPP_WAVES_P1 : 4)
+#define MLP_WAVES(P) ((P) == 1 ? probe::WAVES_P1 : 4)
 
 template <int NET, int P, bool TRAIN>
 static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {

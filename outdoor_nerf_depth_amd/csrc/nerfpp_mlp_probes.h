@@ -1,0 +1,86 @@
+// Diagnostic variants of the fused MLP kernels (nerfpp_mlp.hip includes this ONLY under -DNERFPP_PROBES; the shipped
+// libraries are built without it: outdoor_nerf_depth_amd/csrc/build.py).  tools/probes/variant.sh builds them:
+//   tools/probes/variant.sh <name> "-DNERFPP_PROBES -DNERFPP_DBG=1"
+// Most of these produce GARBAGE results by design (component removal for timing); none is reachable from build.py.
+//
+//   NERFPP_DBG bits: 1 drops the activation stores, 2 the saves altogether, 4 plain instead of
+//     non-temporal stores, 16 drops the loader hand-off, 32 folds every activation store into a 2 MiB window of out_raw
+//     (forward kernel; no HBM write traffic), 64 keeps the address math of the saves but drops the store instructions
+//   NERFPP_DBG_NO_DMA      no weight DMA (LDS holds stale bytes)
+//   NERFPP_DBG_NO_MFMA     no MFMAs (the weight fragment reads stay)
+//   NERFPP_STORE_FLAVOR    1 sc1 | 2 sc0 sc1 | 3 sc1 nt | 4 sc0 sc1 nt   (default: nt)
+//   NERFPP_HOOK_ORDER      0 the two waves of a SIMD save at opposite ends of a block | 1 after the MFMAs | 2 before
+//   NERFPP_LDS_PREFETCH    weight fragments in flight ahead of their MFMA (default 4)
+//   NERFPP_WAVES_P1        waves per workgroup of the bf16 kernels (default 8; 4 = 128-sample tiles)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifndef NERFPP_DBG
+#define NERFPP_DBG 0
+#endif
+#ifndef NERFPP_HOOK_ORDER
+#define NERFPP_HOOK_ORDER 1
+#endif
+#ifndef NERFPP_LDS_PREFETCH
+#define NERFPP_LDS_PREFETCH 4
+#endif
+#ifndef NERFPP_WAVES_P1
+#define NERFPP_WAVES_P1 8
+#endif
+#ifndef NERFPP_STORE_FLAVOR
+#define NERFPP_STORE_FLAVOR 0
+#endif
+
+namespace nerfpp { namespace probe {
+
+constexpr int DBG = NERFPP_DBG;
+#ifdef NERFPP_DBG_NO_DMA
+constexpr bool NO_DMA = true;
+#else
+constexpr bool NO_DMA = false;
+#endif
+#ifdef NERFPP_DBG_NO_MFMA
+constexpr bool NO_MFMA = true;
+#else
+constexpr bool NO_MFMA = false;
+#endif
+constexpr int LDS_PREFETCH = NERFPP_LDS_PREFETCH;
+constexpr int HOOK_ORDER = NERFPP_HOOK_ORDER;
+constexpr int WAVES_P1 = NERFPP_WAVES_P1;
+
+#if (NERFPP_DBG & 32)
+__device__ char* dbg_sink;      // timing experiment: every activation store folded into a 2 MiB window of out_raw
+__device__ __forceinline__ void kernel_prologue(float* out_raw) {
+  if (threadIdx.x == 0) dbg_sink = (char*)out_raw;
+  __syncthreads();
+}
+#else
+__device__ __forceinline__ void kernel_prologue(float*) {}
+#endif
+
+__device__ __forceinline__ void store16(char* gptr, const uint4 v) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  if constexpr ((NERFPP_DBG & 1) != 0) return;
+#if (NERFPP_DBG & 32)
+  gptr = dbg_sink + ((uintptr_t)gptr & 0x1FFFF0);
+#endif
+#if (NERFPP_DBG & 64)
+  asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(gptr));   // keep the address math, drop the store
+  return;
+#endif
+  if constexpr ((NERFPP_DBG & 4) != 0) { *(uint4*)gptr = v; return; }                                     // plain (temporal) store
+  const u32x4_ vv = {v.x, v.y, v.z, v.w};
+#if NERFPP_STORE_FLAVOR == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gptr), "v"(vv) : "memory");
+#elif NERFPP_STORE_FLAVOR == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(gptr), "v"(vv) : "memory");
+#elif NERFPP_STORE_FLAVOR == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(gptr), "v"(vv) : "memory");
+#elif NERFPP_STORE_FLAVOR == 4
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(gptr), "v"(vv) : "memory");
+#else
+  __builtin_nontemporal_store(vv, (u32x4_*)gptr);
+#endif
+}
+
+}}  // namespace nerfpp::probe

@@ -19,6 +19,6 @@ objs="$V/p_nerfpp_api.o $V/p_nerfpp_dw.o $C/build/nerfpp_tables.o $C/build/nerfp
 for k in 0 1 2 3 4 5 6 7 8 9 10 11 12; do objs="$objs $C/build/nerfpp_mlp_$k.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libnerfpp_hip_probes.so $objs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libmip360_hip_probes.so $V/p_mip360_gemm.o $V/p_mip360_train.o \
-  $C/build/mip360_kernels.o $C/build/mip360_api.o
+  $C/build/mip360_kernels.o $C/build/mip360_api.o $C/build/mip360_fm.o
 rm -f $V/p_*.o
 ls -la $V/*_probes.so

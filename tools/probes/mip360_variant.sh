@@ -7,7 +7,7 @@ name=$1; src=$2; shift 2
 C=outdoor_nerf_depth_amd/csrc
 mkdir -p $C/build/variants
 python $C/build.py > /dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fhip-fp32-correctly-rounded-divide-sqrt "$@" -c $C/$src -o $C/build/variants/mip360_${name}_$(basename $src .hip).o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fhip-fp32-correctly-rounded-divide-sqrt -DNERFPP_PROBES "$@" -c $C/$src -o $C/build/variants/mip360_${name}_$(basename $src .hip).o
 objs=""
 for f in mip360_kernels mip360_gemm mip360_fm mip360_train mip360_api; do
   if [ "$f.hip" = "$src" ]; then objs="$objs $C/build/variants/mip360_${name}_$f.o"; else objs="$objs $C/build/$f.o"; fi
