@@ -28,6 +28,8 @@ roofline            : SURVEY 8(d): algorithmic dense-layer FLOP (1.797 GFLOP per
 cpu_baseline        : oracle/nerfpp_torch_cpu.py (PyTorch-CPU restatement of the path, the way the reference
                       runs on CPU) on the host cores: N_rand 1024, 2 warm-up + 5 timed steps, median
 render              : SURVEY 8 f-2: one 375x1242 frame through render_single_image, whole call and MLP kernels alone
+cli_loop            : the drop-in training loop itself (ddp_train_nerf(): per-step frame choice, ray-batch sampling, log lines)
+                      with the device sampler and with the reference's host sampler, ms per step beside the kernel-only figure
 """
 import argparse
 import json
@@ -120,6 +122,8 @@ def parse():
     p.add_argument('--render_frames', type=int, default=1,
                    help='375x1242 frames rendered per precision by the inference leg (`render`; 0 = skip)')
     p.add_argument('--render_chunk', type=int, default=8192, help='rays per render chunk (ddp_train_nerf.py --chunk_size)')
+    p.add_argument('--cli_steps', type=int, default=600,
+                   help='steps of the drop-in training loop (outdoor_nerf_depth_amd/ddp_train_nerf.py) timed by `cli_loop` (0 = skip)')
     return p.parse_args()
 
 
@@ -381,6 +385,62 @@ def render_leg(args, device, precision, label):
                     'algorithmic figure in split-bf16)'}
 
 
+def cli_loop(args, kernel_only_ms):
+    """the drop-in loop itself -- `ddp_train_nerf()` of outdoor_nerf_depth_amd/ddp_train_nerf.py
+    (reference: ddp_train_nerf.py:417-431 per-step frame choice + random_sample + H2D, here device_sampler.py +
+    nerfpp_gather_rays; log line every i_print = 100 steps) on the KITTI-shaped scene (375x1242 frames), bf16, gt / mse / 0.1
+    -- once with the device sampler (default) and once with the reference's host sampler (--host_sampling).  ms per step =
+    the loop's own `iter_time` (wall time between log lines / steps; the log line reads the scalars, i.e. synchronises),
+    averaged over the log lines after step 200; `kernel_only_ms` = the headline's ms_per_step (pre-staged device batches)."""
+    import logging
+    import re
+    import shutil
+    import tempfile
+    from outdoor_nerf_depth_amd import ddp_train_nerf as C
+
+    class Cap(logging.Handler):
+        def __init__(self):
+            logging.Handler.__init__(self)
+            self.rows = []
+
+        def emit(self, record):
+            m = re.search(r'step: (\d+) .* iter_time: ([0-9.eE+-]+)', record.getMessage())
+            if m:
+                self.rows.append((int(m.group(1)), float(m.group(2))))
+
+    out = {'steps': args.cli_steps, 'i_print': 100, 'scene': 'synthetic KITTI-shaped, 30 frames of 375x1242, N_rand %d' % args.n_rand,
+           'kernel_only_ms_per_step': kernel_only_ms}
+    for name, extra in (('device_sampler', []), ('host_sampler', ['--host_sampling'])):
+        tmp = tempfile.mkdtemp(prefix='nerfpp_cli_')
+        cap = Cap()
+        C.setup_logger()
+        lg = logging.getLogger(C.__package__ or 'outdoor_nerf_depth_amd')
+        lg.addHandler(cap)
+        level = lg.level
+        try:
+            a = C.config_parser().parse_args(
+                ['--expname', 'bench', '--basedir', tmp, '--synthetic', '--synthetic_frames', '30', '--world_size', '1',
+                 '--cascade_samples', '64,128', '--N_rand_override', str(args.n_rand), '--N_iters', str(args.cli_steps),
+                 '--i_print', '100', '--i_weights', '100000000', '--i_test', '100000000', '--precision', 'bf16', '--use_depth',
+                 '--depth_sup_type', args.depth_sup_type, '--depth_loss_type', args.depth_loss_type,
+                 '--lambda_depth', str(args.lambda_depth)] + extra)
+            C.validate_args(a)
+            a.world_size = 1
+            C.ddp_train_nerf(0, a)
+        finally:
+            lg.removeHandler(cap)
+            lg.setLevel(level)
+            shutil.rmtree(tmp, ignore_errors=True)
+        late = [t for (st, t) in cap.rows if st > 200 and st % 100 == 0]
+        if not late:
+            out[name] = None
+            continue
+        ms = 1e3 * float(np.mean(late))
+        out[name] = {'ms_per_step': ms, 'rays_per_s': args.n_rand / (ms * 1e-3), 'log_lines_averaged': len(late),
+                     'overhead_vs_kernel_only_pct': 100.0 * (ms / kernel_only_ms - 1.0)}
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get('WORLD_SIZE')
@@ -506,6 +566,8 @@ def main():
                          'bf16': render_leg(args, device, L.PREC_BF16, 'bf16 MFMA operands, f32 accumulate')}
         if args.precision == 'both':
             out['render']['split_bf16'] = render_leg(args, device, L.PREC_SPLIT_BF16, 'split-bf16 (hi+lo, 3 MFMA passes): 1e-4 parity mode')
+    if world == 1 and args.cli_steps >= 300 and main_key == 'bf16':
+        out['cli_loop'] = cli_loop(args, r['ms_per_step'])
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

@@ -52,6 +52,9 @@ __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // ac
   __builtin_nontemporal_store(vv, (u32x4_*)gptr);
 }
 __device__ __forceinline__ void kernel_prologue(float*) {}
+constexpr int STAMP_BYTES = 0;         // per-block cycle stamps (probes only)
+__device__ __forceinline__ void stamp(int, int, int, int, uint32_t) {}
+__device__ __forceinline__ void dump_stamps(uint32_t, int, int) {}
 }}  // namespace nerfpp::probe
 #endif
 
@@ -90,6 +93,7 @@ struct WeightPipe {
   static constexpr int PER_BLK = MODE == PIPE_ROLES ? BLK_FRAGS * P : BLK_FRAGS * P / NW;
   static_assert(MODE == PIPE_CLASSIC ? NBUF == 2 : (NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_BLK < 63), "ring depth");
   const char* g;
+  uint32_t stamp_off = 0;                                      // (probes: LDS offset of the cycle stamps)
   int nblk, cur, wave, lane;
   int slot_cur, slot_issue, next_issue;                        // ring positions (NBUF need not be a power of 2)
   uint32_t lds_base;
@@ -132,6 +136,7 @@ struct WeightPipe {
   }
   // make block `cur` readable, start fetching into the slot freed by the barrier, return LDS address
   __device__ __forceinline__ const char* acquire() {
+    probe::stamp(0, cur, wave, lane, stamp_off);                 // arrival at the block boundary
     if constexpr (MODE == PIPE_RING) {
       wait_counted();
       __builtin_amdgcn_s_barrier();
@@ -144,6 +149,7 @@ struct WeightPipe {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    probe::stamp(1, cur, wave, lane, stamp_off);                 // released by the barrier
     issue();
     const char* l = smem + slot_cur * BLK_BYTES + lane * 16;
     slot_cur = slot_cur + 1 == NBUF ? 0 : slot_cur + 1;
@@ -585,6 +591,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
   WeightPipe<P, NW, LD::MODE, LD::NBUF> pipe;
+  pipe.stamp_off = LD::TOTAL;
   pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
   if constexpr (LD::BIAS_LDS) {
     for (int i = threadIdx.x; i < FWD_BIAS_FLOATS / 4; i += NW * 64)
@@ -760,6 +767,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     ((float4*)a.out_raw)[row] = o;
     if (NET == 1) a.depth_real[row] = depth_real;
   }
+  probe::dump_stamps(LD::TOTAL, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -827,6 +835,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   issue_masks(8);
   issue_masks(7);
   WeightPipe<P, NW, LD::MODE, LD::NBUF> pipe;
+  pipe.stamp_off = LD::TOTAL;
   pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
 
   float4 d = ((const float4*)a.d_out)[row];
@@ -895,6 +904,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     // writes its own tile
     save_frags<16, P>(a.ws.t[T_DZ0], plane_rows * 256, 256, wrow0, lane, dz);
   }
+  probe::dump_stamps(LD::TOTAL, wave, lane);
 }
 
 }  // namespace nerfpp
@@ -908,7 +918,7 @@ static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  constexpr size_t lds = FwdLds<NET, P, NW, TRAIN>::TOTAL;
+  constexpr size_t lds = FwdLds<NET, P, NW, TRAIN>::TOTAL + probe::STAMP_BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
 }
@@ -917,7 +927,7 @@ static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int grid = (int)((a.rows + tile - 1) / tile);
-  constexpr size_t lds = BwdLds<P, NW>::TOTAL;
+  constexpr size_t lds = BwdLds<P, NW>::TOTAL + probe::STAMP_BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((mlp_bwd_kernel<NET, P, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
 }

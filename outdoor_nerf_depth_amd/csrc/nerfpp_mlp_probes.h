@@ -12,6 +12,10 @@
 //   NERFPP_HOOK_ORDER      0 the two waves of a SIMD save at opposite ends of a block | 1 after the MFMAs | 2 before
 //   NERFPP_LDS_PREFETCH    weight fragments in flight ahead of their MFMA (default 4)
 //   NERFPP_WAVES_P1        waves per workgroup of the bf16 kernels (default 8; 4 = 128-sample tiles)
+//   NERFPP_STAMPS=k        per-block cycle stamps (s_memtime at arrival at / release from every block barrier, per wave) of
+//                          workgroups 0-3 and 400-403 of kernel instantiation k (NERFPP_MLP_PART numbering: 4 = forward fg
+//                          bf16 training, 8 = backward fg bf16), kept in LDS and copied out at the end of the kernel;
+//                          read back with nerfpp_probe_stamps() (tools/probes/stamps_probe.py)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -83,4 +87,38 @@ __device__ __forceinline__ void store16(char* gptr, const uint4 v) {
 #endif
 }
 
+
+#if defined(NERFPP_STAMPS) && defined(NERFPP_MLP_PART) && NERFPP_STAMPS == NERFPP_MLP_PART
+constexpr int STAMP_BLKS = 96, STAMP_WGS = 8;
+constexpr int STAMP_BYTES = 8 * STAMP_BLKS * 2 * 4;
+static __device__ uint32_t g_stamps[STAMP_WGS][8][STAMP_BLKS][2];
+extern __shared__ __attribute__((aligned(16))) char probe_smem[];
+__device__ __forceinline__ void stamp(int which, int blk, int wave, int lane, uint32_t lds_off) {
+  if (blk >= STAMP_BLKS) return;
+  const uint32_t t = (uint32_t)__builtin_readcyclecounter();
+  if (lane == 0) *(uint32_t*)(probe_smem + lds_off + ((wave * STAMP_BLKS + blk) * 2 + which) * 4) = t;
+}
+__device__ __forceinline__ void dump_stamps(uint32_t lds_off, int wave, int lane) {
+  const int b = blockIdx.x;
+  const int slot = b < 4 ? b : (b >= 400 && b < 404 ? b - 396 : -1);
+  if (slot < 0) return;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int i = lane; i < STAMP_BLKS * 2; i += 64)
+    (&g_stamps[slot][wave][0][0])[i] = *(const uint32_t*)(probe_smem + lds_off + (wave * STAMP_BLKS * 2 + i) * 4);
+}
+#define NERFPP_STAMPS_READER 1
+#else
+constexpr int STAMP_BYTES = 0;
+__device__ __forceinline__ void stamp(int, int, int, int, uint32_t) {}
+__device__ __forceinline__ void dump_stamps(uint32_t, int, int) {}
+#endif
+
 }}  // namespace nerfpp::probe
+
+#ifdef NERFPP_STAMPS_READER
+extern "C" int nerfpp_probe_stamps(void* host_dst, int bytes) {
+  if (bytes != (int)sizeof(nerfpp::probe::g_stamps)) return (int)sizeof(nerfpp::probe::g_stamps);
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nerfpp::probe::g_stamps), sizeof(nerfpp::probe::g_stamps));
+}
+#endif

@@ -94,3 +94,69 @@ def test_concurrent_backward_two_ranks_gloo(tmp_path):
         for k in ('params', 'm', 'v', 'scalars'):
             np.testing.assert_array_equal(a[k], b[k], err_msg='rank %d %s' % (rank, k))
     np.testing.assert_array_equal(np.load(tmp_path / 'r0_c1.npz')['params'], np.load(tmp_path / 'r1_c1.npz')['params'])
+
+
+# ------------------------------------------------------------------------------------------- training trajectory
+def _trajectory(precision, mode, n_steps=None):
+    """NerfppTrainer on the fixture's batches and uniforms; returns the logged rgb losses per step [n,2] and the final
+    frame rendered by render_single_image (deterministic sampling) with its PSNR against the image."""
+    import trajectory_common as TC
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    from outdoor_nerf_depth_amd.ddp_train_nerf import render_single_image
+    d = dev()
+    smp = TC.sampler()
+    tr = NerfppTrainer(d, precision=precision, cascade_samples=TC.CASCADE, use_depth=(mode != 'rgbonly'),
+                       depth_loss_type='mse', lambda_depth=TC.LAMBDA_DEPTH)
+    sc_all = []
+    for step in range(1, (n_steps or TC.N_STEPS) + 1):
+        b, uni = TC.step_batch(smp, step), TC.step_uniforms(step)
+        sc = tr.train_step({k: T(v, d) for k, v in b.items()}, uniforms={k: T(v, d) for k, v in uni.items()})
+        sc_all.append(torch.stack([s[1] for s in sc]))
+    rgb_mse = torch.stack(sc_all).cpu().numpy().astype(np.float64)
+    tr.check_cameras()
+    ret = render_single_image(0, 1, tr, smp, 1024, keep_dists=False)
+    im = ret[-1]['rgb'].numpy().astype(np.float64)
+    mse = float(np.mean((im - smp.get_img().astype(np.float64)) ** 2))
+    return rgb_mse, im, mse, float(TC.psnr(mse))
+
+
+@pytest.mark.parametrize('mode', ['rgbonly', 'mse'])
+def test_training_trajectory_psnr_against_reference(mode):
+    """VERDICT r03 item 3.  The imported reference trained 200 steps on the config-1 scene (tests/golden/trajectory.npz);
+    the HIP trainer replays the same batches and uniforms.  Gates: the split-bf16 forward modes (the ones that carry the
+    1e-4 output parity) end within 0.05 dB of the float32 reference in render PSNR and in the mean in-loop PSNR of the last
+    25 steps; single-pass bf16 within the bound stated below (its measured gap is recorded in the JSON this test writes)."""
+    import json
+    import trajectory_common as TC
+    g = np.load(os.path.join(GOLD, 'trajectory.npz'))
+    ref_psnr = float(g[mode + '.f32.render_psnr'])
+    ref_tail = float(np.mean(TC.psnr(g[mode + '.f32.tail_rgb_mse'][:, 1])))
+    f64_gap = abs(float(g[mode + '.f64.render_psnr']) - ref_psnr)             # noise floor of the float32 reference itself
+    report = {'mode': mode, 'reference_f32_render_psnr': ref_psnr, 'reference_f64_minus_f32_db': float(g[mode + '.f64.render_psnr']) - ref_psnr,
+              'reference_tail_inloop_psnr_L1': ref_tail}
+    from outdoor_nerf_depth_amd import _lib as L
+    for name, prec in (('split_bf16', L.PREC_SPLIT_BF16), ('split_fwd', L.PREC_SPLIT_FWD), ('bf16', L.PREC_BF16)):
+        rgb_mse, im, mse, ps = _trajectory(prec, mode)
+        tail = float(np.mean(TC.psnr(rgb_mse[-TC.LOG_EVERY:, 1])))
+        logged = rgb_mse[TC.LOG_EVERY - 1::TC.LOG_EVERY]
+        report[name] = {'render_psnr': ps, 'render_gap_db': ps - ref_psnr, 'tail_inloop_psnr_L1': tail,
+                        'tail_gap_db': tail - ref_tail,
+                        'logged_rgb_mse_rel_dev_max': float(np.max(np.abs(logged[:, 1] / g[mode + '.f32.rgb1'] - 1.0))),
+                        'image_rms_vs_reference': float(np.sqrt(np.mean((im.reshape(-1, 3) - g[mode + '.f32.render_rgb']) ** 2)))}
+    # Gate: within 0.05 dB of the band spanned by the reference's own float32 and float64 runs (rgb-only: the two agree to
+    # 0.005 dB, so this IS "within 0.05 dB of the reference"; with the depth term the reference moves by 0.10 dB between its
+    # own two precisions after 200 steps, and no implementation can be pinned tighter than that to either of them)
+    lo_r, hi_r = sorted([ref_psnr, float(g[mode + '.f64.render_psnr'])])
+    f64_tail = float(np.mean(TC.psnr(g[mode + '.f64.tail_rgb_mse'][:, 1])))
+    lo_t, hi_t = sorted([ref_tail, f64_tail])
+    report['gate'] = {'render_band': [lo_r - 0.05, hi_r + 0.05], 'tail_band': [lo_t - 0.05, hi_t + 0.05], 'reference_f64_gap_db': f64_gap}
+    out = os.path.join(os.path.dirname(HERE), 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'trajectory_%s.json' % mode), 'w') as f:
+            json.dump(report, f, indent=1)
+    print(json.dumps(report))
+    for name in ('split_bf16', 'split_fwd'):
+        assert lo_r - 0.05 <= report[name]['render_psnr'] <= hi_r + 0.05, (name, report[name], lo_r, hi_r)
+        assert lo_t - 0.05 <= report[name]['tail_inloop_psnr_L1'] <= hi_t + 0.05, (name, report[name], lo_t, hi_t)
+    assert abs(report['bf16']['render_gap_db']) <= 0.5, report['bf16']
+    assert abs(report['bf16']['tail_gap_db']) <= 0.5, report['bf16']

@@ -298,3 +298,23 @@ def test_torch_cpu_baseline_matches_numpy_oracle(kind):
         for k, v in levels[m].items():                              # after Adam (first step moves every weight by ~lr)
             bad = np.abs(tc.params(m)[k] - v) > 2e-5
             assert bad.mean() < 0.02, (m, k, bad.mean())
+
+
+def test_torch_cpu_trainer_follows_the_reference_trajectory():
+    """tests/golden/trajectory.npz (make_golden.py gen_trajectory: the imported reference's training loop, 200 steps on the
+    config-1 scene): the torch-CPU restatement replays the first 25 steps on the same batches and uniforms and must log
+    the reference's level losses (float32 summation orders differ: 2e-3 relative after 25 Adam steps)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import trajectory_common as TC
+    from oracle import nerfpp_torch_cpu as TCPU
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trajectory.npz'))
+    smp = TC.sampler()
+    for mode in TC.MODES:
+        tc = TCPU.TorchCpuTrainer(O.init_params_like_reference(2), cascade_samples=TC.CASCADE, use_depth=(mode != 'rgbonly'),
+                                  depth_loss_type='mse', lambda_depth=TC.LAMBDA_DEPTH)
+        for step in range(1, TC.LOG_EVERY + 1):
+            logs = tc.train_step(TC.step_batch(smp, step), TC.step_uniforms(step))
+        for m in range(2):
+            np.testing.assert_allclose(logs[m]['loss'], g['%s.f32.loss%d' % (mode, m)][0], rtol=2e-3)
+            np.testing.assert_allclose(logs[m]['rgb_loss'], g['%s.f32.rgb%d' % (mode, m)][0], rtol=2e-3)

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Per-block cycle stamps of the fused MLP kernels (probes build, csrc/nerfpp_mlp_probes.h: -DNERFPP_STAMPS=k).
+
+    tools/probes/variant.sh stamps4 "-DNERFPP_STAMPS=4"        # forward, fg net, bf16 training
+    NERFPP_HIP_LIB=.../variants/stamps4.so python tools/probes/stamps_probe.py --what fwd --out gpurun_out/x/stamps4
+
+Every wave stamps s_memtime when it ARRIVES at a block boundary (before its waits + the barrier) and when the barrier
+RELEASES it.  Printed: per workgroup the cycles per block (release to release), which wave arrives last and how long the
+others have waited for it, split by stage.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from outdoor_nerf_depth_amd import ops, _lib as L            # noqa: E402
+from outdoor_nerf_depth_amd.model import init_level_params   # noqa: E402
+from outdoor_nerf_depth_amd.synthetic import SyntheticKitti  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--what', default='fwd', choices=['fwd', 'bwd'])
+    p.add_argument('--n_rays', type=int, default=1024)
+    p.add_argument('--out', default='stamps')
+    a = p.parse_args()
+    dev = torch.device('cuda:0')
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    b = SyntheticKitti().random_batch(a.n_rays, np.random.RandomState(0))
+    ray_o, ray_d = T(b['ray_o']), T(b['ray_d'])
+    far, fg_z, bg_z = ops.sample_coarse(ray_o, ray_d, T(b['min_depth']), 192)
+    eng = ops.LevelEngine(init_level_params(1)[0].to(dev), precision=1)
+    for _ in range(30):                                          # clocks up
+        ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True)
+        if a.what == 'bwd':
+            eng.backward(torch.rand_like(ret['rgb']) * 1e-3, torch.rand_like(ret['depth']) * 1e-3, None)
+    torch.cuda.synchronize()
+    lib = L.lib()
+    buf = np.zeros((8, 8, 96, 2), np.uint32)
+    fn = lib.nerfpp_probe_stamps
+    fn.argtypes = [C.c_void_p, C.c_int]
+    rc = fn(buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+    assert rc == 0, 'nerfpp_probe_stamps rc=%d (is this the stamps build?)' % rc
+    np.save(a.out + '.npy', buf)
+    arr, rel = buf[..., 0].astype(np.int64), buf[..., 1].astype(np.int64)
+    nblk = int((rel[0, 0] != 0).sum())
+    rep = {'what': a.what, 'blocks': nblk, 'workgroups': []}
+    for wg in range(8):
+        r = rel[wg, :, :nblk]
+        ar = arr[wg, :, :nblk]
+        if r[0, 0] == 0:
+            continue
+        per_blk = np.diff(r[0])                                   # release to release (all waves release together)
+        last = ar.argmax(0)                                       # wave that arrived last at each block boundary
+        wait = (r - ar)                                           # cycles each wave waited at the boundary
+        rep['workgroups'].append({
+            'wg_slot': wg, 'total_cycles': int(r[0, -1] - ar[:, 0].min()),
+            'cycles_per_block_mean': float(per_blk.mean()), 'cycles_per_block_p10_p50_p90': [float(x) for x in np.percentile(per_blk, [10, 50, 90])],
+            'last_arriver_histogram': np.bincount(last, minlength=8).tolist(),
+            'mean_wait_per_wave': [float(x) for x in wait.mean(1)],
+            'release_skew_max': int((r.max(0) - r.min(0)).max()),
+            'per_block_cycles': per_blk.tolist(), 'last_arriver': last.tolist()})
+    with open(a.out + '.json', 'w') as f:
+        json.dump(rep, f)
+    for w in rep['workgroups']:
+        print('wg %d: %d blocks, %.0f cycles/block (p10/50/90 %s), total %d; last arriver by wave %s; mean wait by wave %s'
+              % (w['wg_slot'], nblk, w['cycles_per_block_mean'], w['cycles_per_block_p10_p50_p90'], w['total_cycles'],
+                 w['last_arriver_histogram'], ['%.0f' % x for x in w['mean_wait_per_wave']]))
+
+
+if __name__ == '__main__':
+    main()
