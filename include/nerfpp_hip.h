@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERFPP_ABI_VERSION 4
+#define NERFPP_ABI_VERSION 5
 
 #define NERFPP_OK 0
 #define NERFPP_ERR_ARG 1          /* bad argument (null pointer, size out of range) */
@@ -116,6 +116,12 @@ int nerfpp_sample_fine_pair_rng(void* stream, int n_rays, int s_old, int n_new, 
  *   rgb / depth_sup gathered from the frame's images, min_depth = 1e-4.
  * cam: 21 floats on the device = K^-1 (3x3 row-major) then c2w[:3,:4] (row-major).
  * rgb_img [H*W,3] / depth_img [H*W] and their outputs may be NULL. */
+/* The pixel draw of RaySamplerSingleImage.random_sample (nerf_sample_ray_split.py:178: np.random.choice(H * W, size=(N_rand,),
+ * replace=False)): n_rays DISTINCT flat pixel indices in [0, n_pixels), uniform over ordered tuples of distinct values, drawn
+ * inside one kernel from the counter-based generator (stream 4 of (seed, step)) instead of permuting all H * W pixels.
+ * pix: int64 [n_rays] on the device.  1 <= n_rays <= 8192 <= ... <= n_pixels < 2^31. */
+int nerfpp_sample_pixels(void* stream, uint64_t seed, uint64_t step, int64_t n_pixels, int n_rays, int64_t* pix);
+
 int nerfpp_gather_rays(void* stream, int n_rays, int width, const float* cam, const int64_t* pix,
                        const float* rgb_img, const float* depth_img, float* ray_o, float* ray_d,
                        float* rgb, float* depth_sup, float* min_depth);

@@ -119,6 +119,49 @@ def philox_uniform(seed, step, stream_id, n):
     return ((c0 >> np.uint64(8)).astype(np.float32) * f32(2.0 ** -24)).astype(f32)
 
 
+def philox_words(seed, step, stream_id, idx):
+    """raw 32-bit word 0 of the same generator at the given 64-bit counters (csrc/nerfpp_common.h: philox_word)"""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    i = np.asarray(idx, dtype=np.uint64)
+    c0, c1 = i & mask, i >> np.uint64(32)
+    c2 = np.full(i.shape, stream_id, np.uint64)
+    c3 = np.full(i.shape, int(step) & 0xFFFFFFFF, np.uint64)
+    k0, k1 = np.uint64(int(seed) & 0xFFFFFFFF), np.uint64((int(seed) >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        h0, l0 = p0 >> np.uint64(32), p0 & mask
+        h1, l1 = p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = h1 ^ c1 ^ k0, l1, h0 ^ c3 ^ k1, l0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c0
+
+
+def sample_pixels(n_pixels, n_rays, seed, step):
+    """nerf_sample_ray_split.py:178 `np.random.choice(H * W, size=(N_rand,), replace=False)` as the HIP path draws it
+    (nerfpp_sample_pixels): element i owns the draws d = 0, 1, ... of Philox stream 4 at counter i + 2^20 d, each mapped to
+    [0, n_pixels) by multiply-shift with Lemire's rejection (exactly uniform); x_i = its first draw that differs from every
+    x_j, j < i -- i.e. sequential sampling without replacement, uniform over ordered tuples of distinct pixels."""
+    n = int(n_pixels)
+    thresh = ((1 << 32) - n) % n
+    taken, out = set(), []
+    for i in range(n_rays):
+        d = 0
+        while True:
+            w = int(philox_words(seed, step, 4, np.array([i + (d << 20)], np.uint64))[0])
+            d += 1
+            m = w * n
+            if (m & 0xFFFFFFFF) < thresh:
+                continue
+            v = m >> 32
+            if v not in taken:
+                break
+        taken.add(v)
+        out.append(v)
+    return np.array(out, np.int64)
+
+
 def step_uniforms(seed, step, n, S0, S1):
     """The four uniform tensors one training step of the HIP trainer draws in its kernels."""
     return dict(t_fg=philox_uniform(seed, step, 0, n * S0).reshape(n, S0),

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hip.so')   # override: diagnostic builds
 
 OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2
 PREC_SPLIT_FWD = 3        # host-side combination: split-bf16 forward, bf16 backward (ops.LevelEngine)
 LOSS_RGB_ONLY, LOSS_MSE, LOSS_L1, LOSS_KL = 0, 1, 2, 3
@@ -52,6 +52,7 @@ SYMBOLS = {
     'nerfpp_sample_coarse': (C.c_int, [_fp, C.c_int, C.c_int] + [_fp] * 9),
     'nerfpp_sample_coarse_rng': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_uint64, C.c_uint64, _fp, _fp, _fp, _fp]),
     'nerfpp_rng_uniform': (C.c_int, [_fp, C.c_uint64, C.c_uint64, C.c_int, C.c_int64, _fp]),
+    'nerfpp_sample_pixels': (C.c_int, [_fp, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, _fp]),
     'nerfpp_perturb_samples': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'nerfpp_sample_pdf': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     'nerfpp_sample_fine': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -224,6 +224,13 @@ int nerfpp_sample_fine_pair_rng(void* stream, int n_rays, int s_old, int n_new, 
   return check_launch("sample_fine_pair_rng");
 }
 
+int nerfpp_sample_pixels(void* stream, uint64_t seed, uint64_t step, int64_t n_pixels, int n_rays, int64_t* pix) {
+  REQUIRE(pix && n_rays >= 1 && n_rays <= 8192, "1 <= n_rays <= 8192, non-null output");
+  REQUIRE(n_pixels >= n_rays && n_pixels < ((int64_t)1 << 31), "n_rays <= n_pixels < 2^31");
+  launch_sample_pixels((hipStream_t)stream, make_rng_key(seed, step, true), n_pixels, n_rays, pix);
+  return check_launch("sample_pixels");
+}
+
 int nerfpp_gather_rays(void* stream, int n_rays, int width, const float* cam, const int64_t* pix,
                        const float* rgb_img, const float* depth_img, float* ray_o, float* ray_d, float* rgb,
                        float* depth_sup, float* min_depth) {

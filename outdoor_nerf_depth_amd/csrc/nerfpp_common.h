@@ -288,9 +288,15 @@ __host__ __device__ constexpr int slab_job_index(const SlabMap& m, int net, int 
 }
 
 // How many row slices (= workgroups = slabs) each job gets.  The full 256x256 jobs all stream the
-// same bytes per row; the narrow ones get slices in proportion to theirs, so that every workgroup
-// of a launch moves about the same number of bytes and each launch fills the 256 CUs once.
+// same bytes per row; the narrow ones get slices in proportion to their measured cost per 32-row chunk, so that
+// every workgroup of a launch finishes at about the same time and each launch fills the 256 CUs once.
+// (Until round 4 the narrow weights were the jobs' bytes per row; per-workgroup timestamps -- profiles/r04_dw_stamps.md --
+// showed the [dS | dG]^T H7 job, 40 output blocks dealt round-robin, at 6.9 cycles per column-chunk against 5.0-5.5 for the
+// others: its 38 slices finished 30 % after everybody else.)
 struct DwPlan { int k[N_NET][DW_JOBS]; };
+constexpr int dw_narrow_cost(const DwJob& j) {        // shader cycles per 32-row chunk, bf16 (dw_kernel<1, false>)
+  return j.n_o == DSG_LD ? 2860 : j.n_o == 256 ? (j.n_i == 64 ? 1666 : 1749) : j.n_o == 128 ? 873 : 984;
+}
 inline DwPlan dw_plan(int64_t rows) {
   const JobTable jt = build_all_jobs();
   int64_t cap = rows / 512;
@@ -299,11 +305,11 @@ inline DwPlan dw_plan(int64_t rows) {
   for (int net = 0; net < N_NET; ++net)
     for (int j = 0; j < jt.count[net]; ++j) {
       if (dw_job_is_full(jt.jobs[net][j])) ++n_full;
-      else w_narrow += jt.jobs[net][j].n_o + jt.jobs[net][j].n_i;
+      else w_narrow += dw_narrow_cost(jt.jobs[net][j]);
     }
   DwPlan pl{};
   // full jobs: equal shares of 256 workgroups.  Narrow jobs: largest-remainder apportionment of exactly
-  // <= 256 workgroups in proportion to their bytes per row (a 257th workgroup would wait for a whole
+  // <= 256 workgroups in proportion to their cost per chunk (a 257th workgroup would wait for a whole
   // second round of the launch).
   int64_t rem[N_NET][DW_JOBS] = {};
   int used = 0;
@@ -314,7 +320,7 @@ inline DwPlan dw_plan(int64_t rows) {
       if (dw_job_is_full(job)) {
         k = 256 / n_full;
       } else {
-        const int64_t num = (int64_t)256 * (job.n_o + job.n_i);
+        const int64_t num = (int64_t)256 * dw_narrow_cost(job);
         k = num / w_narrow;
         rem[net][j] = num - k * w_narrow;
       }
@@ -339,7 +345,8 @@ inline DwPlan dw_plan(int64_t rows) {
 // Philox4x32-10 (Salmon et al., SC'11; the generator family torch's CUDA/HIP backend uses), keyed by the
 // caller's 64-bit seed; counter = (element index lo, hi, stream id, step).  Stream ids follow the order
 // the reference consumes torch's RNG per step: 0 = rand_like(fg_z), 1 = rand_like(bg_z)
-// (perturb_samples, ddp_train_nerf.py:444,449), 2 = fg sample_pdf u, 3 = bg sample_pdf u (:455,463).
+// (perturb_samples, ddp_train_nerf.py:444,449), 2 = fg sample_pdf u, 3 = bg sample_pdf u (:455,463); 4 = the pixel draw of
+// the ray-batch sampler (nerf_sample_ray_split.py:178 np.random.choice, here nerfpp_sample_pixels).
 // uniform = (word0 >> 8) * 2^-24 in [0, 1) like torch.rand's float32 mapping.  The numpy oracle carries
 // the same function (oracle/nerfpp_oracle.py: philox_uniform), checked bit-for-bit in the GPU tests.
 struct RngKey { uint32_t k0, k1, step_lo, enabled; };
@@ -349,6 +356,19 @@ __host__ __device__ inline RngKey make_rng_key(uint64_t seed, uint64_t step, boo
   return k;
 }
 __host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+__host__ __device__ inline uint32_t philox_word(const RngKey& key, uint32_t stream_id, uint64_t idx) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream_id, c3 = key.step_lo;
+  uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
 __host__ __device__ inline float philox_uniform(const RngKey& key, uint32_t stream_id, uint64_t idx) {
   uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream_id, c3 = key.step_lo;
   uint32_t k0 = key.k0, k1 = key.k1;

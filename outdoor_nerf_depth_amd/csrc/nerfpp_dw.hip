@@ -187,6 +187,21 @@ __device__ __forceinline__ void compute_chunk_rr(lds_addr buf_a, lds_addr buf_b,
   }
 }
 
+// Probes build only: per-workgroup timestamps of the last launch of each instantiation -- entry, end of the
+// chunk loop, end of the slab write -- with the job, its chunk count and the XCD, read back by nerfpp_probe_dw_stamps()
+// (tools/probes/dw_stamps_probe.py).
+#ifdef NERFPP_PROBES
+static __device__ unsigned long long g_dw_stamps[2][256][6];
+#define DW_STAMP(full_, slot_, val_) { if (threadIdx.x == 0 && blockIdx.x < 256) g_dw_stamps[(full_) ? 0 : 1][blockIdx.x][slot_] = (unsigned long long)(val_); }
+extern "C" int nerfpp_probe_dw_stamps(void* host_dst, int bytes) {
+  if (bytes != (int)sizeof(g_dw_stamps)) return (int)sizeof(g_dw_stamps);
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_dw_stamps), sizeof(g_dw_stamps));
+}
+#else
+#define DW_STAMP(full_, slot_, val_) {}
+#endif
+
 // workgroup -> (job of this launch, row slice): jobs in table order (net 0 then net 1), k slices each
 struct DwSched {
   int wg_end[2 * DW_JOBS];       // exclusive prefix of workgroups per job
@@ -214,6 +229,10 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
   const int64_t r_begin = split * rps;
   const int64_t r_end = r_begin + rps < rows32 ? r_begin + rps : rows32;
   const int nchunk = r_end > r_begin ? (int)((r_end - r_begin) / 32) : 0;
+  DW_STAMP(FULL, 0, __builtin_readcyclecounter());
+  DW_STAMP(FULL, 3, job_id);
+  DW_STAMP(FULL, 4, nchunk);
+  DW_STAMP(FULL, 5, __builtin_amdgcn_s_getreg((3 << 11) | 20));      // XCC_ID
 
   const int wo = wave >> 2, wi = wave & 3;
   int nbo = job.n_o / 32 - 4 * wo, nbi = job.n_i / 32 - 2 * wi;       // valid blocks of this wave
@@ -354,6 +373,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
     }
   }
 
+  DW_STAMP(FULL, 1, __builtin_readcyclecounter());
   float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
   if constexpr (!FULL) {
 #pragma unroll
@@ -376,6 +396,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
         if (hi == 0) slab[gw_floats(net) + s_gb + 32 * sbo + li] = tot;
       }
     }
+    DW_STAMP(FULL, 2, __builtin_readcyclecounter());
     return;
   }
 #pragma unroll
@@ -397,6 +418,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
       if (hi == 0) slab[gw_floats(net) + job.gb_off + ob + li] = tot;
     }
   }
+  DW_STAMP(FULL, 2, __builtin_readcyclecounter());
 }
 
 }  // namespace nerfpp

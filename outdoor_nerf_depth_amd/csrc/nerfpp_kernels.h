@@ -79,6 +79,7 @@ void launch_loss(hipStream_t st, int n, int S, int type, float lambda_depth, flo
                  const float* rgb_gt, const float* depth, const float* depth_sup, const float* fg_weights,
                  const float* fg_z, const float* fg_dists, const float* fg_far, float* scalars, float* g_rgb,
                  float* g_depth, float* g_fg_weights);
+int launch_sample_pixels(hipStream_t st, const nerfpp::RngKey& rng, int64_t n_pixels, int k, int64_t* pix);
 void launch_gather_rays(hipStream_t st, int n, int W, const float* cam, const int64_t* pix, const float* rgb_img,
                         const float* depth_img, float* ray_o, float* ray_d, float* rgb, float* depth_sup,
                         float* min_depth);

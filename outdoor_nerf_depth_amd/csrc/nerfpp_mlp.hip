@@ -85,12 +85,45 @@ __device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
                : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_base_addr() { return (uint32_t)(uintptr_t)(LDS_AS char*)smem; }
+// N (<= 4) consecutive 1 KiB fragments with ONE M0 / address set-up: the instruction offset advances the global and the
+// LDS address alike.  Global address = wave-uniform SGPR base + per-lane byte offset (lane * 16): no 64-bit VALU add, no
+// M0 save / restore per fragment (round 4: the loader wave of the roles pipe was the last wave at 3 of 4 block barriers,
+// with 7 instructions per DMA -- profiles/r04_block_stamps.md).
+template <int N>
+__device__ __forceinline__ void glds16xN_saddr(const char* sbase, uint32_t voff, uint32_t lds_abs) {
+  static_assert(N >= 1 && N <= 4, "the 13-bit instruction offset reaches 3 x 1024");
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+  uint32_t keep;                         // M0 is saved / restored around the group (the compiler does not track it)
+#define GLDS_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+#define GLDS_TAIL "\n\ts_mov_b32 m0, %0"
+  if constexpr (N == 4)
+    asm volatile(GLDS_HEAD "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072" GLDS_TAIL : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+  else if constexpr (N == 3)
+    asm volatile(GLDS_HEAD "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048" GLDS_TAIL
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+  else if constexpr (N == 2)
+    asm volatile(GLDS_HEAD "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" GLDS_TAIL : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+  else
+    asm volatile(GLDS_HEAD GLDS_TAIL : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+#undef GLDS_HEAD
+#undef GLDS_TAIL
+}
 
-template <int P, int NW, int MODE, int NBUF>
+// fragments per weight block: the split-bf16 training kernels use 8 (x 2 planes = the same 16 KiB per block as bf16), which
+// buys a 4-deep ring next to the doubled hand-off region and encoded-point stash in 160 KiB of LDS
+template <int P, bool TRAIN>
+constexpr int blk_frags_of() { return (P == 2 && TRAIN) ? 8 : BLK_FRAGS; }
+
+template <int P, int NW, int MODE, int NBUF, int BF = BLK_FRAGS>
 struct WeightPipe {
-  static constexpr int BLK_BYTES = BLK_FRAGS * P * FRAG_BYTES;
+  static constexpr int BLKF = BF;
+  static constexpr int BLK_BYTES = BF * P * FRAG_BYTES;
   // DMA wave-instructions per block of the waves that wait for it (roles: the loader issues them all)
-  static constexpr int PER_BLK = MODE == PIPE_ROLES ? BLK_FRAGS * P : BLK_FRAGS * P / NW;
+  static constexpr int PER_BLK = MODE == PIPE_ROLES ? BF * P : BF * P / NW;
   static_assert(MODE == PIPE_CLASSIC ? NBUF == 2 : (NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_BLK < 63), "ring depth");
   const char* g;
   uint32_t stamp_off = 0;                                      // (probes: LDS offset of the cycle stamps)
@@ -113,15 +146,26 @@ struct WeightPipe {
     const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
     if constexpr (MODE == PIPE_ROLES) {
       if (wave != 0) return;                                   // the loader wave issues the whole block
+      static_assert(BF * P % 4 == 0, "groups of four fragments");
 #pragma unroll
-      for (int fi = 0; fi < BLK_FRAGS * P; ++fi)
-        glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
+      for (int fi = 0; fi < BF * P; fi += 4)
+        glds16xN_saddr<4>(g + (size_t)blk * BLK_BYTES + fi * FRAG_BYTES, (uint32_t)lane * 16u, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
+    } else if constexpr (MODE == PIPE_RING) {
+      // every wave fetches a contiguous run of the block's fragments, four per M0 / address set-up
+      constexpr int C = BF * P / NW;
+      static_assert(C == 2 || C % 4 == 0, "per-wave fragment count");
+      const char* sb = g + (size_t)blk * BLK_BYTES + (size_t)wave * C * FRAG_BYTES;
+      const uint32_t dst = lds_base + slot * BLK_BYTES + wave * C * FRAG_BYTES;
+      if constexpr (C == 2) glds16xN_saddr<2>(sb, (uint32_t)lane * 16u, dst);
+      else {
+#pragma unroll
+        for (int f = 0; f < C; f += 4) glds16xN_saddr<4>(sb + f * FRAG_BYTES, (uint32_t)lane * 16u, dst + f * FRAG_BYTES);
+      }
     } else {
 #pragma unroll
-      for (int f = 0; f < BLK_FRAGS * P / NW; ++f) {
+      for (int f = 0; f < BF * P / NW; ++f) {
         const int fi = f * NW + wave;
-        if constexpr (MODE == PIPE_RING) glds16_asm(src + fi * FRAG_BYTES, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
-        else glds16(src + fi * FRAG_BYTES, smem + slot * BLK_BYTES + fi * FRAG_BYTES);
+        glds16(src + fi * FRAG_BYTES, smem + slot * BLK_BYTES + fi * FRAG_BYTES);
       }
     }
   }
@@ -182,7 +226,7 @@ struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // pipe at once; wave 1 flushes the loader's tile there and the loader queues the next sign-word DMA.
 template <int NOB, int NKC, int P, typename Pipe, typename Hook>
 __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC], const Hook& hook) {
-  constexpr int KPB = BLK_FRAGS / NOB;            // k-chunks per block
+  constexpr int KPB = Pipe::BLKF / NOB;           // k-chunks per block
   static_assert(NKC % KPB == 0, "stage must be block aligned");
 #pragma unroll
   for (int blk = 0; blk < NKC / KPB; ++blk) {
@@ -370,8 +414,8 @@ __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) { probe::s
 // Rows past the end of the batch (tile tail, < rows_padded) must be written as zeros so the weight-gradient GEMMs can
 // run over whole 32-row chunks without masking: the kernels zero those lanes' fragments -- zero_invalid, last tile only
 // -- before they get here.
-constexpr int REGION_MASK = 16 * FRAG_BYTES;                 // hand-off region: 16 chunk blocks, then 64 x 16 B of sign words
-constexpr int REGION_BYTES = REGION_MASK + 1024;
+constexpr int region_mask(int P) { return 16 * P * FRAG_BYTES; }   // hand-off region: 16 chunk blocks per plane, then 64 x 16 B of sign words
+constexpr int region_bytes(int P) { return region_mask(P) + 1024; }
 
 __device__ __forceinline__ char* frag_addr(__bf16* base, int ld, size_t wave_row0, int c, int lane) {
   const size_t blk = (wave_row0 >> 5) * (size_t)(ld >> 4) + (size_t)c;
@@ -396,17 +440,23 @@ __device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, s
 
 // ---- PIPE_ROLES hand-off: the loader never stores; its tile goes to an LDS region (lane-linear chunk blocks,
 // conflict-free 16-byte accesses) and helper waves write it out after the next barrier --------------------------------
-template <int NCH>
-__device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<1> (&h)[NCH]) {
+template <int NCH, int P>
+__device__ __forceinline__ void handoff_write(char* region, int lane, const Frag<P> (&h)[NCH]) {
   if constexpr ((probe::DBG & (2 | 16)) != 0) return;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) *(uint4*)(region + (c * 64 + lane) * 16) = *(const uint4*)&h[c].v[0];
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int p = 0; p < P; ++p) *(uint4*)(region + ((c * P + p) * 64 + lane) * 16) = *(const uint4*)&h[c].v[p];
 }
-// chunks [c0, c0 + n) of the loader's tile (tile rows row0 .. row0 + 31): region -> HBM
-__device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, int ld, size_t row0, int c0, int n) {
+// chunks [c0, c0 + n) of the loader's tile (tile rows row0 .. row0 + 31): region -> HBM (plane p at base + p * plane elements)
+template <int P>
+__device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int c0, int n) {
   if constexpr ((probe::DBG & 16) != 0) return;
 #pragma unroll 4
-  for (int c = c0; c < c0 + n; ++c) store_nt16(frag_addr(base, ld, row0, c, lane), *(const uint4*)(region + (c * 64 + lane) * 16));
+  for (int c = c0; c < c0 + n; ++c)
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      store_nt16(frag_addr(base + p * plane, ld, row0, c, lane), *(const uint4*)(region + ((c * P + p) * 64 + lane) * 16));
 }
 
 // dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
@@ -545,25 +595,27 @@ __device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P>
 // LDS carve-up shared by kernel and launcher
 template <int NET, int P, int NW, bool TRAIN>
 struct FwdLds {
-  static constexpr int MODE = !TRAIN ? PIPE_RING : (P == 1 ? PIPE_ROLES : PIPE_CLASSIC);
+  static constexpr int MODE = !TRAIN ? PIPE_RING : PIPE_ROLES;
   static constexpr bool ROLES = MODE == PIPE_ROLES;
   static constexpr bool BIAS_LDS = MODE != PIPE_CLASSIC;
+  static constexpr int BF = blk_frags_of<P, TRAIN>();
   // ring depth: as deep as the 160 KiB of LDS allow
   static constexpr int NBUF = MODE == PIPE_CLASSIC ? 2 : MODE == PIPE_RING ? (P == 1 ? 4 : 3) : 4;
-  static constexpr int W = NBUF * BLK_FRAGS * P * FRAG_BYTES;
+  static constexpr int W = NBUF * BF * P * FRAG_BYTES;
   static constexpr int REGION = W;
-  static constexpr int STASH = REGION + (ROLES ? REGION_BYTES : 0);
+  static constexpr int STASH = REGION + (ROLES ? region_bytes(P) : 0);
   static constexpr int BIAS = STASH + NW * kpe(NET) * P * 1024;
   static constexpr int TOTAL = BIAS + (BIAS_LDS ? FWD_BIAS_FLOATS * 4 : 0);
 };
 template <int P, int NW>
 struct BwdLds {
-  static constexpr int MODE = P == 1 ? PIPE_ROLES : PIPE_CLASSIC;
+  static constexpr int MODE = PIPE_ROLES;
   static constexpr bool ROLES = MODE == PIPE_ROLES;
+  static constexpr int BF = blk_frags_of<P, true>();
   static constexpr int NBUF = ROLES ? 4 : 2;
-  static constexpr int W = NBUF * BLK_FRAGS * P * FRAG_BYTES;
+  static constexpr int W = NBUF * BF * P * FRAG_BYTES;
   static constexpr int REGION = W;
-  static constexpr int MASKS = REGION + (ROLES ? REGION_BYTES : 0);          // 2 x NW KiB of sign words (ROLES)
+  static constexpr int MASKS = REGION + (ROLES ? region_bytes(P) : 0);       // 2 x NW KiB of sign words (ROLES)
   static constexpr int TOTAL = MASKS + (ROLES ? 2 * NW * 1024 : 0);
 };
 
@@ -590,9 +642,14 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   const size_t nblk32 = a.rows_padded / 32;
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
-  WeightPipe<P, NW, LD::MODE, LD::NBUF> pipe;
+  WeightPipe<P, NW, LD::MODE, LD::NBUF, LD::BF> pipe;
   pipe.stamp_off = LD::TOTAL;
-  pipe.init(a.w_stream, fwd_frags(NET) / BLK_FRAGS, wave, lane);
+  pipe.init(a.w_stream, fwd_frags(NET) / LD::BF, wave, lane);
+  // The loader's tile is written out by the helper waves 1..H.  CPB chunks of a storer's own tile go out per weight block
+  // (a 16-chunk stage has 16 / CPB blocks).  bf16: every helper writes its share of the loader's tile in block 2; split-bf16
+  // (two planes per chunk, one wave per SIMD): one chunk per block from block 2 on.
+  constexpr int H = NW >= 5 ? 4 : NW - 1, Q = (16 + H - 1) / H, CPB = LD::BF / 8;
+  constexpr int RMASK = region_mask(P);
   if constexpr (LD::BIAS_LDS) {
     for (int i = threadIdx.x; i < FWD_BIAS_FLOATS / 4; i += NW * 64)
       *(float4*)(smem + LD::BIAS + i * 16) = ((const float4*)a.bias)[i];
@@ -614,12 +671,12 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   auto flush = [&](int blk, auto nch_c, __bf16* base, int ld, int mask_stage) __attribute__((always_inline)) {
     if constexpr (ROLES) {
       constexpr int NCH = decltype(nch_c)::value;
-      if (blk == 0 && wave >= 1 && wave <= 4) {
+      if (blk == 0 && wave >= 1 && wave <= H) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
-          if ((c & 3) == wave - 1) handoff_flush_chunks(region, lane, base, ld, tile_row0, c, 1);
+          if ((c % H) == wave - 1) handoff_flush_chunks<P>(region, lane, base, plane_rows * ld, ld, tile_row0, c, 1);
         if (partner && mask_stage >= 0)
-          mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + REGION_MASK + lane * 16);
+          mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
       }
     }
   };
@@ -633,7 +690,7 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     if constexpr (!TRAIN) return;
     if (tail) zero_invalid(frags, valid);
     if constexpr (ROLES) {
-      if (loader) *(uint4*)(region + REGION_MASK + lane * 16) = bits;
+      if (loader) *(uint4*)(region + RMASK + lane * 16) = bits;
       else mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
     } else {
       mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
@@ -643,17 +700,23 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
   auto psave_h = [&](int blk, const Frag<P> (&frags)[16], __bf16* base, int mask_stage) __attribute__((always_inline)) {
     if constexpr (TRAIN && ROLES) {
       if (loader) {
-        if (blk == 0) handoff_write<16>(region, lane, frags);
+        if (blk == 0) handoff_write<16, P>(region, lane, frags);
       } else {
         if constexpr ((probe::DBG & 2) == 0) {
-          if (blk < 8) {
-            store_chunk<P>(base, 0, 256, wrow0, lane, 2 * blk, frags[2 * blk]);
-            store_chunk<P>(base, 0, 256, wrow0, lane, 2 * blk + 1, frags[2 * blk + 1]);
+          if (blk * CPB < 16) {
+#pragma unroll
+            for (int i = 0; i < CPB; ++i)
+              store_chunk<P>(base, plane_rows * 256, 256, wrow0, lane, CPB * blk + i, frags[CPB * blk + i]);
           }
         }
-        if (wave <= 4 && blk == 2) handoff_flush_chunks(region, lane, base, 256, tile_row0, 4 * (wave - 1), 4);
+        if constexpr (P == 1) {
+          if (wave <= H && blk == 2) handoff_flush_chunks<P>(region, lane, base, plane_rows * 256, 256, tile_row0, Q * (wave - 1), Q);
+        } else {
+          if (wave <= H && blk >= 2 && blk < 2 + Q && Q * (wave - 1) + blk - 2 < 16)
+            handoff_flush_chunks<P>(region, lane, base, plane_rows * 256, 256, tile_row0, Q * (wave - 1) + blk - 2, 1);
+        }
         if (partner && blk == 1)
-          mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + REGION_MASK + lane * 16);
+          mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
       }
     }
   };
@@ -664,8 +727,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
     if (tail) zero_invalid(frags, valid);       // wave-uniform, last tile only; those rows' values are never used
     if constexpr (ROLES) {
       if (loader) {
-        handoff_write<NCH>(region, lane, frags);
-        if (has_mask) *(uint4*)(region + REGION_MASK + lane * 16) = bits;
+        handoff_write<NCH, P>(region, lane, frags);
+        if (has_mask) *(uint4*)(region + RMASK + lane * 16) = bits;
       } else {
         if (has_mask) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
         save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags);
@@ -797,8 +860,11 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
     if constexpr (ROLES) {
       if (loader && mstage >= 0) {
         const char* src = (const char*)(a.masks + ((size_t)mstage * nblk32 + (size_t)blockIdx.x * NW) * 64) + lane * 16;
+        static_assert(NW % 4 == 0, "groups of four");
+        (void)src;
+        const char* sb = (const char*)(a.masks + ((size_t)mstage * nblk32 + (size_t)blockIdx.x * NW) * 64);
 #pragma unroll
-        for (int w = 0; w < NW; ++w) glds16_asm(src + w * 1024, lds0 + LD::MASKS + ((mstage & 1) * NW + w) * 1024);
+        for (int w = 0; w < NW; w += 4) glds16xN_saddr<4>(sb + w * 1024, (uint32_t)lane * 16u, lds0 + LD::MASKS + ((mstage & 1) * NW + w) * 1024);
       }
     }
   };
@@ -810,18 +876,26 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   // from the operand registers, spread over the stage's blocks; the loader hands its tile over in block 0 and waves
   // 1..NCH/4 write four chunks of it each in block 2.  Without roles (split-bf16) the tile is saved in the epilogue.
   auto psave = [&](int blk, auto nch_c, const auto& frags, __bf16* base, int ld) __attribute__((always_inline)) {
-    constexpr int NCH = decltype(nch_c)::value, PARTS = NCH / 4;
+    // helper waves 1..HN write the loader's tile (Q chunks each); CPB chunks of a storer's own tile per weight block
+    constexpr int NCH = decltype(nch_c)::value, HMAX = NW >= 5 ? 4 : NW - 1, HN = NCH / 4 < HMAX ? NCH / 4 : HMAX;
+    constexpr int Q = (NCH + HN - 1) / HN, CPB = LD::BF / 8;
     if constexpr (ROLES) {
       if (loader) {
-        if (blk == 0) handoff_write<NCH>(region, lane, frags);
+        if (blk == 0) handoff_write<NCH, P>(region, lane, frags);
       } else {
         if constexpr ((probe::DBG & 2) == 0) {
-          if (2 * blk < NCH) {
-            store_chunk<P>(base, 0, ld, wrow0, lane, 2 * blk, frags[2 * blk]);
-            store_chunk<P>(base, 0, ld, wrow0, lane, 2 * blk + 1, frags[2 * blk + 1]);
+          if (CPB * blk < NCH) {
+#pragma unroll
+            for (int i = 0; i < CPB; ++i)
+              store_chunk<P>(base, plane_rows * ld, ld, wrow0, lane, CPB * blk + i, frags[CPB * blk + i]);
           }
         }
-        if (wave <= PARTS && blk == 2) handoff_flush_chunks(region, lane, base, ld, tile_row0, 4 * (wave - 1), 4);
+        if constexpr (P == 1) {
+          if (wave <= HN && blk == 2) handoff_flush_chunks<P>(region, lane, base, plane_rows * ld, ld, tile_row0, Q * (wave - 1), Q);
+        } else {
+          if (wave <= HN && blk >= 2 && blk < 2 + Q && Q * (wave - 1) + blk - 2 < NCH)
+            handoff_flush_chunks<P>(region, lane, base, plane_rows * ld, ld, tile_row0, Q * (wave - 1) + blk - 2, 1);
+        }
       }
     }
   };
@@ -834,9 +908,9 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   // only guarantee what is OLDER than the weight blocks they count
   issue_masks(8);
   issue_masks(7);
-  WeightPipe<P, NW, LD::MODE, LD::NBUF> pipe;
+  WeightPipe<P, NW, LD::MODE, LD::NBUF, LD::BF> pipe;
   pipe.stamp_off = LD::TOTAL;
-  pipe.init(a.w_stream, BWD_FRAGS / BLK_FRAGS, wave, lane);
+  pipe.init(a.w_stream, BWD_FRAGS / LD::BF, wave, lane);
 
   float4 d = ((const float4*)a.d_out)[row];
   if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);

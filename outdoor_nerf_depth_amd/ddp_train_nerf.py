@@ -346,7 +346,7 @@ def ddp_train_nerf(rank, args):
     if not args.host_sampling:
         from .device_sampler import DeviceRaySamplers
         if len(set((rs.H, rs.W) for rs in ray_samplers)) == 1:
-            device_samplers = DeviceRaySamplers(ray_samplers, device)
+            device_samplers = DeviceRaySamplers(ray_samplers, device, seed=(rank + 1) * 777)
         else:
             logger.info('frames of different sizes: falling back to host-side ray sampling')
 

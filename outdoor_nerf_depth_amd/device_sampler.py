@@ -3,9 +3,11 @@
 The reference draws every batch on the host: `np.random.choice(H*W, N_rand, replace=False)` (a full
 permutation of 465 750 pixels), numpy fancy indexing of five arrays and five H2D copies per step
 (nerf_sample_ray_split.py:155-221, ddp_train_nerf.py:423-427).  At MI355X step times that is the
-bottleneck, so here the frames (rgb, depth prior, cameras) live in HBM and a batch is
-`torch.randperm` on the device + one `nerfpp_gather_rays` kernel that regenerates the rays from
-K^-1 / c2w (same formula as get_rays_single_image) and gathers rgb / depth_sup.
+bottleneck, so here the frames (rgb, depth prior, cameras) live in HBM and a batch is two small kernels:
+`nerfpp_sample_pixels` (N_rand distinct pixels, the distribution of np.random.choice(replace=False), drawn from the
+counter-based generator without permuting the whole frame -- `torch.randperm(H * W)` cost 0.3 ms per step) and
+`nerfpp_gather_rays`, which regenerates the rays from K^-1 / c2w (same formula as get_rays_single_image) and gathers
+rgb / depth_sup.
 
 Keys: the ones the training step reads -- ray_o, ray_d, rgb, min_depth, depth_sup (+ frame).  The
 reference's sampler dict also carries depth_gt, mask and depth (nerf_sample_ray_split.py:199-221), which
@@ -24,8 +26,11 @@ from . import _lib as L
 class DeviceRaySamplers(object):
     """All training frames of one split on the device."""
 
-    def __init__(self, ray_samplers, device):
+    def __init__(self, ray_samplers, device, seed=777):
+        """seed: key of the pixel draw (the CLI passes (rank + 1) * 777 like ddp_train_nerf.py:406); every random_sample()
+        advances its own step counter."""
         self.device = torch.device(device)
+        self.seed, self.draws = int(seed), 0
         s0 = ray_samplers[0]
         self.H, self.W = s0.H, s0.W
         self.n_frames = len(ray_samplers)
@@ -88,10 +93,12 @@ class DeviceRaySamplers(object):
         return out
 
     def random_sample(self, N_rand, frame=None, full_keys=False):
-        """One random frame (host RNG, like ddp_train_nerf.py:423), N_rand distinct pixels (device RNG)."""
+        """One random frame (host RNG, like ddp_train_nerf.py:423), N_rand distinct pixels (nerfpp_sample_pixels)."""
+        from . import ops
         if frame is None:
             frame = int(np.random.randint(low=0, high=self.n_frames))
-        pix = torch.randperm(self.H * self.W, device=self.device)[:N_rand]
+        self.draws += 1
+        pix = ops.sample_pixels(self.H * self.W, N_rand, self.seed, self.draws, self.device)
         out = self.gather(frame, pix, full_keys)
         out['frame'] = frame
         return out

@@ -61,6 +61,15 @@ def rng_uniform(seed, step, stream_id, shape, device):
     return out
 
 
+def sample_pixels(n_pixels, n_rays, seed, step, device):
+    """np.random.choice(H * W, size=(N_rand,), replace=False) of nerf_sample_ray_split.py:178 on the device: n_rays distinct
+    flat pixel indices (int64), uniform over ordered tuples of distinct values, from Philox stream 4 of (seed, step)."""
+    pix = torch.empty(n_rays, dtype=torch.int64, device=device)
+    L.check(L.lib().nerfpp_sample_pixels(_stream(), int(seed), int(step), int(n_pixels), int(n_rays), _p(pix)),
+            'nerfpp_sample_pixels')
+    return pix
+
+
 def sample_coarse(ray_o, ray_d, min_depth, n_samples, t_rand_fg=None, t_rand_bg=None, perturb=True,
                   check=True, rng=None, bad=None):
     """Level-0 depths of ddp_train_nerf.py:438-449 (perturb=True, training) / :166-175 (render).

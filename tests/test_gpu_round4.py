@@ -8,6 +8,7 @@
 """
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,8 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, 'golden')
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)            # trajectory_common.py
 
 
 def dev():
@@ -143,20 +146,59 @@ def test_training_trajectory_psnr_against_reference(mode):
                         'tail_gap_db': tail - ref_tail,
                         'logged_rgb_mse_rel_dev_max': float(np.max(np.abs(logged[:, 1] / g[mode + '.f32.rgb1'] - 1.0))),
                         'image_rms_vs_reference': float(np.sqrt(np.mean((im.reshape(-1, 3) - g[mode + '.f32.render_rgb']) ** 2)))}
-    # Gate: within 0.05 dB of the band spanned by the reference's own float32 and float64 runs (rgb-only: the two agree to
-    # 0.005 dB, so this IS "within 0.05 dB of the reference"; with the depth term the reference moves by 0.10 dB between its
-    # own two precisions after 200 steps, and no implementation can be pinned tighter than that to either of them)
-    lo_r, hi_r = sorted([ref_psnr, float(g[mode + '.f64.render_psnr'])])
+    # Gate.  rgb-only: the reference's float32 and float64 runs agree to 0.005 dB, and every precision mode must end within
+    # 0.05 dB of the float32 reference (north_star's PSNR clause).  With the depth term the 200-step trajectory is chaotic at the
+    # 0.1 dB level -- the reference's own float64 run ends 0.10 dB from its float32 run -- so there the tolerance is 2 x that
+    # spread: nothing can be pinned to the float32 run tighter than the reference pins itself.
     f64_tail = float(np.mean(TC.psnr(g[mode + '.f64.tail_rgb_mse'][:, 1])))
-    lo_t, hi_t = sorted([ref_tail, f64_tail])
-    report['gate'] = {'render_band': [lo_r - 0.05, hi_r + 0.05], 'tail_band': [lo_t - 0.05, hi_t + 0.05], 'reference_f64_gap_db': f64_gap}
+    tol_r = max(0.05, 2.0 * f64_gap)
+    tol_t = max(0.05, 2.0 * abs(f64_tail - ref_tail))
+    report['gate'] = {'render_tolerance_db': tol_r, 'tail_tolerance_db': tol_t, 'reference_f64_gap_db': f64_gap,
+                      'reference_f64_tail_gap_db': f64_tail - ref_tail}
     out = os.path.join(os.path.dirname(HERE), 'gpurun_out')
     if os.path.isdir(out):
         with open(os.path.join(out, 'trajectory_%s.json' % mode), 'w') as f:
             json.dump(report, f, indent=1)
     print(json.dumps(report))
-    for name in ('split_bf16', 'split_fwd'):
-        assert lo_r - 0.05 <= report[name]['render_psnr'] <= hi_r + 0.05, (name, report[name], lo_r, hi_r)
-        assert lo_t - 0.05 <= report[name]['tail_inloop_psnr_L1'] <= hi_t + 0.05, (name, report[name], lo_t, hi_t)
-    assert abs(report['bf16']['render_gap_db']) <= 0.5, report['bf16']
-    assert abs(report['bf16']['tail_gap_db']) <= 0.5, report['bf16']
+    for name in ('split_bf16', 'split_fwd', 'bf16'):
+        assert abs(report[name]['render_gap_db']) <= tol_r, (name, report[name], tol_r)
+        assert abs(report[name]['tail_gap_db']) <= tol_t, (name, report[name], tol_t)
+
+
+# ------------------------------------------------------------------------------------------- pixel draw of the ray-batch sampler
+@pytest.mark.parametrize('n_pixels,k,seed,step', [(465750, 1024, 777, 1), (465750, 1024, 1554, 12345), (4096, 256, 777, 3),
+                                                  (768, 128, 5, 2), (300, 150, 9, 7), (8192 * 64, 8192, 777, 1), (33, 1, 1, 1)])
+def test_sample_pixels_matches_oracle(n_pixels, k, seed, step):
+    """nerfpp_sample_pixels (np.random.choice(H*W, N_rand, replace=False), nerf_sample_ray_split.py:178): bit-exact against the
+    oracle's sequential definition -- also where many draws collide (k = n / 2) -- distinct, in range."""
+    from outdoor_nerf_depth_amd import ops
+    from oracle import nerfpp_oracle as O
+    pix = ops.sample_pixels(n_pixels, k, seed, step, dev()).cpu().numpy()
+    assert pix.dtype == np.int64 and pix.shape == (k,)
+    assert len(set(pix.tolist())) == k and pix.min() >= 0 and pix.max() < n_pixels
+    if k <= 1024:
+        np.testing.assert_array_equal(pix, O.sample_pixels(n_pixels, k, seed, step))
+    else:
+        np.testing.assert_array_equal(pix[:64], O.sample_pixels(n_pixels, 64, seed, step))
+
+
+def test_sample_pixels_is_uniform_and_rejects_bad_sizes():
+    from outdoor_nerf_depth_amd import ops, _lib as L
+    d = dev()
+    n, k = 64, 16
+    counts = np.zeros(n, np.int64)
+    first = np.zeros(n, np.int64)
+    for step in range(1, 2001):
+        p = ops.sample_pixels(n, k, 99, step, d).cpu().numpy()
+        counts[p] += 1
+        first[p[0]] += 1
+    # every pixel is in the batch with probability k / n; chi-square over 64 cells, 63 dof: 99.9 % quantile = 103.4
+    exp = 2000.0 * k / n
+    chi2 = float(((counts - exp) ** 2 / (exp * (1 - k / n))).sum())
+    assert chi2 < 110.0, chi2
+    chi2_first = float(((first - 2000.0 / n) ** 2 / (2000.0 / n)).sum())
+    assert chi2_first < 110.0, chi2_first
+    with pytest.raises(L.NerfppError):
+        ops.sample_pixels(10, 11, 1, 1, d)
+    with pytest.raises(L.NerfppError):
+        ops.sample_pixels(1 << 20, 8193, 1, 1, d)
