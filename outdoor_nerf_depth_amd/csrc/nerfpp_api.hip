@@ -111,26 +111,12 @@ NetWs make_netws(char* ws, const WsLayout& L, int net) {
 
 bool prec_ok(int P) { return P == NERFPP_PREC_BF16 || P == NERFPP_PREC_SPLIT_BF16; }
 
-// The foreground and background nets of a level are independent until the compositing kernel, and each of their
-// kernels is one workgroup per CU: launched back to back on one stream, the second waits for the LAST workgroup of the
-// first (a full drain + ramp per pair, ~20 us at level 0 where a launch is a single round of 256 workgroups).  With
-// NERFPP_OVERLAP_NETS=1 the background kernel goes to a per-device side stream forked from / joined to the caller's
-// stream with events, so its workgroups fill CUs as the foreground's tail frees them.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
-SideStream* side_stream() {
-  static const bool enabled = PROBE_GETENV("NERFPP_OVERLAP_NETS") ? atoi(PROBE_GETENV("NERFPP_OVERLAP_NETS")) != 0 : false;
-  if (!enabled) return nullptr;
-  static SideStream table[16];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  SideStream& t = table[dev];
-  if (!t.ok) {
-    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    t.ok = true;
-  }
-  return &t;
+// The foreground and background nets of a level are independent until the compositing kernel: their MLP kernels run as ONE
+// launch (fg tiles first, bg tiles as CUs free up), one start-up and one tail instead of two.  Probes build only:
+// NERFPP_MLP_SPLIT=1 launches the same kernel once per net (the two-launch form of rounds 1-3) for A/B runs.
+bool split_nets() {
+  static const bool on = PROBE_GETENV("NERFPP_MLP_SPLIT") != nullptr;
+  return on;
 }
 
 }  // namespace
@@ -320,9 +306,10 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
   const PackLayout PL = pack_layout(P);
   char* ws = (char*)a->workspace;
   const char* pk = (const char*)a->packed;
-  SideStream* side = side_stream();
+  MlpFwdArgs mm[N_NET];
   for (int net = 0; net < N_NET; ++net) {
-    MlpFwdArgs m{};
+    MlpFwdArgs& m = mm[net];
+    m = MlpFwdArgs{};
     m.geom.ray_o = a->ray_o;
     m.geom.ray_d = a->ray_d;
     m.geom.z = net == 0 ? a->fg_z : a->bg_z;
@@ -334,12 +321,15 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     m.out_raw = (float*)(ws + L.out_raw[net]);
     m.depth_real = (float*)(ws + L.depth_real);
     if (train) { m.ws = make_netws(ws, L, net); m.masks = (uint4*)(ws + L.masks[net]); }
-    if (net == 0 && a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
-    if (side && net == 0) { (void)hipEventRecord(side->fork, st); (void)hipStreamWaitEvent(side->s, side->fork, 0); }
-    launch_mlp_fwd(side && net == 1 ? side->s : st, net, P, train, m);
-    if (side && net == 1) { (void)hipEventRecord(side->join, side->s); (void)hipStreamWaitEvent(st, side->join, 0); }
-    if (net == N_NET - 1 && a->ev_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_mlp_end, st);
   }
+  if (a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
+  if (split_nets()) {
+    launch_mlp_fwd_pair(st, P, train, mm[0], mm[1], 1);
+    launch_mlp_fwd_pair(st, P, train, mm[0], mm[1], 2);
+  } else {
+    launch_mlp_fwd_pair(st, P, train, mm[0], mm[1], 0);
+  }
+  if (a->ev_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_mlp_end, st);
   launch_composite_fwd(st, a->n_rays, a->n_samples, (const float*)(ws + L.out_raw[0]),
                        (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
                        a->fg_z, a->bg_z, a->rgb, a->depth, a->fg_weights, a->bg_weights, a->fg_dists, a->fg_rgb,
@@ -447,21 +437,25 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
                        (const float*)(ws + L.out_raw[1]), (const float*)(ws + L.depth_real), a->ray_d, a->fg_far,
                        a->fg_z, a->bg_z, a->g_rgb, a->g_depth, a->g_fg_weights, (float*)(ws + L.d_out[0]),
                        (float*)(ws + L.d_out[1]), a->fused_loss ? &lf : nullptr);
-  SideStream* side = side_stream();
+  MlpBwdArgs mb[N_NET];
   for (int net = 0; net < N_NET; ++net) {
-    MlpBwdArgs m{};
+    MlpBwdArgs& m = mb[net];
+    m = MlpBwdArgs{};
     m.rows = L.rows;
     m.rows_padded = L.rows_padded;
     m.w_stream = pk + PL.bwd[net];
     m.d_out = (const float*)(ws + L.d_out[net]);
     m.ws = make_netws(ws, L, net);
     m.masks = (const uint4*)(ws + L.masks[net]);
-    if (net == 0 && a->ev_bwd_begin) (void)hipEventRecord((hipEvent_t)a->ev_bwd_begin, st);
-    if (side && net == 0) { (void)hipEventRecord(side->fork, st); (void)hipStreamWaitEvent(side->s, side->fork, 0); }
-    launch_mlp_bwd(side && net == 1 ? side->s : st, net, P, m);
-    if (side && net == 1) { (void)hipEventRecord(side->join, side->s); (void)hipStreamWaitEvent(st, side->join, 0); }
-    if (net == N_NET - 1 && a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);
   }
+  if (a->ev_bwd_begin) (void)hipEventRecord((hipEvent_t)a->ev_bwd_begin, st);
+  if (split_nets()) {
+    launch_mlp_bwd_pair(st, P, mb[0], mb[1], 1);
+    launch_mlp_bwd_pair(st, P, mb[0], mb[1], 2);
+  } else {
+    launch_mlp_bwd_pair(st, P, mb[0], mb[1], 0);
+  }
+  if (a->ev_bwd_end) (void)hipEventRecord((hipEvent_t)a->ev_bwd_end, st);
   if (!(a->defer_reduce && defer_dw())) weight_grads(st, a, L);
   if (!a->defer_reduce) reduce_grads(st, a, L, T);
   return check_launch("level_backward");

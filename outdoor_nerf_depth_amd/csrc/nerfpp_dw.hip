@@ -192,7 +192,7 @@ __device__ __forceinline__ void compute_chunk_rr(lds_addr buf_a, lds_addr buf_b,
 // (tools/probes/dw_stamps_probe.py).
 #ifdef NERFPP_PROBES
 static __device__ unsigned long long g_dw_stamps[2][256][6];
-#define DW_STAMP(full_, slot_, val_) { if (threadIdx.x == 0 && blockIdx.x < 256) g_dw_stamps[(full_) ? 0 : 1][blockIdx.x][slot_] = (unsigned long long)(val_); }
+#define DW_STAMP(full_, slot_, val_) { if (threadIdx.x == 0 && bid < 256) g_dw_stamps[(full_) ? 0 : 1][bid][slot_] = (unsigned long long)(val_); }
 extern "C" int nerfpp_probe_dw_stamps(void* host_dst, int bytes) {
   if (bytes != (int)sizeof(g_dw_stamps)) return (int)sizeof(g_dw_stamps);
   (void)hipDeviceSynchronize();
@@ -208,13 +208,14 @@ struct DwSched {
   int k[2 * DW_JOBS];
   int njobs, njobs0;
 };
+// bid: index of this workgroup among the launch's workgroups of its kind (full / narrow)
 template <int P, bool FULL>
-__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, uint32_t lds_bytes) {
+__device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int dbg, uint32_t lds_bytes, const int bid) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
   int job_id = 0;
-  for (int j = 0; j < sc.njobs - 1; ++j) job_id += (int)blockIdx.x >= sc.wg_end[j];
-  const int split = blockIdx.x - (job_id == 0 ? 0 : sc.wg_end[job_id - 1]), ksplit = sc.k[job_id];
+  for (int j = 0; j < sc.njobs - 1; ++j) job_id += bid >= sc.wg_end[j];
+  const int split = bid - (job_id == 0 ? 0 : sc.wg_end[job_id - 1]), ksplit = sc.k[job_id];
   const int njobs0 = sc.njobs0;
   const int net = job_id < njobs0 ? 0 : 1;
   const DwJob job = (FULL ? c_full : c_narrow).jobs[net][net == 0 ? job_id : job_id - njobs0];
@@ -421,6 +422,19 @@ __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, 
   DW_STAMP(FULL, 2, __builtin_readcyclecounter());
 }
 
+// Both kinds in ONE launch: the 252 full-job workgroups first (the long ones, ~2x a narrow one), the 256 narrow ones as CUs
+// free up -- one launch tail per level instead of two, and the narrow jobs fill the idle time at the end of the full round.
+template <int P>
+__global__ __launch_bounds__(512) void dw_pair_kernel(DwArgs a, DwSched sf, DwSched sn, int dbg, uint32_t lds_bytes) {
+  const int nf = sf.wg_end[sf.njobs - 1];
+  if ((int)blockIdx.x < nf) dw_body<P, true>(a, sf, dbg, lds_bytes, (int)blockIdx.x);
+  else dw_body<P, false>(a, sn, dbg, lds_bytes, (int)blockIdx.x - nf);
+}
+template <int P, bool FULL>
+__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, uint32_t lds_bytes) {
+  dw_body<P, FULL>(a, sc, dbg, lds_bytes, (int)blockIdx.x);
+}
+
 }  // namespace nerfpp
 
 using namespace nerfpp;
@@ -452,6 +466,13 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   dim3 block(512);
   const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;     // 144 KiB
   static const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
+  static const bool split_launches = PROBE_GETENV("NERFPP_DW_SPLIT") != nullptr;      // probes: the two-launch form of rounds 1-3
+  if (!split_launches) {
+    dim3 gpair(gfull.x + gnarrow.x);
+    if (P == 1) hipLaunchKernelGGL((dw_pair_kernel<1>), gpair, block, lds, st, a, sf, sn, dbg, (uint32_t)lds);
+    else hipLaunchKernelGGL((dw_pair_kernel<2>), gpair, block, lds, st, a, sf, sn, dbg, (uint32_t)lds);
+    return;
+  }
   if (P == 1) {
     hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);
     hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg, (uint32_t)lds);

@@ -84,8 +84,9 @@ void launch_gather_rays(hipStream_t st, int n, int W, const float* cam, const in
                         const float* depth_img, float* ray_o, float* ray_d, float* rgb, float* depth_sup,
                         float* min_depth);
 // nerfpp_mlp.hip
-void launch_mlp_fwd(hipStream_t st, int net, int P, bool train, const nerfpp::MlpFwdArgs& a);
-void launch_mlp_bwd(hipStream_t st, int net, int P, const nerfpp::MlpBwdArgs& a);
+// both nets of a level in one launch (which = 0), or one of them alone (1 = fg, 2 = bg)
+void launch_mlp_fwd_pair(hipStream_t st, int P, bool train, const nerfpp::MlpFwdArgs& a_fg, const nerfpp::MlpFwdArgs& a_bg, int which);
+void launch_mlp_bwd_pair(hipStream_t st, int P, const nerfpp::MlpBwdArgs& a_fg, const nerfpp::MlpBwdArgs& a_bg, int which);
 // nerfpp_dw.hip
 void launch_dw(hipStream_t st, int P, const nerfpp::DwArgs& a);
 // nerfpp_optim.hip

@@ -622,18 +622,19 @@ struct BwdLds {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// bid: this workgroup's tile among the net's tiles (the pair kernel below runs both nets of a level in one launch)
 template <int NET, int P, int NW, bool TRAIN>
-__global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpFwdArgs a) {
+__device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid) {
   using LD = FwdLds<NET, P, NW, TRAIN>;
   constexpr int KPE = kpe(NET);
   constexpr bool ROLES = LD::ROLES;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
-  const size_t row_raw = (size_t)blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
+  const size_t row_raw = (size_t)bid * (NW * 32) + wave * 32 + (lane & 31);
   const bool valid = row_raw < (size_t)a.rows;
   const size_t row = valid ? row_raw : (size_t)a.rows - 1;
   const size_t plane_rows = a.rows_padded;
-  const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;          // this wave's first tile row
+  const size_t wrow0 = (size_t)bid * (NW * 32) + wave * 32;                 // this wave's first tile row
   const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
   probe::kernel_prologue(a.out_raw);
   const bool tail = wrow0 + 32 > (size_t)a.rows;                            // wave-uniform
@@ -837,16 +838,16 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_kernel(MlpF
 // backward (dX chain).  d_out[row] = (d rgb_pre-sigmoid[3], d sigma_raw)
 // ------------------------------------------------------------------------------------------------
 template <int NET, int P, int NW>
-__global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpBwdArgs a) {
+__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a, const int bid) {
   using LD = BwdLds<P, NW>;
   constexpr bool ROLES = LD::ROLES;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
-  const size_t row_raw = (size_t)blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
+  const size_t row_raw = (size_t)bid * (NW * 32) + wave * 32 + (lane & 31);
   const bool valid = row_raw < (size_t)a.rows;
   const size_t row = valid ? row_raw : (size_t)a.rows - 1;
   const size_t plane_rows = a.rows_padded;
-  const size_t wrow0 = (size_t)blockIdx.x * (NW * 32) + wave * 32;
+  const size_t wrow0 = (size_t)bid * (NW * 32) + wave * 32;
   const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
   char* region = smem + LD::REGION;
   const size_t tile_row0 = wrow0 - (size_t)wave * 32;
@@ -859,10 +860,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   auto issue_masks = [&](int mstage) __attribute__((always_inline)) {
     if constexpr (ROLES) {
       if (loader && mstage >= 0) {
-        const char* src = (const char*)(a.masks + ((size_t)mstage * nblk32 + (size_t)blockIdx.x * NW) * 64) + lane * 16;
         static_assert(NW % 4 == 0, "groups of four");
-        (void)src;
-        const char* sb = (const char*)(a.masks + ((size_t)mstage * nblk32 + (size_t)blockIdx.x * NW) * 64);
+        const char* sb = (const char*)(a.masks + ((size_t)mstage * nblk32 + (size_t)bid * NW) * 64);
 #pragma unroll
         for (int w = 0; w < NW; w += 4) glds16xN_saddr<4>(sb + w * 1024, (uint32_t)lane * 16u, lds0 + LD::MASKS + ((mstage & 1) * NW + w) * 1024);
       }
@@ -981,93 +980,84 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_kernel(MlpB
   probe::dump_stamps(LD::TOTAL, wave, lane);
 }
 
+// Both nets of a cascade level in ONE launch: the fg net's tiles first, the bg net's as CUs free up.  They are independent
+// (ddp_model.py:86-120 evaluates the two MLPs on different points), so one launch has one start-up and one tail where two
+// launches had two (profiles/r04_pair_launch.md: ~20 us per launch boundary at N_rand = 1024, 12 MLP / weight-gradient
+// launches per step before, 6 now).  tiles0 = 0 or grid = tiles0 runs one net alone (probes: the two-launch form).
+template <int P, int NW, bool TRAIN>
+__global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_pair_kernel(MlpFwdArgs a0, MlpFwdArgs a1, int tiles0) {
+  if ((int)blockIdx.x < tiles0) mlp_fwd_body<0, P, NW, TRAIN>(a0, (int)blockIdx.x);
+  else mlp_fwd_body<1, P, NW, TRAIN>(a1, (int)blockIdx.x - tiles0);
+}
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_pair_kernel(MlpBwdArgs a0, MlpBwdArgs a1, int tiles0) {
+  if ((int)blockIdx.x < tiles0) mlp_bwd_body<0, P, NW>(a0, (int)blockIdx.x);
+  else mlp_bwd_body<1, P, NW>(a1, (int)blockIdx.x - tiles0);
+}
+
 }  // namespace nerfpp
 
 using namespace nerfpp;
 
 #define MLP_WAVES(P) ((P) == 1 ? probe::WAVES_P1 : 4)
 
-template <int NET, int P, bool TRAIN>
-static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a) {
+// which: 0 = both nets, 1 = fg only, 2 = bg only
+template <int P, bool TRAIN>
+static void launch_fwd_t(hipStream_t st, const MlpFwdArgs& a0, const MlpFwdArgs& a1, int which) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
-  const int grid = (int)((a.rows + tile - 1) / tile);
-  constexpr size_t lds = FwdLds<NET, P, NW, TRAIN>::TOTAL + probe::STAMP_BYTES;
+  const int t0 = which == 2 ? 0 : (int)((a0.rows + tile - 1) / tile), t1 = which == 1 ? 0 : (int)((a1.rows + tile - 1) / tile);
+  constexpr size_t l0 = FwdLds<0, P, NW, TRAIN>::TOTAL, l1 = FwdLds<1, P, NW, TRAIN>::TOTAL;
+  constexpr size_t lds = (l0 > l1 ? l0 : l1) + probe::STAMP_BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((mlp_fwd_kernel<NET, P, NW, TRAIN>), dim3(grid), dim3(NW * 64), lds, st, a);
+  hipLaunchKernelGGL((mlp_fwd_pair_kernel<P, NW, TRAIN>), dim3(t0 + t1), dim3(NW * 64), lds, st, a0, a1, t0);
 }
-template <int NET, int P>
-static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a) {
+template <int P>
+static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a0, const MlpBwdArgs& a1, int which) {
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
-  const int grid = (int)((a.rows + tile - 1) / tile);
+  const int t0 = which == 2 ? 0 : (int)((a0.rows + tile - 1) / tile), t1 = which == 1 ? 0 : (int)((a1.rows + tile - 1) / tile);
   constexpr size_t lds = BwdLds<P, NW>::TOTAL + probe::STAMP_BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((mlp_bwd_kernel<NET, P, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
+  hipLaunchKernelGGL((mlp_bwd_pair_kernel<P, NW>), dim3(t0 + t1), dim3(NW * 64), lds, st, a0, a1, t0);
 }
 
-// The kernels are fully unrolled instruction streams (1200 MFMAs each) and take about a minute each to compile, so the
-// in-tree build compiles this file once per kernel instantiation: -DNERFPP_MLP_PART=k emits instantiation k only
-// (k = 0..11, bit layout below; 12 = the dispatchers), no define = everything in one translation unit.
+// The kernels are fully unrolled instruction streams (2 x 1200 MFMAs each) and take minutes to compile, so the in-tree build
+// compiles this file once per kernel instantiation: -DNERFPP_MLP_PART=k emits instantiation k only (0 / 1: inference forward
+// bf16 / split-bf16, 2 / 3: training forward, 4 / 5: backward, 6: the dispatchers), no define = everything in one translation unit.
 #ifndef NERFPP_MLP_PART
 #define NERFPP_MLP_PART -1
 #endif
 #define MLP_PART(k) (NERFPP_MLP_PART == -1 || NERFPP_MLP_PART == (k))
-// forward: k = net + 2 * (P - 1) + 4 * train;  backward: k = 8 + net + 2 * (P - 1)
-#define FWD_ENTRY(NET, P, TRAIN) void launch_fwd_##NET##_##P##_##TRAIN(hipStream_t st, const MlpFwdArgs& a)
-#define BWD_ENTRY(NET, P) void launch_bwd_##NET##_##P(hipStream_t st, const MlpBwdArgs& a)
-FWD_ENTRY(0, 1, 0); FWD_ENTRY(1, 1, 0); FWD_ENTRY(0, 2, 0); FWD_ENTRY(1, 2, 0);
-FWD_ENTRY(0, 1, 1); FWD_ENTRY(1, 1, 1); FWD_ENTRY(0, 2, 1); FWD_ENTRY(1, 2, 1);
-BWD_ENTRY(0, 1); BWD_ENTRY(1, 1); BWD_ENTRY(0, 2); BWD_ENTRY(1, 2);
+#define FWD_ENTRY(P, TRAIN) void launch_fwd_##P##_##TRAIN(hipStream_t st, const MlpFwdArgs& a0, const MlpFwdArgs& a1, int which)
+#define BWD_ENTRY(P) void launch_bwd_##P(hipStream_t st, const MlpBwdArgs& a0, const MlpBwdArgs& a1, int which)
+FWD_ENTRY(1, 0); FWD_ENTRY(2, 0); FWD_ENTRY(1, 1); FWD_ENTRY(2, 1);
+BWD_ENTRY(1); BWD_ENTRY(2);
 #if MLP_PART(0)
-FWD_ENTRY(0, 1, 0) { launch_fwd_t<0, 1, false>(st, a); }
+FWD_ENTRY(1, 0) { launch_fwd_t<1, false>(st, a0, a1, which); }
 #endif
 #if MLP_PART(1)
-FWD_ENTRY(1, 1, 0) { launch_fwd_t<1, 1, false>(st, a); }
+FWD_ENTRY(2, 0) { launch_fwd_t<2, false>(st, a0, a1, which); }
 #endif
 #if MLP_PART(2)
-FWD_ENTRY(0, 2, 0) { launch_fwd_t<0, 2, false>(st, a); }
+FWD_ENTRY(1, 1) { launch_fwd_t<1, true>(st, a0, a1, which); }
 #endif
 #if MLP_PART(3)
-FWD_ENTRY(1, 2, 0) { launch_fwd_t<1, 2, false>(st, a); }
+FWD_ENTRY(2, 1) { launch_fwd_t<2, true>(st, a0, a1, which); }
 #endif
 #if MLP_PART(4)
-FWD_ENTRY(0, 1, 1) { launch_fwd_t<0, 1, true>(st, a); }
+BWD_ENTRY(1) { launch_bwd_t<1>(st, a0, a1, which); }
 #endif
 #if MLP_PART(5)
-FWD_ENTRY(1, 1, 1) { launch_fwd_t<1, 1, true>(st, a); }
-#endif
-#if MLP_PART(6)
-FWD_ENTRY(0, 2, 1) { launch_fwd_t<0, 2, true>(st, a); }
-#endif
-#if MLP_PART(7)
-FWD_ENTRY(1, 2, 1) { launch_fwd_t<1, 2, true>(st, a); }
-#endif
-#if MLP_PART(8)
-BWD_ENTRY(0, 1) { launch_bwd_t<0, 1>(st, a); }
-#endif
-#if MLP_PART(9)
-BWD_ENTRY(1, 1) { launch_bwd_t<1, 1>(st, a); }
-#endif
-#if MLP_PART(10)
-BWD_ENTRY(0, 2) { launch_bwd_t<0, 2>(st, a); }
-#endif
-#if MLP_PART(11)
-BWD_ENTRY(1, 2) { launch_bwd_t<1, 2>(st, a); }
+BWD_ENTRY(2) { launch_bwd_t<2>(st, a0, a1, which); }
 #endif
 
-#if MLP_PART(12)
-void launch_mlp_fwd(hipStream_t st, int net, int P, bool train, const MlpFwdArgs& a) {
-  if (net == 0) {
-    if (P == 1) { if (train) launch_fwd_0_1_1(st, a); else launch_fwd_0_1_0(st, a); }
-    else        { if (train) launch_fwd_0_2_1(st, a); else launch_fwd_0_2_0(st, a); }
-  } else {
-    if (P == 1) { if (train) launch_fwd_1_1_1(st, a); else launch_fwd_1_1_0(st, a); }
-    else        { if (train) launch_fwd_1_2_1(st, a); else launch_fwd_1_2_0(st, a); }
-  }
+#if MLP_PART(6)
+void launch_mlp_fwd_pair(hipStream_t st, int P, bool train, const MlpFwdArgs& a0, const MlpFwdArgs& a1, int which) {
+  if (P == 1) { if (train) launch_fwd_1_1(st, a0, a1, which); else launch_fwd_1_0(st, a0, a1, which); }
+  else        { if (train) launch_fwd_2_1(st, a0, a1, which); else launch_fwd_2_0(st, a0, a1, which); }
 }
-void launch_mlp_bwd(hipStream_t st, int net, int P, const MlpBwdArgs& a) {
-  if (net == 0) { if (P == 1) launch_bwd_0_1(st, a); else launch_bwd_0_2(st, a); }
-  else          { if (P == 1) launch_bwd_1_1(st, a); else launch_bwd_1_2(st, a); }
+void launch_mlp_bwd_pair(hipStream_t st, int P, const MlpBwdArgs& a0, const MlpBwdArgs& a1, int which) {
+  if (P == 1) launch_bwd_1(st, a0, a1, which); else launch_bwd_2(st, a0, a1, which);
 }
 #endif

@@ -13,8 +13,8 @@
 //   NERFPP_LDS_PREFETCH    weight fragments in flight ahead of their MFMA (default 4)
 //   NERFPP_WAVES_P1        waves per workgroup of the bf16 kernels (default 8; 4 = 128-sample tiles)
 //   NERFPP_STAMPS=k        per-block cycle stamps (s_memtime at arrival at / release from every block barrier, per wave) of
-//                          workgroups 0-3 and 400-403 of kernel instantiation k (NERFPP_MLP_PART numbering: 4 = forward fg
-//                          bf16 training, 8 = backward fg bf16), kept in LDS and copied out at the end of the kernel;
+//                          workgroups 0-3 and 400-403 (fg tiles) of kernel instantiation k (NERFPP_MLP_PART numbering: 2 = bf16
+//                          training forward, 4 = bf16 backward), kept in LDS and copied out at the end of the kernel;
 //                          read back with nerfpp_probe_stamps() (tools/probes/stamps_probe.py)
 #pragma once
 #include <hip/hip_runtime.h>
