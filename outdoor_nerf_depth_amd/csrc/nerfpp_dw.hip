@@ -422,14 +422,9 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
   DW_STAMP(FULL, 2, __builtin_readcyclecounter());
 }
 
-// Both kinds in ONE launch: the 252 full-job workgroups first (the long ones, ~2x a narrow one), the 256 narrow ones as CUs
-// free up -- one launch tail per level instead of two, and the narrow jobs fill the idle time at the end of the full round.
-template <int P>
-__global__ __launch_bounds__(512) void dw_pair_kernel(DwArgs a, DwSched sf, DwSched sn, int dbg, uint32_t lds_bytes) {
-  const int nf = sf.wg_end[sf.njobs - 1];
-  if ((int)blockIdx.x < nf) dw_body<P, true>(a, sf, dbg, lds_bytes, (int)blockIdx.x);
-  else dw_body<P, false>(a, sn, dbg, lds_bytes, (int)blockIdx.x - nf);
-}
+// (Round 4 also ran both kinds in ONE launch -- full-job workgroups first, the narrow ones as CUs free up, the way the fg and
+// bg MLP kernels of a level share a launch since then: 2.426 vs 2.411 ms per step in alternating runs on one box, i.e. 0.6 %
+// SLOWER, the weight-gradient group 0.634 vs 0.620 ms; profiles/r04_pair_launch.md.  Two launches it stays.)
 template <int P, bool FULL>
 __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, uint32_t lds_bytes) {
   dw_body<P, FULL>(a, sc, dbg, lds_bytes, (int)blockIdx.x);
@@ -466,13 +461,6 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   dim3 block(512);
   const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;     // 144 KiB
   static const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
-  static const bool split_launches = PROBE_GETENV("NERFPP_DW_SPLIT") != nullptr;      // probes: the two-launch form of rounds 1-3
-  if (!split_launches) {
-    dim3 gpair(gfull.x + gnarrow.x);
-    if (P == 1) hipLaunchKernelGGL((dw_pair_kernel<1>), gpair, block, lds, st, a, sf, sn, dbg, (uint32_t)lds);
-    else hipLaunchKernelGGL((dw_pair_kernel<2>), gpair, block, lds, st, a, sf, sn, dbg, (uint32_t)lds);
-    return;
-  }
   if (P == 1) {
     hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);
     hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg, (uint32_t)lds);

@@ -13,20 +13,18 @@
 //              2 = split-bf16 (x = hi + lo, 3 MFMA passes hi*hi + hi*lo + lo*hi), which holds
 //                  ~1e-5 relative error against the float32 reference ("parity" mode).
 //
-// Weight-pipe modes (WeightPipe<P, NW, MODE>):
-//   PIPE_CLASSIC : double buffer, builtin DMA, every wave drains vmcnt(0) + __syncthreads per block.
-//                  Used by the split-bf16 training kernels.
-//   PIPE_RING    : inference forward (no stores in flight): 4-deep ring, inline-asm DMA, COUNTED
-//                  vmcnt (all outstanding VMEM ops are same-type loads, in order), raw s_barrier.
-//   PIPE_ROLES   : bf16 training kernels.  Activation stores and the weight DMA share vmcnt and may
-//                  retire out of order, so a wave that stores can only wait for its DMA with a full
+// Weight-pipe modes (WeightPipe<P, NW, MODE, NBUF, BF>): blocks of BF fragments x P planes (16 KiB in every training kernel)
+// through an LDS ring, four fragments per DMA set-up (glds16xN_saddr), COUNTED vmcnt waits, one raw s_barrier per block.
+//   PIPE_RING    : inference forward (no stores in flight): every wave fetches its share of a block; all outstanding VMEM
+//                  ops of a wave are same-type loads, in order, so "at most k blocks' worth outstanding" is exact.
+//   PIPE_ROLES   : training kernels (bf16 and, since round 4, split-bf16).  Activation stores and the weight DMA share
+//                  vmcnt and may retire out of order, so a wave that stores can only wait for its DMA with a full
 //                  drain -- which serialises "compute" and "write 16 KB per wave" at every layer.
-//                  Here wave 0 (the LOADER) is the only wave that issues and waits for the DMA, and it
-//                  never stores: it hands its tile to wave 1 through an LDS region, and wave 1 writes
-//                  it out after the next barrier.  The other waves never touch vmcnt, so their stores
-//                  drain under the following MFMA work.  Biases come from LDS and (backward) the ReLU
-//                  sign words are DMA'd into LDS by the loader, so no wave issues a global LOAD in
-//                  steady state either.
+//                  Here wave 0 (the LOADER) is the only wave that issues and waits for the DMA, and it never stores: it
+//                  hands its tile to helper waves through an LDS region, and they write it out after the next barrier.
+//                  The other waves never touch vmcnt, so their stores drain under the following MFMA work.  Biases come
+//                  from LDS and (backward) the ReLU sign words are DMA'd into LDS by the loader, so no wave issues a
+//                  global LOAD in steady state either.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -71,19 +69,8 @@ template <int P> struct Frag { bf16x8 v[P]; };
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-enum { PIPE_CLASSIC = 0, PIPE_RING = 1, PIPE_ROLES = 2 };
+enum { PIPE_RING = 1, PIPE_ROLES = 2 };
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (LDS_AS void*)l, 16, 0, 0);
-}
-// LDS-DMA through inline asm (invisible to hipcc's waitcnt pass; completion is tracked by our own
-// s_waitcnt).  M0 carries the wave-uniform absolute LDS destination.
-__device__ __forceinline__ void glds16_asm(const void* g, uint32_t lds_abs) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_abs);
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-}
 __device__ __forceinline__ uint32_t lds_base_addr() { return (uint32_t)(uintptr_t)(LDS_AS char*)smem; }
 // N (<= 4) consecutive 1 KiB fragments with ONE M0 / address set-up: the instruction offset advances the global and the
 // LDS address alike.  Global address = wave-uniform SGPR base + per-lane byte offset (lane * 16): no 64-bit VALU add, no
@@ -124,7 +111,7 @@ struct WeightPipe {
   static constexpr int BLK_BYTES = BF * P * FRAG_BYTES;
   // DMA wave-instructions per block of the waves that wait for it (roles: the loader issues them all)
   static constexpr int PER_BLK = MODE == PIPE_ROLES ? BF * P : BF * P / NW;
-  static_assert(MODE == PIPE_CLASSIC ? NBUF == 2 : (NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_BLK < 63), "ring depth");
+  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_BLK < 63, "ring depth");
   const char* g;
   uint32_t stamp_off = 0;                                      // (probes: LDS offset of the cycle stamps)
   int nblk, cur, wave, lane;
@@ -143,14 +130,13 @@ struct WeightPipe {
     slot_issue = slot_issue + 1 == NBUF ? 0 : slot_issue + 1;
     if (blk >= nblk) return;
     if constexpr (probe::NO_DMA) return;
-    const char* src = g + (size_t)blk * BLK_BYTES + lane * 16;
     if constexpr (MODE == PIPE_ROLES) {
       if (wave != 0) return;                                   // the loader wave issues the whole block
       static_assert(BF * P % 4 == 0, "groups of four fragments");
 #pragma unroll
       for (int fi = 0; fi < BF * P; fi += 4)
         glds16xN_saddr<4>(g + (size_t)blk * BLK_BYTES + fi * FRAG_BYTES, (uint32_t)lane * 16u, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
-    } else if constexpr (MODE == PIPE_RING) {
+    } else {
       // every wave fetches a contiguous run of the block's fragments, four per M0 / address set-up
       constexpr int C = BF * P / NW;
       static_assert(C == 2 || C % 4 == 0, "per-wave fragment count");
@@ -160,12 +146,6 @@ struct WeightPipe {
       else {
 #pragma unroll
         for (int f = 0; f < C; f += 4) glds16xN_saddr<4>(sb + f * FRAG_BYTES, (uint32_t)lane * 16u, dst + f * FRAG_BYTES);
-      }
-    } else {
-#pragma unroll
-      for (int f = 0; f < BF * P / NW; ++f) {
-        const int fi = f * NW + wave;
-        glds16(src + fi * FRAG_BYTES, smem + slot * BLK_BYTES + fi * FRAG_BYTES);
       }
     }
   }
@@ -184,14 +164,11 @@ struct WeightPipe {
     if constexpr (MODE == PIPE_RING) {
       wait_counted();
       __builtin_amdgcn_s_barrier();
-    } else if constexpr (MODE == PIPE_ROLES) {
+    } else {
       // only the loader has DMA to wait for; everybody: LDS writes of the hand-off region must have landed
       if (wave == 0) wait_counted();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
     }
     probe::stamp(1, cur, wave, lane, stamp_off);                 // released by the barrier
     issue();
@@ -362,20 +339,8 @@ __device__ __forceinline__ void zero_invalid(Frag<P> (&f)[N], bool valid) {
     }
 }
 
-template <int NOB>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NOB], const float* __restrict__ bias, int hi) {
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
-    const float4* p = (const float4*)(bias + ob * 32 + hi * 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = p[q];
-      acc[ob][4 * q] = v.x; acc[ob][4 * q + 1] = v.y; acc[ob][4 * q + 2] = v.z; acc[ob][4 * q + 3] = v.w;
-    }
-  }
-}
-// same, but the bias stream has been copied to LDS (keeps compiler-tracked global loads out of the
-// steady state of the ring / roles pipes)
+// biases initialise the accumulators; the bias stream has been copied to LDS (keeps compiler-tracked global loads out of
+// the steady state of the ring / roles pipes)
 template <int NOB>
 __device__ __forceinline__ void init_bias_lds(f32x16 (&acc)[NOB], uint32_t lds_off_bytes, int hi) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -597,22 +562,21 @@ template <int NET, int P, int NW, bool TRAIN>
 struct FwdLds {
   static constexpr int MODE = !TRAIN ? PIPE_RING : PIPE_ROLES;
   static constexpr bool ROLES = MODE == PIPE_ROLES;
-  static constexpr bool BIAS_LDS = MODE != PIPE_CLASSIC;
   static constexpr int BF = blk_frags_of<P, TRAIN>();
   // ring depth: as deep as the 160 KiB of LDS allow
-  static constexpr int NBUF = MODE == PIPE_CLASSIC ? 2 : MODE == PIPE_RING ? (P == 1 ? 4 : 3) : 4;
+  static constexpr int NBUF = MODE == PIPE_RING ? (P == 1 ? 4 : 3) : 4;
   static constexpr int W = NBUF * BF * P * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STASH = REGION + (ROLES ? region_bytes(P) : 0);
   static constexpr int BIAS = STASH + NW * kpe(NET) * P * 1024;
-  static constexpr int TOTAL = BIAS + (BIAS_LDS ? FWD_BIAS_FLOATS * 4 : 0);
+  static constexpr int TOTAL = BIAS + FWD_BIAS_FLOATS * 4;
 };
 template <int P, int NW>
 struct BwdLds {
   static constexpr int MODE = PIPE_ROLES;
-  static constexpr bool ROLES = MODE == PIPE_ROLES;
+  static constexpr bool ROLES = true;
   static constexpr int BF = blk_frags_of<P, true>();
-  static constexpr int NBUF = ROLES ? 4 : 2;
+  static constexpr int NBUF = 4;
   static constexpr int W = NBUF * BF * P * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int MASKS = REGION + (ROLES ? region_bytes(P) : 0);       // 2 x NW KiB of sign words (ROLES)
@@ -651,21 +615,13 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
   // (two planes per chunk, one wave per SIMD): one chunk per block from block 2 on.
   constexpr int H = NW >= 5 ? 4 : NW - 1, Q = (16 + H - 1) / H, CPB = LD::BF / 8;
   constexpr int RMASK = region_mask(P);
-  if constexpr (LD::BIAS_LDS) {
-    for (int i = threadIdx.x; i < FWD_BIAS_FLOATS / 4; i += NW * 64)
-      *(float4*)(smem + LD::BIAS + i * 16) = ((const float4*)a.bias)[i];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  auto bias_init8 = [&](f32x16 (&acc_)[8], int off) {
-    if constexpr (!LD::BIAS_LDS) init_bias<8>(acc_, a.bias + off, hi); else init_bias_lds<8>(acc_, LD::BIAS + off * 4, hi);
-  };
-  auto bias_init4 = [&](f32x16 (&acc_)[4], int off) {
-    if constexpr (!LD::BIAS_LDS) init_bias<4>(acc_, a.bias + off, hi); else init_bias_lds<4>(acc_, LD::BIAS + off * 4, hi);
-  };
-  auto bias_init1 = [&](f32x16 (&acc_)[1], int off) {
-    if constexpr (!LD::BIAS_LDS) init_bias<1>(acc_, a.bias + off, hi); else init_bias_lds<1>(acc_, LD::BIAS + off * 4, hi);
-  };
+  for (int i = threadIdx.x; i < FWD_BIAS_FLOATS / 4; i += NW * 64)
+    *(float4*)(smem + LD::BIAS + i * 16) = ((const float4*)a.bias)[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  auto bias_init8 = [&](f32x16 (&acc_)[8], int off) { init_bias_lds<8>(acc_, LD::BIAS + off * 4, hi); };
+  auto bias_init4 = [&](f32x16 (&acc_)[4], int off) { init_bias_lds<4>(acc_, LD::BIAS + off * 4, hi); };
+  auto bias_init1 = [&](f32x16 (&acc_)[1], int off) { init_bias_lds<1>(acc_, LD::BIAS + off * 4, hi); };
   const size_t tile_row0 = wrow0 - (size_t)wave * 32;                       // = the loader's rows
   // after the first barrier of a stage: helper waves 1..4 write out what the loader handed over at the end of the
   // previous stage (chunk c by wave 1 + c % 4; statically known per stage; mask_stage < 0: no sign words)

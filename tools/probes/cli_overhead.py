@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Where the drop-in loop's overhead over the kernel-only step comes from (bench.py `cli_loop`): the same trainer driven
+(a) with pre-staged device batches (= bench.py's headline loop), (b) with DeviceRaySamplers.random_sample on the training
+stream, (c) with DeviceRaySamplers.prefetch (side stream), (d) like (c) plus the log line's synchronising scalar read every
+100 steps.  ms per step over `--steps` steps after 50 warm-up steps; three alternating repetitions."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from outdoor_nerf_depth_amd import _lib as L                                   # noqa: E402
+from outdoor_nerf_depth_amd.data_loader_split import synthetic_ray_samplers    # noqa: E402
+from outdoor_nerf_depth_amd.device_sampler import DeviceRaySamplers            # noqa: E402
+from outdoor_nerf_depth_amd.trainer import NerfppTrainer                       # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--steps', type=int, default=400)
+    a = p.parse_args()
+    dev = torch.device('cuda:0')
+    samplers = synthetic_ray_samplers('train', 1, 'gt', 30, 375, 1242)
+    ds = DeviceRaySamplers(samplers, dev, seed=777)
+    tr = NerfppTrainer(dev, precision=L.PREC_BF16, use_depth=True, depth_loss_type='mse', lambda_depth=0.1,
+                       depth_scale=float(samplers[0].get_depth_scale()), seed=777)
+    staged = [ds.random_sample(1024) for _ in range(64)]
+
+    def run(mode):
+        for i in range(50):
+            tr.train_step(staged[i % 64])
+        tr.flush()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            if mode == 'staged':
+                b = staged[i % 64]
+            elif mode == 'random_sample':
+                b = ds.random_sample(1024)
+            else:
+                b = ds.prefetch(1024)
+            sc = tr.train_step(b)
+            if mode == 'prefetch_log' and (i + 1) % 100 == 0:
+                tr.check_cameras()
+                _ = [s.cpu().numpy() for s in sc]
+        tr.flush()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / a.steps
+    res = {m: [] for m in ('staged', 'random_sample', 'prefetch', 'prefetch_log')}
+    for rep in range(3):
+        for m in res:
+            res[m].append(run(m))
+    out = {m: {'ms_per_step': [round(x, 4) for x in v], 'median': float(np.median(v))} for m, v in res.items()}
+    base = out['staged']['median']
+    for m in out:
+        out[m]['overhead_pct'] = 100.0 * (out[m]['median'] / base - 1.0)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
