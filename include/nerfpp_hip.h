@@ -33,6 +33,8 @@ extern "C" {
 #define NERFPP_ERR_HIP 2          /* a HIP runtime call / kernel launch failed */
 #define NERFPP_ERR_INTERNAL 3
 #define NERFPP_ERR_UNSUPPORTED 4
+#define NERFPP_ERR_COMM 5         /* RCCL missing or an RCCL call failed: nerfpp_comm_last_error() */
+#define NERFPP_ERR_LAUNCH NERFPP_ERR_HIP
 
 /* precision of the MLP kernels */
 #define NERFPP_PREC_BF16 1        /* single-pass bf16 MFMA, f32 accumulate ("speed") */
@@ -264,6 +266,19 @@ int nerfpp_level_reduce_grads(void* stream, const nerfpp_backward_args* args);
 int nerfpp_adam_step(void* stream, float* params, const float* grads, float* exp_avg,
                      float* exp_avg_sq, int64_t n, int step, double lr, double beta1, double beta2,
                      double eps, const float* skip_if_nonzero);
+
+/* ---------------------------------------------------------------- data-parallel gradient averaging (RCCL over xGMI)
+ * DistributedDataParallel's gradient average of ddp_train_nerf.py:323 (process group :298) behind the C ABI, for hosts that do
+ * not go through torch.distributed.  RCCL is bound with dlopen("librccl.so.1") at the first call (NERFPP_ERR_COMM when it
+ * cannot be loaded; there is no host-side fallback).  One process per GPU: rank 0 creates the 128-byte id, every rank gets it
+ * over a channel of the host's choosing and builds its communicator; `comm` is an opaque ncclComm_t.
+ * nerfpp_allreduce_mean: grads[count] (device float32, in place) <- mean over the ranks, on `stream`.  prescaled != 0: the
+ * gradients already carry 1 / world_size (nerfpp_backward_args.grad_scale), only the SUM all-reduce is issued. */
+const char* nerfpp_comm_last_error(void);
+int nerfpp_rccl_unique_id(char out_id[128]);
+int nerfpp_rccl_comm_init(void** comm, int world_size, const char id[128], int rank);
+int nerfpp_rccl_comm_destroy(void* comm);
+int nerfpp_allreduce_mean(void* stream, void* rccl_comm, float* grads, int64_t count, int world_size, int prescaled);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,11 @@ SYMBOLS = {
     'nerfpp_level_reduce_grads': (C.c_int, [_fp, C.POINTER(BackwardArgs)]),
     'nerfpp_adam_step': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_double, C.c_double,
                                    C.c_double, C.c_double, _fp]),
+    'nerfpp_comm_last_error': (C.c_char_p, []),
+    'nerfpp_rccl_unique_id': (C.c_int, [C.c_char_p]),
+    'nerfpp_rccl_comm_init': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_int]),
+    'nerfpp_rccl_comm_destroy': (C.c_int, [_fp]),
+    'nerfpp_allreduce_mean': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int]),
 }
 
 _lib = None

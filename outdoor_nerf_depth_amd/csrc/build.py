@@ -22,6 +22,7 @@ SOURCES = {
     'nerfpp_dw.hip': [],
     'nerfpp_optim.hip': ['-ffp-contract=off'],      # Adam rounds like torch
     'nerfpp_api.hip': [],
+    'nerfpp_comm.hip': [],                         # RCCL entry points (librccl.so.1 bound with dlopen at first use)
 }
 HEADERS = ['nerfpp_common.h', 'nerfpp_kernels.h', 'probe_env.h', 'nerfpp_mlp_probes.h', os.path.join('..', '..', 'include', 'nerfpp_hip.h')]
 # SURVEY 8 f-4 (MipNeRF-360 path): its own shared object and C ABI (include/mip360_hip.h)

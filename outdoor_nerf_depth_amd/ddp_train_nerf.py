@@ -139,6 +139,9 @@ def config_parser():
                         'float32 reference -- with the single-pass bf16 backward (200-step training trajectory within 0.01 dB of the '
                         "reference's PSNR, tests/test_gpu_round4.py); split: split-bf16 everywhere (gradients at float32 grade too, "
                         '1.6x slower); bf16: single-pass bf16 MFMA everywhere (fastest; outputs at bf16 grade)')
+    p.add_argument('--grad_comm', choices=['torch', 'rccl_abi'], default='torch',
+                   help="gradient all-reduce: torch.distributed (backend nccl = RCCL), or the library's own RCCL entry point "
+                        '(nerfpp_allreduce_mean; the communicator id travels over the torch process group)')
     p.add_argument('--synthetic', action='store_true', help='KITTI-shaped procedural scene, no datadir')
     p.add_argument('--synthetic_hw', type=str, default=None, help="'H,W' of the synthetic frames (default 375,1242)")
     p.add_argument('--synthetic_frames', type=int, default=295)
@@ -353,12 +356,16 @@ def ddp_train_nerf(rank, args):
             logger.info('frames of different sizes: falling back to host-side ray sampling')
 
     cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
+    comm = None
+    if args.grad_comm == 'rccl_abi':
+        from .dist_utils import RcclComm
+        comm = RcclComm(rank, world)
     trainer = NerfppTrainer(device, precision={'bf16': L.PREC_BF16, 'split': L.PREC_SPLIT_BF16, 'split_fwd': L.PREC_SPLIT_FWD}[args.precision],
                             cascade_samples=cascade, lrate=args.lrate, use_depth=args.use_depth,
                             depth_loss_type=args.depth_loss_type, lambda_depth=args.lambda_depth,
                             depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world,
                             optim_autoexpo=args.optim_autoexpo, img_names=img_names,
-                            lambda_autoexpo=args.lambda_autoexpo, seed=(rank + 1) * 777)   # :406-408
+                            lambda_autoexpo=args.lambda_autoexpo, seed=(rank + 1) * 777, comm=comm)   # :406-408
     ckpt, start = find_latest_checkpoint(args)
     if ckpt is not None:
         logger.info('Reloading from: {}'.format(ckpt))
@@ -379,7 +386,8 @@ def ddp_train_nerf(rank, args):
             t_log, n_log = time.time(), 0
         n_log += 1
         if device_samplers is not None:
-            ray_batch = device_samplers.prefetch(args.N_rand)      # the next step's batch is drawn beside this step's kernels
+            ray_batch = device_samplers.random_sample(args.N_rand)   # two small kernels on the training stream: +0.8 % of a step
+            # (drawing the next batch on a side stream instead measured +1.0 %: profiles/r04_cli_loop.md)
         else:
             i = np.random.randint(low=0, high=len(ray_samplers))
             ray_batch = batch_to_device(ray_samplers[i].random_sample(args.N_rand, center_crop=False), device)

@@ -102,29 +102,3 @@ class DeviceRaySamplers(object):
         out = self.gather(frame, pix, full_keys)
         out['frame'] = frame
         return out
-
-    def prefetch(self, N_rand):
-        """Draw the NEXT batch on the sampler's own stream and return the batch drawn by the previous call (the first call
-        draws two): the two small sampling kernels then run beside the previous step's MLP launches instead of between two
-        steps on the training stream (bench.py `cli_loop`).  The training stream is ordered after the
-        batch it receives; the tensors are handed over with record_stream."""
-        if getattr(self, '_stream', None) is None:
-            self._stream = torch.cuda.Stream(device=self.device)
-            self._next = None
-        main = torch.cuda.current_stream(self.device)
-
-        def draw():
-            with torch.cuda.stream(self._stream):
-                b = self.random_sample(N_rand)
-                ev = torch.cuda.Event()
-                ev.record()
-            return b, ev
-        if self._next is None:
-            self._next = draw()
-        batch, ev = self._next
-        main.wait_event(ev)
-        for v in batch.values():
-            if torch.is_tensor(v):
-                v.record_stream(main)
-        self._next = draw()
-        return batch

@@ -49,3 +49,55 @@ def gather_ragged(t, sizes, rank, world_size):
     if rank != 0:
         return None
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+
+
+
+class RcclComm(object):
+    """An RCCL communicator driven through the C ABI (include/nerfpp_hip.h: nerfpp_rccl_* / nerfpp_allreduce_mean) instead of
+    torch.distributed: what a host without torch would bind.  One process per GPU; `exchange(id_bytes_or_None) -> id_bytes`
+    moves rank 0's 128-byte unique id to every rank (default: torch.distributed.broadcast_object_list over whatever process
+    group is initialised, e.g. gloo)."""
+
+    def __init__(self, rank, world_size, exchange=None):
+        import ctypes as C
+        from . import _lib as L
+        self.rank, self.world_size = int(rank), int(world_size)
+        lib = L.lib()
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            self._check(lib.nerfpp_rccl_unique_id(buf), 'nerfpp_rccl_unique_id')
+        uid = buf.raw if self.rank == 0 else None
+        if self.world_size > 1:
+            if exchange is None:
+                import torch.distributed as dist
+
+                def exchange(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            uid = exchange(uid)
+        self._comm = C.c_void_p()
+        self._check(lib.nerfpp_rccl_comm_init(C.byref(self._comm), self.world_size, uid, self.rank), 'nerfpp_rccl_comm_init')
+
+    @staticmethod
+    def _check(rc, what):
+        from . import _lib as L
+        if rc != L.OK:
+            raise L.NerfppError('%s failed (code %d): %s' % (what, rc, L.lib().nerfpp_comm_last_error().decode('utf-8', 'replace')))
+
+    def allreduce_mean(self, grads, prescaled=True):
+        """grads (device float32, contiguous) <- mean over the ranks, in place, on torch's current stream."""
+        import ctypes as C
+        import torch
+        from . import _lib as L
+        assert grads.is_cuda and grads.dtype == torch.float32 and grads.is_contiguous()
+        self._check(L.lib().nerfpp_allreduce_mean(C.c_void_p(torch.cuda.current_stream().cuda_stream), self._comm,
+                                                   C.c_void_p(grads.data_ptr()), grads.numel(), self.world_size, int(bool(prescaled))),
+                    'nerfpp_allreduce_mean')
+        return grads
+
+    def destroy(self):
+        from . import _lib as L
+        if getattr(self, '_comm', None) is not None and self._comm.value:
+            self._check(L.lib().nerfpp_rccl_comm_destroy(self._comm), 'nerfpp_rccl_comm_destroy')
+            self._comm = None

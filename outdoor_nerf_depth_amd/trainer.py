@@ -24,11 +24,13 @@ class NerfppTrainer(object):
     def __init__(self, device, precision=L.PREC_SPLIT_BF16, cascade_samples=(64, 128), lrate=5e-4,
                  use_depth=True, depth_loss_type='mse', lambda_depth=0.1, depth_sigma=0.01, depth_scale=1.0,
                  world_size=1, level_params=None, overlap_allreduce=True, optim_autoexpo=False, img_names=None,
-                 lambda_autoexpo=1.0, seed=777, torch_rng=False, fuse_loss=False):
+                 lambda_autoexpo=1.0, seed=777, torch_rng=False, fuse_loss=False, comm=None):
         """seed: key of the in-kernel sampling RNG (the CLI passes (rank+1)*777 like ddp_train_nerf.py:406-408);
         torch_rng=True draws the four uniform tensors with torch.rand in the reference's call order instead
-        (4 extra launches per step)."""
+        (4 extra launches per step).  comm: optional dist_utils.RcclComm -- the gradient average then goes through the
+        library's own RCCL entry point (nerfpp_allreduce_mean) instead of torch.distributed.all_reduce."""
         self.device = torch.device(device)
+        self.comm = comm
         self.precision = precision
         self.cascade_samples = tuple(cascade_samples)
         self.lrate = lrate
@@ -92,7 +94,7 @@ class NerfppTrainer(object):
         eng.reduce_grads()
         flag = self.grads[m][L.LEVEL_PARAMS:L.LEVEL_PARAMS + 1]
         flag.copy_(self.bad_cameras)                      # int32 count -> float, cumulative since the last check_cameras()
-        if self.world_size > 1:
+        if self.world_size > 1 or self.comm is not None:
             import torch.distributed as dist
             if self.autoexpo is not None:
                 # [n_img, 3]: grads | used flag; a few hundred bytes.  EVERY rank issues this collective every
@@ -100,8 +102,14 @@ class NerfppTrainer(object):
                 # rgb loss) contributes zeros, otherwise the ranks' collective sequences would diverge
                 if self._ae_grad[m] is None:
                     self._ae_grad[m] = torch.zeros(len(self.autoexpo[m].names), 3, device=self.device)
-                dist.all_reduce(self._ae_grad[m])
-            dist.all_reduce(self.grads[m])
+                if self.comm is not None:
+                    self.comm.allreduce_mean(self._ae_grad[m].view(-1), prescaled=True)
+                else:
+                    dist.all_reduce(self._ae_grad[m])
+            if self.comm is not None:
+                self.comm.allreduce_mean(self.grads[m], prescaled=True)      # grads carry 1 / world_size already (grad_scale)
+            else:
+                dist.all_reduce(self.grads[m])
         ops.adam_step(eng.params, self.grads[m][:L.LEVEL_PARAMS], self.exp_avg[m], self.exp_avg_sq[m], step, lr=self.lrate,
                       skip=flag)
         eng.repack()

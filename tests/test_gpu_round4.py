@@ -202,3 +202,60 @@ def test_sample_pixels_is_uniform_and_rejects_bad_sizes():
         ops.sample_pixels(10, 11, 1, 1, d)
     with pytest.raises(L.NerfppError):
         ops.sample_pixels(1 << 20, 8193, 1, 1, d)
+
+
+# ------------------------------------------------------------------------------------------- RCCL behind the C ABI
+def test_rccl_entry_points_single_rank():
+    """nerfpp_rccl_* / nerfpp_allreduce_mean (ddp_train_nerf.py:323): a one-rank communicator built through the
+    C ABI, the all-reduce on a side stream, mean semantics for both `prescaled` forms, and a training run whose gradient
+    average goes through it -- bit-identical to the run without a communicator (the mean over one rank is the identity)."""
+    from outdoor_nerf_depth_amd.dist_utils import RcclComm
+    from outdoor_nerf_depth_amd.trainer import NerfppTrainer
+    d = dev()
+    comm = RcclComm(0, 1)
+    g = torch.arange(1202444, device=d, dtype=torch.float32) * 1e-3
+    ref = g.clone()
+    side = torch.cuda.Stream(device=d)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.allreduce_mean(g, prescaled=True)
+        comm.allreduce_mean(g, prescaled=False)
+    side.synchronize()
+    assert torch.equal(g, ref)
+    outs = []
+    for c in (None, comm):
+        tr = NerfppTrainer(d, precision=1, use_depth=True, depth_loss_type='mse', lambda_depth=0.1, comm=c)
+        for b in _batches(0, 64, 3):
+            tr.train_step({k: T(v, d) for k, v in b.items() if isinstance(v, np.ndarray)})
+        tr.flush()
+        torch.cuda.synchronize()
+        outs.append(np.stack([e.params.cpu().numpy() for e in tr.engines]))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    comm.destroy()
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from outdoor_nerf_depth_amd.dist_utils import RcclComm
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(rank)
+    comm = RcclComm(rank, world)
+    g = torch.full((1202444,), float(rank + 1), device='cuda')
+    comm.allreduce_mean(g, prescaled=False)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, 'g%d.npy' % rank), g[:8].cpu().numpy())
+    comm.destroy()
+    dist.destroy_process_group()
+
+
+def test_rccl_entry_points_two_ranks(tmp_path):
+    """two ranks on two GPUs over xGMI: mean of (1, 2) = 1.5 on both (skipped on a 1-GPU box: RCCL refuses two ranks on one device)"""
+    dev()
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        np.testing.assert_array_equal(np.load(tmp_path / ('g%d.npy' % r)), np.full(8, 1.5, np.float32))

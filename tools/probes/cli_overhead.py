@@ -42,7 +42,7 @@ def main():
             elif mode == 'random_sample':
                 b = ds.random_sample(1024)
             else:
-                b = ds.prefetch(1024)
+                b = ds.prefetch(1024)       # (round-4 experiment, removed from device_sampler.py: see profiles/r04_cli_loop.md)
             sc = tr.train_step(b)
             if mode == 'prefetch_log' and (i + 1) % 100 == 0:
                 tr.check_cameras()

@@ -17,7 +17,7 @@ for k in 0 1 2 3 4 5 6; do
   objs="$objs $V/${name}_$k.o"
 done
 wait
-for s in nerfpp_tables nerfpp_render nerfpp_dw nerfpp_optim nerfpp_api; do objs="$objs $C/build/$s.o"; done
+for s in nerfpp_tables nerfpp_render nerfpp_dw nerfpp_optim nerfpp_api nerfpp_comm; do objs="$objs $C/build/$s.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/$name.so $objs
 rm -f $V/${name}_*.o
 echo $V/$name.so
