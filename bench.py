@@ -57,8 +57,8 @@ SETUP_STEPS = 12                 # untimed steps run when a trainer is set up, b
 # HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16: PARSED at start-up from the rocprofv3 --pmc passes committed
 # under profiles/ (they cannot be collected inside this process: separate --pmc runs, MI355X_MICROARCH.md "HBM").  The
 # field is named `traffic_from_profile`-style in the output (`traffic_source`), it is not a live measurement.
-PMC_PROFILE = os.path.join('profiles', 'r03_final_kernel_stats_timeline_hbm.md')
-PMC_PROFILE_FALLBACK = os.path.join('profiles', 'r02_h_kernel_stats_timeline_hbm.md')
+PMC_PROFILE = os.path.join('profiles', 'r04_final_kernel_stats_timeline_hbm.md')
+PMC_PROFILE_FALLBACK = os.path.join('profiles', 'r03_final_kernel_stats_timeline_hbm.md')
 PMC_GROUPS = {            # launch group -> kernel-name prefix of its bf16 training instantiations (both nets / both launches)
     'dw_L1': 'dw_kernel<1,',
     'mlp_fwd_L1': 'mlp_fwd_kernel<',
@@ -90,8 +90,12 @@ def load_pmc_traffic():
         for grp, prefix in PMC_GROUPS.items():
             if grp == 'dw_L1':                    # dw_kernel<1, true> (256 x 256 jobs) + dw_kernel<1, false> (narrow jobs)
                 ks = [k for k in per if k.startswith(prefix)]
-            else:                                 # <net, P = 1, 8 waves[, TRAIN = true]>: the bf16 training instantiations
-                ks = [k for k in per if k.startswith(prefix) and ', 1, 8' in k and not k.endswith('false>')]
+            else:
+                # round 4: mlp_fwd_pair_kernel<P = 1, 8 waves, TRAIN = true> / mlp_bwd_pair_kernel<1, 8> (both nets in one launch)
+                pair = prefix.replace('_kernel<', '_pair_kernel<')
+                ks = [k for k in per if k.startswith(pair + '1, 8') and not k.endswith('false>')]
+                if not ks:                        # rounds 1-3: <net, P = 1, 8 waves[, TRAIN = true]>, one launch per net
+                    ks = [k for k in per if k.startswith(prefix) and ', 1, 8' in k and not k.endswith('false>')]
             ks = [k for k in ks if 'FETCH_SIZE' in per[k] and 'WRITE_SIZE' in per[k]]
             if not ks:
                 return None
