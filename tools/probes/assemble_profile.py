@@ -19,7 +19,7 @@ def main(d, tag):
         f.write('# %s -- NeRF++ training step (bench.py, N_rand = 1024, 64 + 128 samples), one MI355X\n\n' % tag)
         f.write('Collected by `tools/probes/profile_round.sh %s` (rocprofv3 --kernel-trace --stats; bf16, split-bf16 and split_fwd in '
                 'one process).\n\n' % tag)
-        f.write("Level 0's backward and weight-gradient dispatches run on their own stream under level 1's sampling and forward (`NerfppTrainer.concurrent_backward`): their durations and those of level 1's `mlp_fwd_kernel` below are wall time while sharing the GPU (negative gaps in the timeline).  Level 1's `mlp_bwd_kernel` / `dw_kernel` dispatches are never overlapped; the average rows mix level-0 (1024 x 64 samples) and level-1 (1024 x 192) launches -- the timeline separates them." + '\n\n')
+        f.write("Level 0's backward and weight-gradient dispatches run on their own stream under level 1's sampling and forward (`NerfppTrainer.concurrent_backward`): their durations and those of level 1's `mlp_fwd_pair_kernel` below are wall time while sharing the GPU (negative gaps in the timeline).  Level 1's `mlp_bwd_pair_kernel` / `dw_kernel` dispatches are never overlapped; a `*_pair_kernel` dispatch covers the fg and the bg net of a level; the average rows mix level-0 (1024 x 64 samples) and level-1 (1024 x 192) launches -- the timeline separates them." + '\n\n')
         f.write(rd(d, 'kernel_stats.md'))
         f.write('\n## One bf16 training step, dispatch by dispatch (tools/rocpd_timeline.py)\n\n')
         f.write(rd(d, 'timeline_bf16.md'))

@@ -6,8 +6,8 @@
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${1:-rXX}; FULL=$2; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-B="--no_cpu_baseline --large_batch 0 --mip360_rays 0 --render_frames 0"
-if [ -n "$FULL" ]; then timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err; fi
+B="--no_cpu_baseline --large_batch 0 --mip360_rays 0 --render_frames 0 --cli_steps 0"
+if [ -n "$FULL" ]; then timeout 1200 python $R/bench.py --cli_steps 1100 > $O/bench.json 2> $O/bench.err; fi
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 10 --warmup 2 $B > $O/trace.log 2>&1
 python $R/tools/rocpd_stats.py $(ls $O/trace/*/*.db | head -1) > $O/kernel_stats.md
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace1 -- python $R/bench.py --steps 6 --warmup 2 $B --precision bf16 > $O/trace1.log 2>&1
