@@ -44,6 +44,7 @@ constexpr bool NO_DMA = false, NO_MFMA = false;
 constexpr int LDS_PREFETCH = 4;        // weight fragments in flight ahead of the MFMA that consumes them
 constexpr int HOOK_ORDER = 1;          // saves issued after a block's MFMAs by every wave
 constexpr int WAVES_P1 = 8;            // waves per workgroup of the bf16 kernels (256-sample tiles)
+constexpr int LOADER_SLEEP = 0;        // (probes: idle cycles / 64 added to the loader wave per weight block)
 __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   const u32x4_ vv = {v.x, v.y, v.z, v.w};
@@ -133,6 +134,7 @@ struct WeightPipe {
     if constexpr (MODE == PIPE_ROLES) {
       if (wave != 0) return;                                   // the loader wave issues the whole block
       static_assert(BF * P % 4 == 0, "groups of four fragments");
+      if constexpr (probe::LOADER_SLEEP > 0) __builtin_amdgcn_s_sleep(probe::LOADER_SLEEP);
 #pragma unroll
       for (int fi = 0; fi < BF * P; fi += 4)
         glds16xN_saddr<4>(g + (size_t)blk * BLK_BYTES + fi * FRAG_BYTES, (uint32_t)lane * 16u, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);

@@ -464,6 +464,9 @@ def ddp_train_nerf(rank, args):
 
     trainer.flush()                               # the last step's level-1 update is applied lazily under DP
     trainer.check_cameras()
+    on_finish = getattr(args, 'on_finish', None)  # (bench.py: times the kernel-only step on the SAME trained state)
+    if on_finish is not None:
+        on_finish(trainer, device_samplers if device_samplers is not None else ray_samplers)
     if world > 1:
         dist.destroy_process_group()
 

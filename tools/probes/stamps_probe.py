@@ -40,6 +40,18 @@ def main():
         if a.what == 'bwd':
             eng.backward(torch.rand_like(ret['rgb']) * 1e-3, torch.rand_like(ret['depth']) * 1e-3, None)
     torch.cuda.synchronize()
+    # wall time of the same launches, in this process: HIP events the library records around the MLP kernels
+    ms = []
+    for _ in range(20):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for e in ev:
+            e.record()
+        ret = eng.forward(ray_o, ray_d, far, fg_z, bg_z, training=True, events=(ev[0], ev[1]))
+        if a.what == 'bwd':
+            eng.backward(torch.rand_like(ret['rgb']) * 1e-3, torch.rand_like(ret['depth']) * 1e-3, None, events=ev)
+        torch.cuda.synchronize()
+        ms.append(ev[0].elapsed_time(ev[1]))
+    launch_ms = float(np.median(ms))
     lib = L.lib()
     buf = np.zeros((8, 8, 96, 2), np.uint32)
     fn = lib.nerfpp_probe_stamps
@@ -48,23 +60,30 @@ def main():
     assert rc == 0, 'nerfpp_probe_stamps rc=%d (is this the stamps build?)' % rc
     np.save(a.out + '.npy', buf)
     arr, rel = buf[..., 0].astype(np.int64), buf[..., 1].astype(np.int64)
-    nblk = int((rel[0, 0] != 0).sum())
-    rep = {'what': a.what, 'blocks': nblk, 'workgroups': []}
+    nblk = 75 if a.what == 'fwd' else 70                      # weight blocks per tile (fg net): fwd_frags(0) / 16, BWD_FRAGS / 16
+    rep = {'what': a.what, 'blocks': nblk, 'launch_ms_both_nets': launch_ms, 'workgroups': []}
+    print('launch (fg + bg in one launch): %.4f ms' % launch_ms)
     for wg in range(8):
-        r = rel[wg, :, :nblk]
-        ar = arr[wg, :, :nblk]
-        if r[0, 0] == 0:
+        if rel[wg, 0, 0] == 0:
             continue
+        t0 = rel[wg, 0, 0]
+        r = (rel[wg, :, :nblk] - t0) % (1 << 32)                              # 32-bit stamps: differences modulo 2^32
+        ar = (arr[wg, :, :nblk] - t0 + (1 << 31)) % (1 << 32) - (1 << 31)
         per_blk = np.diff(r[0])                                   # release to release (all waves release together)
         last = ar.argmax(0)                                       # wave that arrived last at each block boundary
-        wait = (r - ar)                                           # cycles each wave waited at the boundary
+        wait = r - ar                                             # cycles each wave waited at the boundary
         rep['workgroups'].append({
             'wg_slot': wg, 'total_cycles': int(r[0, -1] - ar[:, 0].min()),
             'cycles_per_block_mean': float(per_blk.mean()), 'cycles_per_block_p10_p50_p90': [float(x) for x in np.percentile(per_blk, [10, 50, 90])],
             'last_arriver_histogram': np.bincount(last, minlength=8).tolist(),
             'mean_wait_per_wave': [float(x) for x in wait.mean(1)],
-            'release_skew_max': int((r.max(0) - r.min(0)).max()),
             'per_block_cycles': per_blk.tolist(), 'last_arriver': last.tolist()})
+    if rep['workgroups']:
+        tot = float(np.mean([w['total_cycles'] for w in rep['workgroups']]))
+        rep['tile_cycles_mean'] = tot
+        # 768 fg tiles + 768 bg tiles over 256 CUs = 6 rounds of one tile per CU (the bg tile is ~2 % longer)
+        rep['implied_clock_ghz'] = 6.0 * tot / (launch_ms * 1e-3) / 1e9
+        print('tile: %.0f cycles (mean of %d stamped workgroups); 6 rounds / launch time -> %.2f GHz' % (tot, len(rep['workgroups']), rep['implied_clock_ghz']))
     with open(a.out + '.json', 'w') as f:
         json.dump(rep, f)
     for w in rep['workgroups']:
