@@ -292,10 +292,11 @@ __host__ __device__ constexpr int slab_job_index(const SlabMap& m, int net, int 
 // every workgroup of a launch finishes at about the same time and each launch fills the 256 CUs once.
 // (Until round 4 the narrow weights were the jobs' bytes per row; per-workgroup timestamps -- profiles/r04_dw_stamps.md --
 // showed the [dS | dG]^T H7 job, 40 output blocks dealt round-robin, at 6.9 cycles per column-chunk against 5.0-5.5 for the
-// others: its 38 slices finished 30 % after everybody else.)
+// others: its 38 slices finished 30 % after everybody else.  The per-shape loops of nerfpp_dw.hip: narrow_job brought that job
+// to 4.9 and the table below is their measurement.)
 struct DwPlan { int k[N_NET][DW_JOBS]; };
-constexpr int dw_narrow_cost(const DwJob& j) {        // shader cycles per 32-row chunk, bf16 (dw_kernel<1, false>)
-  return j.n_o == DSG_LD ? 2860 : j.n_o == 256 ? (j.n_i == 64 ? 1666 : 1749) : j.n_o == 128 ? 873 : 984;
+constexpr int dw_narrow_cost(const DwJob& j) {        // shader cycles per 32-row tile, bf16 (dw_kernel<1, false>, per-shape loops)
+  return j.n_o == DSG_LD ? 2050 : j.n_o == 256 ? (j.n_i == 64 ? 1545 : 1697) : j.n_o == 128 ? 786 : 790;
 }
 inline DwPlan dw_plan(int64_t rows) {
   const JobTable jt = build_all_jobs();

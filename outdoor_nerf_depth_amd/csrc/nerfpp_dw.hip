@@ -52,19 +52,19 @@ constexpr JobTable build_jobs(bool full) {
   }
   return jt;
 }
-// The narrow kernel deals a chunk's 1 KiB blocks (DMA wave-instructions) round-robin to its 8 waves and instantiates its
-// main loop per count c_w = ceil((n_total - wave) / 8) in 1 .. CMAX: every wave must own at least one block (c_w == 0 would
-// fall into the largest instantiation and issue DMAs past the operand) and at most CMAX = 4 P.
-constexpr bool narrow_jobs_fit_the_dma_deal() {
+// The narrow kernel is instantiated per job SHAPE (n_o x n_i); every narrow job of the table must have one.
+constexpr bool narrow_shape_known(int n_o, int n_i) {
+  return (n_o == 256 && (n_i == 64 || n_i == 96)) || (n_o == DSG_LD && n_i == 256) || (n_o == 128 && n_i == 32) ||
+         (n_o == 32 && n_i == 128);
+}
+constexpr bool narrow_jobs_have_shapes() {
   const JobTable jt = build_jobs(false);
   for (int net = 0; net < N_NET; ++net)
-    for (int k = 0; k < jt.count[net]; ++k) {
-      const int blocks = (jt.jobs[net][k].n_o + jt.jobs[net][k].n_i) / 16;      // per plane; P planes scale both bounds
-      if (blocks < 8 || blocks > 32) return false;
-    }
+    for (int k = 0; k < jt.count[net]; ++k)
+      if (!narrow_shape_known(jt.jobs[net][k].n_o, jt.jobs[net][k].n_i)) return false;
   return true;
 }
-static_assert(narrow_jobs_fit_the_dma_deal(), "narrow dW job: 8 <= (n_o + n_i) / 16 <= 32 blocks per plane");
+static_assert(narrow_jobs_have_shapes(), "narrow dW job without a NarrowShape instantiation (dw_body)");
 __constant__ JobTable c_full = build_jobs(true);
 __constant__ JobTable c_narrow = build_jobs(false);
 
@@ -92,25 +92,29 @@ __device__ __forceinline__ bf16x8 tr_frag(lds_addr off, uint32_t row2 = 128) {
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + row2));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-// Narrow jobs: an operand image is its n/16 chunk blocks per plane; smaller chunks leave room for a deeper ring.
-struct NarrowGeom {
-  uint32_t nblk[2];     // 1 KiB blocks (= DMA wave-instructions) per plane of A, B
-  uint32_t img[2];      // nblk * BLKP
-  uint32_t chunk;       // P * (img[0] + img[1])
-  int nbuf;             // ring depth: min(8, LDS bytes / chunk)
+constexpr int DW_LDS_BYTES = 8 * OPER_BYTES;   // 144 KiB of dynamic LDS for every instantiation
+// Narrow jobs, per shape.  An operand image is its n / 16 chunk blocks per plane per 32-row tile; a ring slot holds T tiles
+// (two for the 160-column jobs, whose 10 KiB tiles are too little work per barrier: the serial chain wait -> barrier -> DMA
+// issue -> LDS read -> MFMA took 870-980 cycles per tile against ~700 of HBM time).  The wave index runs along the LONGER
+// block axis of the output, so that a wave's fragment on that axis is read once per 16 samples for all KB MFMAs that use it
+// (until round 4 the blocks were dealt round-robin with both fragments read per MFMA and the reads not hoisted: the
+// [dS | dG]^T H7 job ran a serial read -> MFMA chain ten times per tile, 2860 cycles against ~1870 of HBM time).
+template <int P, int N_O, int N_I>
+struct NarrowShape {
+  static constexpr int N_OB = N_O / 32, N_IB = N_I / 32;
+  static constexpr bool BI_WAVE = N_IB > N_OB;                 // wave = in-block (else out-block)
+  static constexpr int NW = BI_WAVE ? N_IB : N_OB;             // waves with MFMA work; the others only move data
+  static constexpr int KB = BI_WAVE ? N_OB : N_IB;             // blocks per wave
+  static constexpr int NBLK_A = N_O / 16, NBLK_B = N_I / 16;   // 1 KiB blocks (= DMA wave-instructions) per plane per tile
+  static constexpr int T = NBLK_A + NBLK_B <= 10 ? 2 : 1;      // 32-row tiles per ring slot
+  static constexpr int IMG_A = NBLK_A * BLKP, IMG_B = NBLK_B * BLKP;
+  static constexpr int SUB = P * (IMG_A + IMG_B);              // one tile in LDS: [A planes | B planes]
+  static constexpr int CHUNK = T * SUB;
+  static constexpr int NT = P * (NBLK_A + NBLK_B), NTOT = T * NT;       // DMA wave-instructions per tile / per slot
+  static constexpr int CW_HI = (NTOT + 7) / 8;                 // waves < NTOT % 8 issue CW_HI of them, the others one fewer
+  static constexpr int NB = DW_LDS_BYTES / CHUNK > 8 ? 8 : DW_LDS_BYTES / CHUNK;
+  static_assert(NW <= 8 && KB <= NW && NTOT >= 8 && NB >= 2 && (NB - 2) * CW_HI < 63, "narrow dW shape");
 };
-template <int P>
-__device__ __forceinline__ NarrowGeom narrow_geom(const DwJob& job, uint32_t lds_bytes) {
-  NarrowGeom g;
-  g.nblk[0] = (uint32_t)job.n_o / 16;
-  g.nblk[1] = (uint32_t)job.n_i / 16;
-  g.img[0] = g.nblk[0] * BLKP;
-  g.img[1] = g.nblk[1] * BLKP;
-  g.chunk = P * (g.img[0] + g.img[1]);
-  const int n = (int)(lds_bytes / g.chunk);
-  g.nbuf = n > 8 ? 8 : n;
-  return g;
-}
 __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
   const uint4 w = *(const uint4*)&v;
   const uint32_t u[4] = {w.x, w.y, w.z, w.w};
@@ -156,32 +160,47 @@ __device__ __forceinline__ void compute_chunk(lds_addr buf, int wo, int wi, int 
   }
 }
 
-// Narrow jobs (fewer than 8x8 blocks): blocks are dealt round-robin to the 8 waves (wave w owns blocks
-// w, w+8, ...; block b = (bo = b / n_ib, bi = b % n_ib)), so every wave has work between barriers.
-template <int P>
-__device__ __forceinline__ void compute_chunk_rr(lds_addr buf_a, lds_addr buf_b, const NarrowGeom& gm, int wave, int n_ib,
-                                                 int nblk, bool has_bias, f32x16 (&acc)[8], float (&bsum)[8]) {
+// one ring slot of a narrow job: T tiles x 2 k16-steps x KB MFMAs; all LDS reads of a k16-step precede its MFMAs
+template <int P, typename S>
+__device__ __forceinline__ void compute_narrow(lds_addr buf, int wave, bool has_bias, f32x16 (&acc)[S::KB], float& bsum) {
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
+  for (int sub = 0; sub < S::T; ++sub) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int b = wave + 8 * k;
-      if (b >= nblk) break;
-      const int bo = b / n_ib, bi = b - bo * n_ib;
-      bf16x8 fa[P], fb[P];
+    for (int kk = 0; kk < 2; ++kk) {
+      const lds_addr base = buf + sub * S::SUB + kk * 512;
+      bf16x8 fw[P], fk[S::KB][P];            // the wave's own fragment (long axis), the KB fragments of the short axis
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        fa[p] = tr_frag(buf_a + p * gm.img[0] + kk * 512 + 2 * bo * BLKP);
-        fb[p] = tr_frag(buf_b + p * gm.img[1] + kk * 512 + 2 * bi * BLKP);
+        if constexpr (S::BI_WAVE) fw[p] = tr_frag(base + P * S::IMG_A + p * S::IMG_B + 2 * wave * BLKP);
+        else fw[p] = tr_frag(base + p * S::IMG_A + 2 * wave * BLKP);
+#pragma unroll
+        for (int k = 0; k < S::KB; ++k) {
+          if constexpr (S::BI_WAVE) fk[k][p] = tr_frag(base + p * S::IMG_A + 2 * k * BLKP);
+          else fk[k][p] = tr_frag(base + P * S::IMG_A + p * S::IMG_B + 2 * k * BLKP);
+        }
       }
-      acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[k], 0, 0, 0);
-      if constexpr (P == 2) {
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[k], 0, 0, 0);
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[k], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < S::KB; ++k) {
+        const bf16x8* fa = S::BI_WAVE ? fk[k] : fw;
+        const bf16x8* fb = S::BI_WAVE ? fw : fk[k];
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[k], 0, 0, 0);
+        if constexpr (P == 2) {
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[k], 0, 0, 0);
+        }
       }
-      if (has_bias && bi == 0) {
-        bsum[k] += bf16_sum8(fa[0]);
-        if constexpr (P == 2) bsum[k] += bf16_sum8(fa[1]);
+      if (has_bias) {                        // column sums of dZ: out-block `wave` (BI_WAVE: wave k < KB sums out-block k)
+        if constexpr (S::BI_WAVE) {
+#pragma unroll
+          for (int k = 0; k < S::KB; ++k)
+            if (k == wave) {
+              bsum += bf16_sum8(fk[k][0]);
+              if constexpr (P == 2) bsum += bf16_sum8(fk[k][1]);
+            }
+        } else {
+          bsum += bf16_sum8(fw[0]);
+          if constexpr (P == 2) bsum += bf16_sum8(fw[1]);
+        }
       }
     }
   }
@@ -202,6 +221,121 @@ extern "C" int nerfpp_probe_dw_stamps(void* host_dst, int bytes) {
 #define DW_STAMP(full_, slot_, val_) {}
 #endif
 
+// A narrow job over its row slice.  The slot's NTOT blocks, in the order [tile 0: A planes | B planes][tile 1: ...], are dealt
+// round-robin to the 8 waves: wave w issues ids w, w + 8, ... (CW of them; every instruction is one whole block, all 64
+// lanes live) and waits for ITS OWN instructions before the barrier.  The main loop is instantiated per CW (the counted
+// waits need immediates; the waves of a workgroup differ by at most one).
+template <int P, int N_O, int N_I>
+__device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, int net, int split, int ksplit, int dbg, int bid) {
+  using S = NarrowShape<P, N_O, N_I>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int rb_a = tensor_ld(net, job.a_tensor) * 2, rb_b = tensor_ld(net, job.b_tensor) * 2;   // row bytes
+  const char* ga = (const char*)a.ws[net].t[job.a_tensor];
+  const char* gb = (const char*)a.ws[net].t[job.b_tensor];
+  const size_t plane_a = (size_t)a.rows_padded * rb_a, plane_b = (size_t)a.rows_padded * rb_b;
+  constexpr int RT = 32 * S::T;                          // rows per ring slot (rows_padded is a multiple of 256, zero-filled)
+  const int64_t rows_t = (a.rows + RT - 1) / RT * RT;
+  int64_t rps = (rows_t + ksplit - 1) / ksplit;
+  rps = (rps + RT - 1) / RT * RT;
+  const int64_t r_begin = split * rps;
+  const int64_t r_end = r_begin + rps < rows_t ? r_begin + rps : rows_t;
+  const int nchunk = r_end > r_begin ? (int)((r_end - r_begin) / RT) : 0;
+  DW_STAMP(false, 0, __builtin_readcyclecounter());
+  DW_STAMP(false, 4, nchunk * S::T);
+  DW_STAMP(false, 5, __builtin_amdgcn_s_getreg((3 << 11) | 20));      // XCC_ID
+
+  f32x16 acc[S::KB];
+#pragma unroll
+  for (int x = 0; x < S::KB; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+  float bsum = 0.f;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
+  const int g = lane >> 4, a16 = lane & 15;              // per-lane position for the transposed reads (see dw_body)
+  const int lane_off = (g & 1) * BLKP + ((((g >> 1) * 8 + (a16 >> 2)) * 2 + (a16 & 1)) * 16) + ((a16 >> 1) & 1) * 8;
+  const size_t tb_a = (size_t)(rb_a >> 5), tb_b = (size_t)(rb_b >> 5);   // blocks per 32-row tile of each operand TENSOR
+  const bool has_bias = job.gb_off >= 0;
+
+  auto run = [&](auto cw_c) __attribute__((always_inline)) {
+    constexpr int CW = decltype(cw_c)::value;
+    int slot_i = 0, next_i = 0;
+    auto issue = [&]() __attribute__((always_inline)) {          // next chunk of the slice -> next ring slot
+      const int c = next_i, slot = slot_i;
+      ++next_i;
+      slot_i = slot_i + 1 == S::NB ? 0 : slot_i + 1;
+      if (c >= nchunk || dbg == 2) return;
+      const size_t tile = (size_t)(r_begin >> 5) + (size_t)c * S::T;
+      const uint32_t buf = lds_base + slot * S::CHUNK;
+      const char* ca = ga + tile * tb_a * FRAG_BYTES + lane * 16;
+      const char* cb = gb + tile * tb_b * FRAG_BYTES + lane * 16;
+#pragma unroll
+      for (int k = 0; k < CW; ++k) {
+        const int id = wave + 8 * k;                   // < NTOT by the choice of CW
+        const int sub = S::T > 1 ? id / S::NT : 0, r = id - sub * S::NT;
+        const bool is_b = r >= P * S::NBLK_A;
+        const int idl = is_b ? r - P * S::NBLK_A : r, n_op = is_b ? S::NBLK_B : S::NBLK_A;
+        const int pl = idl >= n_op ? 1 : 0, blk = idl - pl * n_op;   // P <= 2
+        const char* src = (is_b ? cb + pl * plane_b + (size_t)sub * tb_b * FRAG_BYTES
+                                : ca + pl * plane_a + (size_t)sub * tb_a * FRAG_BYTES) + (size_t)blk * FRAG_BYTES;
+        glds16(src, buf + (uint32_t)sub * S::SUB + (is_b ? (uint32_t)(P * S::IMG_A) : 0u) +
+                        (uint32_t)pl * (is_b ? S::IMG_B : S::IMG_A) + (uint32_t)blk * BLKP);
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < S::NB - 1; ++c) issue();
+    int slot_c = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      const int younger = nchunk - 1 - c < S::NB - 2 ? nchunk - 1 - c : S::NB - 2;
+      switch (dbg == 2 ? 0 : younger) {            // wave-uniform; the count must be an immediate
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CW) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CW) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * CW) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * CW) : "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();
+      issue();
+      const lds_addr buf = slot_c * S::CHUNK + lane_off;
+      slot_c = slot_c + 1 == S::NB ? 0 : slot_c + 1;
+      if (dbg == 1) continue;
+      if (wave < S::NW) compute_narrow<P, S>(buf, wave, has_bias, acc, bsum);
+    }
+  };
+  if constexpr (S::NTOT % 8 == 0) run(std::integral_constant<int, S::CW_HI>{});
+  else if (wave < S::NTOT % 8) run(std::integral_constant<int, S::CW_HI>{});
+  else run(std::integral_constant<int, S::CW_HI - 1>{});
+
+  DW_STAMP(false, 1, __builtin_readcyclecounter());
+  float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
+  if (wave < S::NW) {
+#pragma unroll
+    for (int k = 0; k < S::KB; ++k) {
+      const int bo = S::BI_WAVE ? k : wave, bi = S::BI_WAVE ? wave : k;
+      // output segment of this out-block (a job may feed two stages, see DwJob::o_split)
+      const bool seg2 = job.o_split > 0 && bo >= job.o_split;
+      const int sbo = seg2 ? bo - job.o_split : bo;
+      const int s_off = seg2 ? job.gw_off2 : job.gw_off, s_ld = seg2 ? job.gw_ld2 : job.gw_ld;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * sbo + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        slab[s_off + o * s_ld + 32 * bi + li] = acc[k][r];
+      }
+    }
+    if (has_bias && wave < S::N_OB) {                     // wave w holds the column sums of out-block w (both mappings)
+      const int bo = wave;
+      const bool seg2 = job.o_split > 0 && bo >= job.o_split;
+      const int sbo = seg2 ? bo - job.o_split : bo;
+      const int s_gb = seg2 ? job.gb_off2 : job.gb_off;
+      const float tot = bsum + __shfl_xor(bsum, 32, 64);
+      if (hi == 0) slab[gw_floats(net) + s_gb + 32 * sbo + li] = tot;
+    }
+  }
+  DW_STAMP(false, 2, __builtin_readcyclecounter());
+}
+
 // workgroup -> (job of this launch, row slice): jobs in table order (net 0 then net 1), k slices each
 struct DwSched {
   int wg_end[2 * DW_JOBS];       // exclusive prefix of workgroups per job
@@ -219,6 +353,15 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
   const int njobs0 = sc.njobs0;
   const int net = job_id < njobs0 ? 0 : 1;
   const DwJob job = (FULL ? c_full : c_narrow).jobs[net][net == 0 ? job_id : job_id - njobs0];
+  DW_STAMP(FULL, 3, job_id);
+  if constexpr (!FULL) {
+    if (job.n_o == 256 && job.n_i == 64) narrow_job<P, 256, 64>(a, job, net, split, ksplit, dbg, bid);
+    else if (job.n_o == 256) narrow_job<P, 256, 96>(a, job, net, split, ksplit, dbg, bid);
+    else if (job.n_o == DSG_LD) narrow_job<P, DSG_LD, 256>(a, job, net, split, ksplit, dbg, bid);
+    else if (job.n_o == 128) narrow_job<P, 128, 32>(a, job, net, split, ksplit, dbg, bid);
+    else narrow_job<P, 32, 128>(a, job, net, split, ksplit, dbg, bid);
+    return;
+  }
   const int rb_a = tensor_ld(net, job.a_tensor) * 2, rb_b = tensor_ld(net, job.b_tensor) * 2;   // row bytes
   const char* ga = (const char*)a.ws[net].t[job.a_tensor];
   const char* gb = (const char*)a.ws[net].t[job.b_tensor];
@@ -231,7 +374,6 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
   const int64_t r_end = r_begin + rps < rows32 ? r_begin + rps : rows32;
   const int nchunk = r_end > r_begin ? (int)((r_end - r_begin) / 32) : 0;
   DW_STAMP(FULL, 0, __builtin_readcyclecounter());
-  DW_STAMP(FULL, 3, job_id);
   DW_STAMP(FULL, 4, nchunk);
   DW_STAMP(FULL, 5, __builtin_amdgcn_s_getreg((3 << 11) | 20));      // XCC_ID
 
@@ -246,15 +388,6 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[x][0][r] = 0.f; acc[x][1][r] = 0.f; }
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  // the narrow instantiation deals blocks round-robin instead (its own accumulator set)
-  f32x16 acc_rr[8];
-#pragma unroll
-  for (int x = 0; x < 8; ++x)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_rr[x][r] = 0.f;
-  float bsum_rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int n_ib = job.n_i / 32, nblk = (job.n_o / 32) * n_ib;
-
   // DMA: 2 operands x P planes x (columns / 16) one-KiB blocks per 32-row chunk; full jobs: 4P wave-instructions per wave
   constexpr int DMA_PER_CHUNK = 4 * P;           // wave-instructions per wave per chunk (full jobs)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
@@ -298,108 +431,10 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
       const lds_addr buf = (c % NBUF) * (2 * P * OPER_BYTES) + lane_off;
       compute_chunk<P, true>(buf, wo, wi, nbo, nbi, do_bias, acc, bsum);
     }
-  } else {
-    const NarrowGeom gm = narrow_geom<P>(job, lds_bytes);
-    const int NB = gm.nbuf;
-    // the chunk's blocks in the order [A plane 0 .. P-1 | B plane 0 .. P-1] are dealt round-robin to the 8 waves: wave w
-    // issues ids w, w + 8, ... (c_w of them; every instruction is one whole block, all 64 lanes live) and waits for ITS OWN
-    // instructions before the barrier
-    const int n_a = (int)gm.nblk[0], n_b = (int)gm.nblk[1], n_total = P * (n_a + n_b);
-    const int c_w = (n_total - wave + 7) >> 3;
-    constexpr int CMAX = (P * 32 + 7) / 8;
-    const lds_addr off_a = lane_off, off_b = P * gm.img[0] + lane_off;
-    // The main loop is instantiated per value of c_w (1 .. CMAX; wave-uniform, the waves of a workgroup differ by at most
-    // one): the counted waits need immediates, and a 61-way switch on younger * c_w in every chunk cost 5-11 % of the
-    // launch (jump table + refetch).  Every instantiation runs the same number of barriers.
-    auto run = [&](auto cw_c) __attribute__((always_inline)) {
-      constexpr int CW = decltype(cw_c)::value;
-      int slot_i = 0, next_i = 0;
-      auto issue = [&]() __attribute__((always_inline)) {          // next chunk of the slice -> next ring slot
-        const int c = next_i, slot = slot_i;
-        ++next_i;
-        slot_i = slot_i + 1 == NB ? 0 : slot_i + 1;
-        if (c >= nchunk || dbg == 2) return;
-        const size_t tile = (size_t)((r_begin >> 5) + c);
-        const uint32_t buf = lds_base + slot * gm.chunk;
-        const char* ca = ga + tile * tb_a * FRAG_BYTES + lane * 16;
-        const char* cb = gb + tile * tb_b * FRAG_BYTES + lane * 16;
-#pragma unroll
-        for (int k = 0; k < CW; ++k) {
-          const int id = wave + 8 * k;                 // < n_total by the definition of c_w
-          const bool is_b = id >= P * n_a;
-          const int idl = is_b ? id - P * n_a : id, n_op = is_b ? n_b : n_a;
-          const int pl = idl >= n_op ? 1 : 0, blk = idl - pl * n_op;   // P <= 2
-          const char* src = (is_b ? cb + pl * plane_b : ca + pl * plane_a) + (size_t)blk * FRAG_BYTES;
-          glds16(src, buf + (is_b ? P * gm.img[0] : 0u) + (uint32_t)pl * (is_b ? gm.img[1] : gm.img[0]) + (uint32_t)blk * BLKP);
-        }
-      };
-      for (int c = 0; c < NB - 1; ++c) issue();
-      int slot_c = 0;
-      for (int c = 0; c < nchunk; ++c) {
-        const int younger = nchunk - 1 - c < NB - 2 ? nchunk - 1 - c : NB - 2;
-        switch (dbg == 2 ? 0 : younger) {            // wave-uniform; the count must be an immediate
-          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CW) : "memory"); break;
-          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
-          case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
-          case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CW) : "memory"); break;
-          case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * CW) : "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * CW) : "memory"); break;
-        }
-        __builtin_amdgcn_s_barrier();
-        issue();
-        const lds_addr buf = slot_c * gm.chunk;
-        slot_c = slot_c + 1 == NB ? 0 : slot_c + 1;
-        if (dbg == 1) continue;
-        compute_chunk_rr<P>(buf + off_a, buf + off_b, gm, wave, n_ib, nblk, job.gb_off >= 0, acc_rr, bsum_rr);
-      }
-    };
-    static_assert(CMAX <= 8 && 6 * CMAX < 63, "counted waits fit the vmcnt field");
-    switch (c_w) {
-      case 1: run(std::integral_constant<int, 1>{}); break;
-      case 2: run(std::integral_constant<int, 2>{}); break;
-      case 3: run(std::integral_constant<int, 3>{}); break;
-      case 4: run(std::integral_constant<int, 4>{}); break;
-      default:
-        if constexpr (P == 2) {
-          switch (c_w) {
-            case 5: run(std::integral_constant<int, 5>{}); break;
-            case 6: run(std::integral_constant<int, 6>{}); break;
-            case 7: run(std::integral_constant<int, 7>{}); break;
-            default: run(std::integral_constant<int, 8>{}); break;
-          }
-        } else {
-          run(std::integral_constant<int, 4>{});
-        }
-    }
   }
 
   DW_STAMP(FULL, 1, __builtin_readcyclecounter());
   float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
-  if constexpr (!FULL) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int b = wave + 8 * k;
-      if (b >= nblk) break;
-      const int bo = b / n_ib, bi = b - bo * n_ib;
-      // output segment of this out-block (a job may feed two stages, see DwJob::o_split)
-      const bool seg2 = job.o_split > 0 && bo >= job.o_split;
-      const int sbo = seg2 ? bo - job.o_split : bo;
-      const int s_off = seg2 ? job.gw_off2 : job.gw_off, s_ld = seg2 ? job.gw_ld2 : job.gw_ld;
-      const int s_gb = seg2 ? job.gb_off2 : job.gb_off;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = 32 * sbo + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        slab[s_off + o * s_ld + 32 * bi + li] = acc_rr[k][r];
-      }
-      if (job.gb_off >= 0 && bi == 0) {
-        const float tot = bsum_rr[k] + __shfl_xor(bsum_rr[k], 32, 64);
-        if (hi == 0) slab[gw_floats(net) + s_gb + 32 * sbo + li] = tot;
-      }
-    }
-    DW_STAMP(FULL, 2, __builtin_readcyclecounter());
-    return;
-  }
 #pragma unroll
   for (int bo = 0; bo < 4; ++bo) {
     if (bo >= nbo) continue;
@@ -427,6 +462,9 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
 // SLOWER, the weight-gradient group 0.634 vs 0.620 ms; profiles/r04_pair_launch.md.  Two launches it stays.)
 template <int P, bool FULL>
 __global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, uint32_t lds_bytes) {
+#ifndef NERFPP_PROBES
+  dbg = 0;                 // (1: DMA only, 2: MFMA only -- diagnostic builds)
+#endif
   dw_body<P, FULL>(a, sc, dbg, lds_bytes, (int)blockIdx.x);
 }
 

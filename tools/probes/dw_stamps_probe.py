@@ -49,9 +49,10 @@ def main():
     for which, name in ((0, 'full'), (1, 'narrow')):
         s = buf[which].astype(np.int64)
         s = s[s[:, 0] > 0]
-        t0 = s[:, 0].min()
-        start, loop_end, end = s[:, 0] - t0, s[:, 1] - t0, s[:, 2] - t0
         job, nch, xcc = s[:, 3], s[:, 4], s[:, 5]
+        # the cycle counters of the XCDs are not synchronised on every box: time is relative to the first start on the same XCD
+        t0 = np.array([s[xcc == x, 0].min() for x in xcc])
+        start, loop_end, end = s[:, 0] - t0, s[:, 1] - t0, s[:, 2] - t0
         span = int(end.max())
         crit = int(end.argmax())
         rows = []
