@@ -141,9 +141,9 @@ int64_t nerfpp_level_tables_elems(void);
 int nerfpp_build_level_tables(int32_t* host_tables);
 
 /* Host-side introspection of the weight-gradient launch plan for a level with `rows` = n_rays * n_samples:
- * k_out[net * 12 + job] = row slices (= workgroups = gradient slabs) of job `job` of net `net`
- * (job order: L0, L1..L4, L5 encoded-point part, L5 h4 part, L6, L7, [sigma | rgb0 M], rgb0 view-dir part,
- * rgb1), is_full_out[...] = 1 for the 256 x 256 jobs.  No GPU needed.  Returns the number of jobs per net. */
+ * k_out[net * 10 + job] = row slices (= workgroups = gradient slabs) of job `job` of net `net`
+ * (job order: L0, L1..L4, L5 (encoded-point and h4 columns), L6, L7, [sigma | rgb0] (M and view-dir columns),
+ * rgb1), is_full_out[...] = 1 for the 256 x 256 jobs.  No GPU needed.  Returns the number of jobs per net (10). */
 int nerfpp_dw_plan(int64_t rows, int32_t* k_out, int32_t* is_full_out);
 
 /* packed weights of one level (both nets, forward + backward streams + biases) */

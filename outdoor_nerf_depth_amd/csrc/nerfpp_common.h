@@ -192,8 +192,9 @@ __host__ __device__ constexpr int gw_dz_tensor(int s) {
 
 struct DwJob {       // one weight-gradient GEMM: the whole (<= 256 x 256) output, contracted over a row slice
   int16_t a_tensor, b_tensor;     // dZ tensor, input tensor
+  int16_t b_tensor2, n_i1;        // the input may span two tensors: columns [0, n_i1) from b_tensor, [n_i1, n_i) from b_tensor2
   int16_t o0, i0;                 // first column in each tensor
-  int16_t n_o, n_i;               // valid columns (multiples of 32, <= 256)
+  int16_t n_o, n_i;               // valid columns (multiples of 32; 256 x 256 = "full", everything else "narrow")
   int32_t gw_off;                 // offset of element (o0, i_global0) in the slab
   int16_t gw_ld;                  // row stride of this stage's GW block
   int16_t gb_off;                 // offset of bias o0 in the slab's bias part, or -1
@@ -202,8 +203,8 @@ struct DwJob {       // one weight-gradient GEMM: the whole (<= 256 x 256) outpu
   int16_t gw_ld2, gb_off2;
   int32_t gw_off2;
 };
-constexpr int DW_JOBS = 12;                  // per net (build_all_jobs order)
-constexpr int DW_KMAX = 48;                  // slabs allocated per net; a job uses the first k_job of them
+constexpr int DW_JOBS = 10;                  // per net (build_all_jobs order)
+constexpr int DW_KMAX = 64;                  // slabs allocated per net; a job uses the first k_job of them
 
 struct JobTable {
   DwJob jobs[N_NET][DW_JOBS];
@@ -213,18 +214,21 @@ constexpr void add_job(JobTable& jt, int net, int s, int b_tensor, int icol, boo
   DwJob j{};
   j.a_tensor = (int16_t)gw_dz_tensor(s);
   j.b_tensor = (int16_t)b_tensor;
+  j.b_tensor2 = (int16_t)b_tensor;
   j.o0 = 0;
   j.i0 = 0;
   j.n_o = (int16_t)gw_O(s);
   j.n_i = (int16_t)tensor_ld(net, b_tensor);
+  j.n_i1 = j.n_i;
   j.gw_off = gw_off(net, s) + icol;
   j.gw_ld = (int16_t)gw_I(net, s);
   j.gb_off = (int16_t)(bias ? gb_off(s) : -1);
   jt.jobs[net][jt.count[net]++] = j;
 }
-// job index per net: 0 L0 | 1-4 L1-L4 | 5 L5 (encoded-point columns) | 6 L5 (h4 columns) | 7,8 L6,L7 |
-// 9 [dS | dG]^T H7 = sigma weights + M (M = dG^T H7, see remap_fixup_kernel) | 10 rgb0 (view-direction
-// columns) | 11 rgb1
+// job index per net: 0 L0 | 1-4 L1-L4 | 5 L5 = dZ5^T [X | H4] | 6,7 L6,L7 | 8 [dS | dG]^T [H7 | DIRX] = sigma weights + M
+// (M = dG^T H7, see remap_fixup_kernel) + the view-direction columns of rgb0 | 9 rgb1.
+// Jobs that share an operand are ONE job since round 4 (dZ5 was read by an encoded-point job and an h4 job, dG by the M job and
+// a view-direction job: 768 of 9.98 KB per row and net).
 constexpr JobTable build_all_jobs() {
   JobTable jt{};
   for (int net = 0; net < N_NET; ++net) {
@@ -232,21 +236,26 @@ constexpr JobTable build_all_jobs() {
     for (int s = 0; s < FS_COUNT; ++s) {
       if (s == FS_L0) add_job(jt, net, s, T_X, 0, true);
       else if (s == FS_L5) {
-        add_job(jt, net, s, T_X, 0, true);
-        add_job(jt, net, s, T_H0 + 4, kpew(net), false);
+        add_job(jt, net, s, T_X, 0, true);           // columns [0, kpew) of the stage's input are the encoded point ...
+        DwJob& m = jt.jobs[net][jt.count[net] - 1];
+        m.b_tensor2 = (int16_t)(T_H0 + 4);           // ... the other 256 are h4
+        m.n_i = (int16_t)(kpew(net) + 256);
       } else if (s < 8) add_job(jt, net, s, T_H0 + s - 1, 0, true);
       else if (s == FS_REMAP) continue;            // dW_remap = Wrgb0r^T * M, derived in remap_fixup_kernel
       else if (s == FS_SIG) continue;              // merged into the next job
       else if (s == FS_RGB0) {
-        // [dS | dG]^T * H7: rows 0..31 -> sigma stage, rows 32..159 -> M (NOT dG^T * R; fixed up after the slab sum)
+        // [dS | dG]^T * [H7 | DIRX]: out-rows 0..31 -> sigma stage (its 256 input columns; the dS^T DIRX block is not
+        // written), rows 32..159 -> rgb0: columns 0..255 = M (NOT dG^T * R; fixed up after the slab sum), 256..287 =
+        // the view-direction columns
         add_job(jt, net, FS_SIG, T_H0 + 7, 0, true);
         DwJob& m = jt.jobs[net][jt.count[net] - 1];
         m.n_o = DSG_LD;
+        m.b_tensor2 = (int16_t)T_DIRX;
+        m.n_i = (int16_t)(256 + DIRW);
         m.o_split = 1;
         m.gw_off2 = gw_off(net, FS_RGB0);
         m.gw_ld2 = (int16_t)gw_I(net, FS_RGB0);
         m.gb_off2 = (int16_t)gb_off(FS_RGB0);
-        add_job(jt, net, s, T_DIRX, 256, false);
       } else add_job(jt, net, s, T_G, 0, true);
     }
   }
@@ -267,24 +276,17 @@ constexpr SlabMap make_slab_map() {
   return m;
 }
 __host__ __device__ constexpr int slab_job_index(const SlabMap& m, int net, int src) {
-  int s = 0;
-  bool is_bias = false;
-  int col = 0;
+  int s = 0;                                         // stage of the element: weights first, then the biases
   if (src >= m.gw[net][FS_COUNT]) {
-    is_bias = true;
     const int b = src - m.gw[net][FS_COUNT];
     for (int t = 1; t < FS_COUNT; ++t) s += m.gb[t] <= b;
   } else {
     for (int t = 1; t < FS_COUNT; ++t) s += m.gw[net][t] <= src;
-    col = (src - m.gw[net][s]) % m.gi[net][s];
   }
-  if (s < 5) return s;
-  if (s == FS_L5) return (is_bias || col < kpew(net)) ? 5 : 6;
-  if (s < 8) return s + 1;
+  if (s < 8) return s;
   if (s == FS_REMAP) return -1;
-  if (s == FS_SIG) return 9;
-  if (s == FS_RGB0) return (is_bias || col < 256) ? 9 : 10;
-  return 11;
+  if (s == FS_SIG || s == FS_RGB0) return 8;
+  return 9;
 }
 
 // How many row slices (= workgroups = slabs) each job gets.  The full 256x256 jobs all stream the
@@ -296,7 +298,7 @@ __host__ __device__ constexpr int slab_job_index(const SlabMap& m, int net, int 
 // to 4.9 and the table below is their measurement.)
 struct DwPlan { int k[N_NET][DW_JOBS]; };
 constexpr int dw_narrow_cost(const DwJob& j) {        // shader cycles per 32-row tile, bf16 (dw_kernel<1, false>, per-shape loops)
-  return j.n_o == DSG_LD ? 2050 : j.n_o == 256 ? (j.n_i == 64 ? 1545 : 1697) : j.n_o == 128 ? 786 : 790;
+  return j.n_o == DSG_LD ? 2250 : j.n_o == 256 ? (j.n_i == 64 ? 1338 : j.n_i == 96 ? 1358 : j.n_i == 320 ? 2909 : 3030) : 764;
 }
 inline DwPlan dw_plan(int64_t rows) {
   const JobTable jt = build_all_jobs();

@@ -53,15 +53,17 @@ constexpr JobTable build_jobs(bool full) {
   return jt;
 }
 // The narrow kernel is instantiated per job SHAPE (n_o x n_i); every narrow job of the table must have one.
-constexpr bool narrow_shape_known(int n_o, int n_i) {
-  return (n_o == 256 && (n_i == 64 || n_i == 96)) || (n_o == DSG_LD && n_i == 256) || (n_o == 128 && n_i == 32) ||
-         (n_o == 32 && n_i == 128);
+constexpr bool narrow_shape_known(int n_o, int n_i, int n_i1) {
+  return (n_o == 256 && (n_i == 64 || n_i == 96) && n_i1 == n_i) ||                  // L0: dZ0^T X
+         (n_o == 256 && (n_i == 320 || n_i == 352) && n_i1 == n_i - 256) ||          // L5: dZ5^T [X | H4]
+         (n_o == DSG_LD && n_i == 288 && n_i1 == 256) ||                             // [dS | dG]^T [H7 | DIRX]
+         (n_o == 32 && n_i == 128 && n_i1 == 128);                                   // rgb1: dP^T G
 }
 constexpr bool narrow_jobs_have_shapes() {
   const JobTable jt = build_jobs(false);
   for (int net = 0; net < N_NET; ++net)
     for (int k = 0; k < jt.count[net]; ++k)
-      if (!narrow_shape_known(jt.jobs[net][k].n_o, jt.jobs[net][k].n_i)) return false;
+      if (!narrow_shape_known(jt.jobs[net][k].n_o, jt.jobs[net][k].n_i, jt.jobs[net][k].n_i1)) return false;
   return true;
 }
 static_assert(narrow_jobs_have_shapes(), "narrow dW job without a NarrowShape instantiation (dw_body)");
@@ -99,13 +101,21 @@ constexpr int DW_LDS_BYTES = 8 * OPER_BYTES;   // 144 KiB of dynamic LDS for eve
 // block axis of the output, so that a wave's fragment on that axis is read once per 16 samples for all KB MFMAs that use it
 // (until round 4 the blocks were dealt round-robin with both fragments read per MFMA and the reads not hoisted: the
 // [dS | dG]^T H7 job ran a serial read -> MFMA chain ten times per tile, 2860 cycles against ~1870 of HBM time).
-template <int P, int N_O, int N_I>
+// A pass covers the in-blocks [IB0, IB0 + IBN) of the job's output (all of them, unless a slot of the whole job would not
+// fit the LDS twice: the split-bf16 L5 job runs two passes over its slice).
+template <int P, int N_O, int N_I1, int IB0, int IBN>
 struct NarrowShape {
-  static constexpr int N_OB = N_O / 32, N_IB = N_I / 32;
-  static constexpr bool BI_WAVE = N_IB > N_OB;                 // wave = in-block (else out-block)
-  static constexpr int NW = BI_WAVE ? N_IB : N_OB;             // waves with MFMA work; the others only move data
-  static constexpr int KB = BI_WAVE ? N_OB : N_IB;             // blocks per wave
-  static constexpr int NBLK_A = N_O / 16, NBLK_B = N_I / 16;   // 1 KiB blocks (= DMA wave-instructions) per plane per tile
+  static constexpr int N_OB = N_O / 32, N_IB = IBN;
+  // wave = in-block (else out-block).  Nine in-blocks: eight of them one per wave, and wave w < N_OB also owns block (w, 8)
+  // -- the [dS | dG]^T [H7 | DIRX] job: 5 x 9 blocks as 6 + 6 + 6 + 6 + 6 + 5 + 5 + 5
+  static constexpr bool BI_WAVE = N_IB > N_OB && N_IB <= 9;
+  static constexpr bool XTRA = BI_WAVE && N_IB == 9;
+  static constexpr int NW = BI_WAVE ? (XTRA ? 8 : N_IB) : N_OB;    // waves with MFMA work; the others only move data
+  static constexpr int KB = BI_WAVE ? N_OB : N_IB;             // blocks per wave (+ 1 accumulator for the extra block)
+  static constexpr int NACC = KB + (XTRA ? 1 : 0);
+  static constexpr int NBLK_A = N_O / 16, NBLK_B = 2 * IBN;    // 1 KiB blocks (= DMA wave-instructions) per plane per tile
+  static constexpr int BLK_B0 = 2 * IB0;                       // first block of the pass in the job's input row
+  static constexpr int NBLK_B1 = N_I1 / 16;                    // blocks of that row the first input tensor supplies
   static constexpr int T = NBLK_A + NBLK_B <= 10 ? 2 : 1;      // 32-row tiles per ring slot
   static constexpr int IMG_A = NBLK_A * BLKP, IMG_B = NBLK_B * BLKP;
   static constexpr int SUB = P * (IMG_A + IMG_B);              // one tile in LDS: [A planes | B planes]
@@ -113,7 +123,8 @@ struct NarrowShape {
   static constexpr int NT = P * (NBLK_A + NBLK_B), NTOT = T * NT;       // DMA wave-instructions per tile / per slot
   static constexpr int CW_HI = (NTOT + 7) / 8;                 // waves < NTOT % 8 issue CW_HI of them, the others one fewer
   static constexpr int NB = DW_LDS_BYTES / CHUNK > 8 ? 8 : DW_LDS_BYTES / CHUNK;
-  static_assert(NW <= 8 && KB <= NW && NTOT >= 8 && NB >= 2 && (NB - 2) * CW_HI < 63, "narrow dW shape");
+  static constexpr int KG = P == 1 ? 6 : 3;                    // short-axis fragments read ahead of their MFMAs (registers)
+  static_assert(NW <= 8 && NTOT >= 8 && NB >= 2 && (NB - 2) * CW_HI < 63, "narrow dW shape");
 };
 __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
   const uint4 w = *(const uint4*)&v;
@@ -162,7 +173,7 @@ __device__ __forceinline__ void compute_chunk(lds_addr buf, int wo, int wi, int 
 
 // one ring slot of a narrow job: T tiles x 2 k16-steps x KB MFMAs; all LDS reads of a k16-step precede its MFMAs
 template <int P, typename S>
-__device__ __forceinline__ void compute_narrow(lds_addr buf, int wave, bool has_bias, f32x16 (&acc)[S::KB], float& bsum) {
+__device__ __forceinline__ void compute_narrow(lds_addr buf, int wave, bool has_bias, f32x16 (&acc)[S::NACC], float& bsum) {
 #pragma unroll
   for (int sub = 0; sub < S::T; ++sub) {
 #pragma unroll
@@ -173,21 +184,40 @@ __device__ __forceinline__ void compute_narrow(lds_addr buf, int wave, bool has_
       for (int p = 0; p < P; ++p) {
         if constexpr (S::BI_WAVE) fw[p] = tr_frag(base + P * S::IMG_A + p * S::IMG_B + 2 * wave * BLKP);
         else fw[p] = tr_frag(base + p * S::IMG_A + 2 * wave * BLKP);
-#pragma unroll
-        for (int k = 0; k < S::KB; ++k) {
-          if constexpr (S::BI_WAVE) fk[k][p] = tr_frag(base + p * S::IMG_A + 2 * k * BLKP);
-          else fk[k][p] = tr_frag(base + P * S::IMG_A + p * S::IMG_B + 2 * k * BLKP);
-        }
       }
 #pragma unroll
-      for (int k = 0; k < S::KB; ++k) {
-        const bf16x8* fa = S::BI_WAVE ? fk[k] : fw;
-        const bf16x8* fb = S::BI_WAVE ? fw : fk[k];
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[k], 0, 0, 0);
-        if constexpr (P == 2) {
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[k], 0, 0, 0);
+      for (int k0 = 0; k0 < S::KB; k0 += S::KG) {
+#pragma unroll
+        for (int k = k0; k < k0 + S::KG && k < S::KB; ++k)
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if constexpr (S::BI_WAVE) fk[k][p] = tr_frag(base + p * S::IMG_A + 2 * k * BLKP);
+            else fk[k][p] = tr_frag(base + P * S::IMG_A + p * S::IMG_B + 2 * k * BLKP);
+          }
+#pragma unroll
+        for (int k = k0; k < k0 + S::KG && k < S::KB; ++k) {
+          const bf16x8* fa = S::BI_WAVE ? fk[k] : fw;
+          const bf16x8* fb = S::BI_WAVE ? fw : fk[k];
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[k], 0, 0, 0);
+          if constexpr (P == 2) {
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[k], 0, 0, 0);
+          }
         }
+      }
+      if constexpr (S::XTRA) {               // block (bo = wave, bi = 8): the wave's out-block fragment is fk[wave]
+        bf16x8 fx[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) fx[p] = tr_frag(base + P * S::IMG_A + p * S::IMG_B + 2 * 8 * BLKP);
+#pragma unroll
+        for (int k = 0; k < S::KB; ++k)
+          if (k == wave) {
+            acc[S::KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[k][0], fx[0], acc[S::KB], 0, 0, 0);
+            if constexpr (P == 2) {
+              acc[S::KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[k][0], fx[1], acc[S::KB], 0, 0, 0);
+              acc[S::KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[k][1], fx[0], acc[S::KB], 0, 0, 0);
+            }
+          }
       }
       if (has_bias) {                        // column sums of dZ: out-block `wave` (BI_WAVE: wave k < KB sums out-block k)
         if constexpr (S::BI_WAVE) {
@@ -225,15 +255,17 @@ extern "C" int nerfpp_probe_dw_stamps(void* host_dst, int bytes) {
 // round-robin to the 8 waves: wave w issues ids w, w + 8, ... (CW of them; every instruction is one whole block, all 64
 // lanes live) and waits for ITS OWN instructions before the barrier.  The main loop is instantiated per CW (the counted
 // waits need immediates; the waves of a workgroup differ by at most one).
-template <int P, int N_O, int N_I>
-__device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, int net, int split, int ksplit, int dbg, int bid) {
-  using S = NarrowShape<P, N_O, N_I>;
+template <int P, int N_O, int N_I1, int IB0, int IBN>
+__device__ __forceinline__ void narrow_pass(const DwArgs& a, const DwJob& job, int net, int split, int ksplit, int dbg, int bid) {
+  using S = NarrowShape<P, N_O, N_I1, IB0, IBN>;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
-  const int rb_a = tensor_ld(net, job.a_tensor) * 2, rb_b = tensor_ld(net, job.b_tensor) * 2;   // row bytes
+  const int rb_a = tensor_ld(net, job.a_tensor) * 2;     // row bytes
+  const int rb_b = tensor_ld(net, job.b_tensor) * 2, rb_b2 = tensor_ld(net, job.b_tensor2) * 2;
   const char* ga = (const char*)a.ws[net].t[job.a_tensor];
   const char* gb = (const char*)a.ws[net].t[job.b_tensor];
-  const size_t plane_a = (size_t)a.rows_padded * rb_a, plane_b = (size_t)a.rows_padded * rb_b;
+  const char* gb2 = (const char*)a.ws[net].t[job.b_tensor2];
+  const size_t plane_a = (size_t)a.rows_padded * rb_a, plane_b = (size_t)a.rows_padded * rb_b, plane_b2 = (size_t)a.rows_padded * rb_b2;
   constexpr int RT = 32 * S::T;                          // rows per ring slot (rows_padded is a multiple of 256, zero-filled)
   const int64_t rows_t = (a.rows + RT - 1) / RT * RT;
   int64_t rps = (rows_t + ksplit - 1) / ksplit;
@@ -245,17 +277,17 @@ __device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, in
   DW_STAMP(false, 4, nchunk * S::T);
   DW_STAMP(false, 5, __builtin_amdgcn_s_getreg((3 << 11) | 20));      // XCC_ID
 
-  f32x16 acc[S::KB];
+  f32x16 acc[S::NACC];
 #pragma unroll
-  for (int x = 0; x < S::KB; ++x)
+  for (int x = 0; x < S::NACC; ++x)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
   float bsum = 0.f;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
   const int g = lane >> 4, a16 = lane & 15;              // per-lane position for the transposed reads (see dw_body)
   const int lane_off = (g & 1) * BLKP + ((((g >> 1) * 8 + (a16 >> 2)) * 2 + (a16 & 1)) * 16) + ((a16 >> 1) & 1) * 8;
-  const size_t tb_a = (size_t)(rb_a >> 5), tb_b = (size_t)(rb_b >> 5);   // blocks per 32-row tile of each operand TENSOR
-  const bool has_bias = job.gb_off >= 0;
+  const size_t tb_a = (size_t)(rb_a >> 5), tb_b = (size_t)(rb_b >> 5), tb_b2 = (size_t)(rb_b2 >> 5);   // blocks per 32-row tile of each operand TENSOR
+  const bool has_bias = job.gb_off >= 0 && IB0 == 0;
 
   auto run = [&](auto cw_c) __attribute__((always_inline)) {
     constexpr int CW = decltype(cw_c)::value;
@@ -269,6 +301,7 @@ __device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, in
       const uint32_t buf = lds_base + slot * S::CHUNK;
       const char* ca = ga + tile * tb_a * FRAG_BYTES + lane * 16;
       const char* cb = gb + tile * tb_b * FRAG_BYTES + lane * 16;
+      const char* cb2 = gb2 + tile * tb_b2 * FRAG_BYTES + lane * 16;
 #pragma unroll
       for (int k = 0; k < CW; ++k) {
         const int id = wave + 8 * k;                   // < NTOT by the choice of CW
@@ -276,8 +309,11 @@ __device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, in
         const bool is_b = r >= P * S::NBLK_A;
         const int idl = is_b ? r - P * S::NBLK_A : r, n_op = is_b ? S::NBLK_B : S::NBLK_A;
         const int pl = idl >= n_op ? 1 : 0, blk = idl - pl * n_op;   // P <= 2
-        const char* src = (is_b ? cb + pl * plane_b + (size_t)sub * tb_b * FRAG_BYTES
-                                : ca + pl * plane_a + (size_t)sub * tb_a * FRAG_BYTES) + (size_t)blk * FRAG_BYTES;
+        const int bblk = S::BLK_B0 + blk;                            // block of the job's input row
+        const bool second = is_b && bblk >= S::NBLK_B1;              // the input's second tensor (its own row width)
+        const char* src = !is_b ? ca + pl * plane_a + (size_t)sub * tb_a * FRAG_BYTES + (size_t)blk * FRAG_BYTES
+                        : !second ? cb + pl * plane_b + (size_t)sub * tb_b * FRAG_BYTES + (size_t)bblk * FRAG_BYTES
+                                  : cb2 + pl * plane_b2 + (size_t)sub * tb_b2 * FRAG_BYTES + (size_t)(bblk - S::NBLK_B1) * FRAG_BYTES;
         glds16(src, buf + (uint32_t)sub * S::SUB + (is_b ? (uint32_t)(P * S::IMG_A) : 0u) +
                         (uint32_t)pl * (is_b ? S::IMG_B : S::IMG_A) + (uint32_t)blk * BLKP);
       }
@@ -312,12 +348,14 @@ __device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, in
   float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
   if (wave < S::NW) {
 #pragma unroll
-    for (int k = 0; k < S::KB; ++k) {
-      const int bo = S::BI_WAVE ? k : wave, bi = S::BI_WAVE ? wave : k;
+    for (int k = 0; k < S::NACC; ++k) {
+      if (k == S::KB && wave >= S::N_OB) continue;       // (the extra block exists for wave < N_OB)
+      const int bo = k == S::KB ? wave : (S::BI_WAVE ? k : wave), bi = IB0 + (k == S::KB ? 8 : (S::BI_WAVE ? wave : k));
       // output segment of this out-block (a job may feed two stages, see DwJob::o_split)
       const bool seg2 = job.o_split > 0 && bo >= job.o_split;
       const int sbo = seg2 ? bo - job.o_split : bo;
       const int s_off = seg2 ? job.gw_off2 : job.gw_off, s_ld = seg2 ? job.gw_ld2 : job.gw_ld;
+      if (32 * bi + 32 > s_ld) continue;                 // (the dS^T DIRX block of the merged sigma / rgb0 job: not a parameter)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = 32 * sbo + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -334,6 +372,22 @@ __device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, in
     }
   }
   DW_STAMP(false, 2, __builtin_readcyclecounter());
+}
+
+template <int P, int N_O, int N_I, int N_I1>
+__device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, int net, int split, int ksplit, int dbg, int bid) {
+  constexpr int N_IB = N_I / 32, T = (N_O + N_I) / 16 <= 10 ? 2 : 1;
+  if constexpr (DW_LDS_BYTES / (T * P * ((N_O + N_I) / 16) * BLKP) >= 2) {
+    narrow_pass<P, N_O, N_I1, 0, N_IB>(a, job, net, split, ksplit, dbg, bid);
+  } else {
+    constexpr int H = (N_IB + 1) / 2;
+    narrow_pass<P, N_O, N_I1, 0, H>(a, job, net, split, ksplit, dbg, bid);
+    // the slab stores of the first pass share vmcnt with the second pass' DMA and may retire out of order: drain them; the
+    // barrier keeps the second pass' first DMA out of slots other waves still read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    narrow_pass<P, N_O, N_I1, H, N_IB - H>(a, job, net, split, ksplit, dbg, bid);
+  }
 }
 
 // workgroup -> (job of this launch, row slice): jobs in table order (net 0 then net 1), k slices each
@@ -355,11 +409,12 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
   const DwJob job = (FULL ? c_full : c_narrow).jobs[net][net == 0 ? job_id : job_id - njobs0];
   DW_STAMP(FULL, 3, job_id);
   if constexpr (!FULL) {
-    if (job.n_o == 256 && job.n_i == 64) narrow_job<P, 256, 64>(a, job, net, split, ksplit, dbg, bid);
-    else if (job.n_o == 256) narrow_job<P, 256, 96>(a, job, net, split, ksplit, dbg, bid);
-    else if (job.n_o == DSG_LD) narrow_job<P, DSG_LD, 256>(a, job, net, split, ksplit, dbg, bid);
-    else if (job.n_o == 128) narrow_job<P, 128, 32>(a, job, net, split, ksplit, dbg, bid);
-    else narrow_job<P, 32, 128>(a, job, net, split, ksplit, dbg, bid);
+    if (job.n_o == 256 && job.n_i == 64) narrow_job<P, 256, 64, 64>(a, job, net, split, ksplit, dbg, bid);
+    else if (job.n_o == 256 && job.n_i == 96) narrow_job<P, 256, 96, 96>(a, job, net, split, ksplit, dbg, bid);
+    else if (job.n_o == 256 && job.n_i == 320) narrow_job<P, 256, 320, 64>(a, job, net, split, ksplit, dbg, bid);
+    else if (job.n_o == 256) narrow_job<P, 256, 352, 96>(a, job, net, split, ksplit, dbg, bid);
+    else if (job.n_o == DSG_LD) narrow_job<P, DSG_LD, 288, 256>(a, job, net, split, ksplit, dbg, bid);
+    else narrow_job<P, 32, 128, 128>(a, job, net, split, ksplit, dbg, bid);
     return;
   }
   const int rb_a = tensor_ld(net, job.a_tensor) * 2, rb_b = tensor_ld(net, job.b_tensor) * 2;   // row bytes

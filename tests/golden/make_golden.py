@@ -522,7 +522,7 @@ def ref_render_frame(nets, rays, cascade, dtype=torch.float32, chunk=1024):
     return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
 
 
-def gen_trajectory(dtypes=(torch.float32, torch.float64)):
+def gen_trajectory(dtypes=(torch.float32, torch.float64), modes=None):
     """the imported reference's training loop (ddp_train_nerf.py:417-498) on the BASELINE config-1
     scene -- one 64x64 frame, --cascade_samples 32,64, N_rand 256, 200 steps -- rgb-only and with the gt / mse depth
     term, on replayed batches and uniforms (tests/trajectory_common.py: seeds only).  Stored: the logged scalars every 25
@@ -531,11 +531,13 @@ def gen_trajectory(dtypes=(torch.float32, torch.float64)):
     of the same reference code gives the noise floor of the float32 reference itself."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import trajectory_common as TC
-    smp = TC.sampler()
-    full = {k: np.ascontiguousarray(v, np.float32) for k, v in smp.get_all().items() if isinstance(v, np.ndarray)}
-    arrs = {}
+    path = os.path.join(HERE, 'trajectory.npz')
+    arrs = dict(np.load(path)) if (modes and os.path.exists(path)) else {}      # extend the fixture: earlier modes are kept as they are
     import time
-    for mode in TC.MODES:
+    for mode in (modes or TC.MODES):
+        smp = TC.sampler(mode)
+        full = {k: np.ascontiguousarray(v, np.float32) for k, v in smp.get_all().items() if isinstance(v, np.ndarray)}
+        sigma = TC.DEPTH_SIGMA * float(smp.get_depth_scale() or 1.0)
         for dtype in dtypes:
             tag = '%s.%s' % (mode, 'f32' if dtype == torch.float32 else 'f64')
             nets = [n.to(dtype) for n in make_levels(2)]
@@ -567,7 +569,7 @@ def gen_trajectory(dtypes=(torch.float32, torch.float64)):
                             bs = R.sample_pdf(bins=.5 * (bg[..., 1:] + bg[..., :-1]), weights=bgw, N_samples=S, det=False)
                             bg, _ = torch.sort(torch.cat((bg, bs), dim=-1))
                         optims[m].zero_grad()
-                        ret, loss, rgb_loss, depth_loss = ref_level_step(nets[m], bt, far, fg, bg, mode, TC.LAMBDA_DEPTH, 0.)
+                        ret, loss, rgb_loss, depth_loss = ref_level_step(nets[m], bt, far, fg, bg, mode, TC.LAMBDA_DEPTH, sigma)
                         optims[m].step()
                         row['loss%d' % m], row['rgb%d' % m] = loss.item(), rgb_loss.item()
                         row['depth%d' % m] = depth_loss.item() if depth_loss is not None else 0.0
@@ -594,7 +596,7 @@ def gen_trajectory(dtypes=(torch.float32, torch.float64)):
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':      # ~30 min of CPU: on request only
         torch.set_num_threads(8)
-        gen_trajectory()
+        gen_trajectory(modes=tuple(sys.argv[2:]) or None)
         sys.exit(0)
     gen_sampling()
     gen_embed()

@@ -100,19 +100,21 @@ def test_concurrent_backward_two_ranks_gloo(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------- training trajectory
-def _trajectory(precision, mode, n_steps=None):
-    """NerfppTrainer on the fixture's batches and uniforms; returns the logged rgb losses per step [n,2] and the final
-    frame rendered by render_single_image (deterministic sampling) with its PSNR against the image."""
+def _trajectory(precision, mode, n_steps=None, seed=0):
+    """NerfppTrainer on the fixture's batches and uniforms (seed 0; other seeds shift the numpy streams); returns the logged rgb
+    losses per step [n,2] and the final frame rendered by render_single_image (deterministic sampling) with its PSNR against
+    the image."""
     import trajectory_common as TC
     from outdoor_nerf_depth_amd.trainer import NerfppTrainer
     from outdoor_nerf_depth_amd.ddp_train_nerf import render_single_image
     d = dev()
-    smp = TC.sampler()
+    smp = TC.sampler(mode)
     tr = NerfppTrainer(d, precision=precision, cascade_samples=TC.CASCADE, use_depth=(mode != 'rgbonly'),
-                       depth_loss_type='mse', lambda_depth=TC.LAMBDA_DEPTH)
+                       depth_loss_type=(mode if mode != 'rgbonly' else 'mse'), lambda_depth=TC.LAMBDA_DEPTH,
+                       depth_sigma=TC.DEPTH_SIGMA, depth_scale=float(smp.get_depth_scale() or 1.0))
     sc_all = []
     for step in range(1, (n_steps or TC.N_STEPS) + 1):
-        b, uni = TC.step_batch(smp, step), TC.step_uniforms(step)
+        b, uni = TC.step_batch(smp, step + 100000 * seed), TC.step_uniforms(step + 100000 * seed)
         sc = tr.train_step({k: T(v, d) for k, v in b.items()}, uniforms={k: T(v, d) for k, v in uni.items()})
         sc_all.append(torch.stack([s[1] for s in sc]))
     rgb_mse = torch.stack(sc_all).cpu().numpy().astype(np.float64)
@@ -123,13 +125,34 @@ def _trajectory(precision, mode, n_steps=None):
     return rgb_mse, im, mse, float(TC.psnr(mse))
 
 
-@pytest.mark.parametrize('mode', ['rgbonly', 'mse'])
-def test_training_trajectory_psnr_against_reference(mode):
-    """VERDICT r03 item 3.  The imported reference trained 200 steps on the config-1 scene (tests/golden/trajectory.npz);
-    the HIP trainer replays the same batches and uniforms.  Gates: the split-bf16 forward modes (the ones that carry the
-    1e-4 output parity) end within 0.05 dB of the float32 reference in render PSNR and in the mean in-loop PSNR of the last
-    25 steps; single-pass bf16 within the bound stated below (its measured gap is recorded in the JSON this test writes)."""
+def _dump(name, report):
     import json
+    out = os.path.join(os.path.dirname(HERE), 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, name), 'w') as f:
+            json.dump(report, f, indent=1)
+    print(json.dumps(report))
+
+
+# relative deviation of the logged level-1 rgb loss from the float32 reference's: at the first log line (step 25), over the
+# first four (steps 25-100).  Measured (gpurun_out/trajectory_*.json): split-bf16 <= 0.0017 / 0.0135, split_fwd <= 0.0022 /
+# 0.037, bf16 <= 0.0098 / 0.0675 -- the trajectories coincide with the reference's and then separate exponentially.
+EARLY_GATE = {'split_bf16': (5e-3, 4e-2), 'split_fwd': (1e-2, 1e-1), 'bf16': (3e-2, 2e-1)}
+
+
+@pytest.mark.parametrize('mode', ['rgbonly', 'mse', 'l1', 'kl'])
+def test_training_trajectory_psnr_against_reference(mode):
+    """VERDICT r03 item 3.  The imported reference trained 200 steps on the config-1 scene (tests/golden/trajectory.npz): rgb-only
+    and with each depth term of the BASELINE configs (gt + mse, stereo_crop + l1, mono_crop + kl); the HIP trainer replays the
+    same batches and uniforms in every precision mode.
+    Gates, all modes: the logged rgb loss follows the reference's over the first 100 steps (EARLY_GATE).
+    rgb-only and gt + mse: every precision ends within max(0.05 dB, 2 x the reference's own float64-float32 spread) of the
+    float32 reference in render PSNR and in the mean in-loop PSNR of the last 25 steps (north_star's PSNR clause).
+    stereo_crop + l1 and mono_crop + kl: at step 200 these runs are in the steep part of training (25 -> 35 dB between steps 200
+    and 1000) and a perturbation of the gradients moves the PSNR AT A FIXED STEP by +-1-2 dB in either direction
+    (tools/probes/traj_seeds.py, profiles/r04_traj_seeds.md: five seeds, sign of the gap varies, gone by step 1000).  Pinned
+    there: split-bf16 (the mode that reproduces the reference's arithmetic to 1e-5) in the in-loop PSNR of the last 25 steps;
+    the bf16-gradient modes are gated statistically over seeds in test_bf16_gradient_modes_match_split_bf16_over_seeds."""
     import trajectory_common as TC
     g = np.load(os.path.join(GOLD, 'trajectory.npz'))
     ref_psnr = float(g[mode + '.f32.render_psnr'])
@@ -145,24 +168,60 @@ def test_training_trajectory_psnr_against_reference(mode):
         report[name] = {'render_psnr': ps, 'render_gap_db': ps - ref_psnr, 'tail_inloop_psnr_L1': tail,
                         'tail_gap_db': tail - ref_tail,
                         'logged_rgb_mse_rel_dev_max': float(np.max(np.abs(logged[:, 1] / g[mode + '.f32.rgb1'] - 1.0))),
+                        'logged_rgb_mse_rel_dev': [float(x) for x in np.abs(logged[:, 1] / g[mode + '.f32.rgb1'] - 1.0)],
+                        'logged_rgb0_mse_rel_dev': [float(x) for x in np.abs(logged[:, 0] / g[mode + '.f32.rgb0'] - 1.0)],
                         'image_rms_vs_reference': float(np.sqrt(np.mean((im.reshape(-1, 3) - g[mode + '.f32.render_rgb']) ** 2)))}
-    # Gate.  rgb-only: the reference's float32 and float64 runs agree to 0.005 dB, and every precision mode must end within
-    # 0.05 dB of the float32 reference (north_star's PSNR clause).  With the depth term the 200-step trajectory is chaotic at the
-    # 0.1 dB level -- the reference's own float64 run ends 0.10 dB from its float32 run -- so there the tolerance is 2 x that
-    # spread: nothing can be pinned to the float32 run tighter than the reference pins itself.
+    # With a depth term the 200-step trajectory is chaotic at the 0.1 dB level even for the reference -- its own float64 run
+    # ends 0.09-0.14 dB from its float32 run -- so the tolerance is 2 x that spread: nothing can be pinned to the float32 run
+    # tighter than the reference pins itself.
     f64_tail = float(np.mean(TC.psnr(g[mode + '.f64.tail_rgb_mse'][:, 1])))
+    steep = mode in ('l1', 'kl')
     tol_r = max(0.05, 2.0 * f64_gap)
-    tol_t = max(0.05, 2.0 * abs(f64_tail - ref_tail))
+    tol_t = max(0.1 if steep else 0.05, 2.0 * abs(f64_tail - ref_tail))
     report['gate'] = {'render_tolerance_db': tol_r, 'tail_tolerance_db': tol_t, 'reference_f64_gap_db': f64_gap,
-                      'reference_f64_tail_gap_db': f64_tail - ref_tail}
-    out = os.path.join(os.path.dirname(HERE), 'gpurun_out')
-    if os.path.isdir(out):
-        with open(os.path.join(out, 'trajectory_%s.json' % mode), 'w') as f:
-            json.dump(report, f, indent=1)
-    print(json.dumps(report))
+                      'reference_f64_tail_gap_db': f64_tail - ref_tail, 'early': EARLY_GATE,
+                      'psnr_gated': ['split_bf16 (tail)'] if steep else ['split_bf16', 'split_fwd', 'bf16']}
+    _dump('trajectory_%s.json' % mode, report)
     for name in ('split_bf16', 'split_fwd', 'bf16'):
+        dev_log = report[name]['logged_rgb_mse_rel_dev']
+        assert dev_log[0] <= EARLY_GATE[name][0] and max(dev_log[:4]) <= EARLY_GATE[name][1], (name, dev_log)
+        if steep:
+            continue
         assert abs(report[name]['render_gap_db']) <= tol_r, (name, report[name], tol_r)
         assert abs(report[name]['tail_gap_db']) <= tol_t, (name, report[name], tol_t)
+    if steep:
+        assert abs(report['split_bf16']['tail_gap_db']) <= tol_t, (report['split_bf16'], tol_t)
+
+
+@pytest.mark.parametrize('mode', ['l1', 'kl'])
+def test_bf16_gradient_modes_match_split_bf16_over_seeds(mode):
+    """The PSNR clause of north_star for the bf16-gradient modes (split_fwd = the CLI default, bf16 = the bench headline) with
+    the depth terms whose single trajectories cannot be pinned at step 200 (see above): 8 seeds of batches / uniforms, 1000
+    steps each, every precision on identical inputs, split-bf16 standing in for the reference (it is pinned to the reference
+    on seed 0).  Gate: the MEDIAN over seeds of the paired gap of the in-loop PSNR (mean of the last 25 steps) is within
+    0.25 dB -- the paired gaps scatter with sigma 0.07-0.26 dB at 1000 steps, so this is what 8 seeds can resolve; the 0.05 dB
+    of north_star is below the run-to-run spread of the reference itself on this scene (float64 vs float32: 0.09-0.14 dB)."""
+    import trajectory_common as TC
+    from outdoor_nerf_depth_amd import _lib as L
+    n_steps, n_seeds = 1000, 8
+    rows = []
+    for seed in range(n_seeds):
+        r = {}
+        for name, prec in (('split_bf16', L.PREC_SPLIT_BF16), ('split_fwd', L.PREC_SPLIT_FWD), ('bf16', L.PREC_BF16)):
+            rgb_mse, _, _, ps = _trajectory(prec, mode, n_steps=n_steps, seed=seed)
+            r[name] = (ps, float(np.mean(TC.psnr(rgb_mse[-TC.LOG_EVERY:, 1]))))
+        rows.append(r)
+    report = {'mode': mode, 'steps': n_steps, 'runs': rows}
+    for name in ('split_fwd', 'bf16'):
+        tail = np.array([r[name][1] - r['split_bf16'][1] for r in rows])
+        rend = np.array([r[name][0] - r['split_bf16'][0] for r in rows])
+        report[name] = {'tail_gap_db': tail.tolist(), 'tail_gap_db_median': float(np.median(tail)), 'tail_gap_db_mean': float(tail.mean()),
+                        'tail_gap_db_std': float(tail.std(ddof=1)), 'render_gap_db': rend.tolist(),
+                        'render_gap_db_median': float(np.median(rend)), 'render_gap_db_mean': float(rend.mean()),
+                        'render_gap_db_std': float(rend.std(ddof=1))}
+    _dump('trajectory_seeds_%s.json' % mode, report)
+    for name in ('split_fwd', 'bf16'):
+        assert abs(report[name]['tail_gap_db_median']) <= 0.25, (name, report[name])
 
 
 # ------------------------------------------------------------------------------------------- pixel draw of the ray-batch sampler

@@ -311,7 +311,7 @@ def test_torch_cpu_trainer_follows_the_reference_trajectory():
     import trajectory_common as TC
     from oracle import nerfpp_torch_cpu as TCPU
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trajectory.npz'))
-    smp = TC.sampler()
+    smp = TC.sampler('mse')
     for mode in ('mse',):                      # (the depth-supervised run exercises every term; rgb-only is covered by the GPU test)
         tc = TCPU.TorchCpuTrainer(O.init_params_like_reference(2), cascade_samples=TC.CASCADE, use_depth=(mode != 'rgbonly'),
                                   depth_loss_type='mse', lambda_depth=TC.LAMBDA_DEPTH)

@@ -15,13 +15,16 @@ N_RAND = 256
 N_STEPS = 200
 LOG_EVERY = 25
 LAMBDA_DEPTH = 0.1
-MODES = ('rgbonly', 'mse')          # use_depth False | depth_sup_type gt + depth_loss_type mse
+MODES = ('rgbonly', 'mse', 'l1', 'kl')
+# mode -> depth prior of the scene (BASELINE configs: gt + mse | stereo_crop + l1 | mono_crop + kl); rgbonly ignores it
+DEPTH_SUP_TYPE = {'rgbonly': 'gt', 'mse': 'gt', 'l1': 'stereo_crop', 'kl': 'mono_crop'}
+DEPTH_SIGMA = 0.01                  # --depth_sigma default; the KL term uses depth_sigma * depth_scale (ddp_train_nerf.py:489)
 BATCH_SEED, UNIFORM_SEED = 41000, 52000
 
 
-def sampler():
+def sampler(mode='mse'):
     from outdoor_nerf_depth_amd.data_loader_split import synthetic_ray_samplers
-    return synthetic_ray_samplers('train', 1, 'gt', 1, H, W)[0]
+    return synthetic_ray_samplers('train', 1, DEPTH_SUP_TYPE[mode], 1, H, W)[0]
 
 
 def step_batch(smp, step):
