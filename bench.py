@@ -51,7 +51,8 @@ FLOP_PER_RAY_STEP = 1.797e9      # 256 fg+bg sample pairs x 3 510 5
 SURVEY_ALGO_BYTES_PER_RAY = 18.8e3   # inputs + outputs + amortised weights/grads at N_rand = 1024
 # algorithmic bytes per sample row read by the weight-gradient GEMMs (every operand once per job):
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
-DW_BYTES_PER_ROW = (4960 + 5024) * 2
+EXEC_OVER_ALGO = {'mlp_fwd': 1.0 - 2 * 65536.0 / (593408 + 604160), 'mlp_bwd': 1.0 - 2 * 65536.0 / (2 * 557696), 'dw': 1.0}
+DW_BYTES_PER_ROW = (4576 + 4640) * 2        # columns the jobs of nerfpp_common.h: build_all_jobs read per row (fg + bg), bf16
 FLOP_PER_RAY_RENDER = 0.613e9    # forward only, both levels
 SETUP_STEPS = 12                 # untimed steps run when a trainer is set up, before the W warm-up steps (see run_mode)
 # HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16: PARSED at start-up from the rocprofv3 --pmc passes committed
@@ -301,6 +302,9 @@ def roofline(r):
                            'traffic_over_survey_algorithmic_bytes':
                                (step_traffic / (SURVEY_ALGO_BYTES_PER_RAY * 1024) if step_traffic else None)},
             'all_kernels': allk, 'share_ms_per_step': {k: round(v, 4) for k, v in r['share_ms'].items()},
+            # FLOP above are the REFERENCE's dense-layer counts.  The kernels execute fewer: the remap layer
+            # (no activation, nerf_network.py:131) is folded into the colour head (csrc/nerfpp_common.h, forward stages)
+            'executed_over_algorithmic_macs': {k: round(v, 4) for k, v in EXEC_OVER_ALGO.items()},
             'hbm_view_of_dw': {'bound': 'hbm', 'achieved': dw['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                'frac': dw['gbs'] / PEAK_HBM_GBS, 'operand_bytes_per_row': DW_BYTES_PER_ROW,
                                'traffic': PMC_TRAFFIC['dw_L1'] if r['pmc_ok'] else None}}

@@ -50,7 +50,7 @@ TblLayout tbl_layout() {
 }
 
 // ---- packed buffer layout (bytes) ---------------------------------------------------------------
-struct PackLayout { size_t fwd[2], bwd[2], bias[2], total; };
+struct PackLayout { size_t fwd[2], bwd[2], bias[2], derived[2], total; };
 PackLayout pack_layout(int P) {
   PackLayout L{};
   size_t off = 0;
@@ -58,6 +58,7 @@ PackLayout pack_layout(int P) {
     L.fwd[net] = off; off = align_up(off + fwd_stream_bytes(net, P), 256);
     L.bwd[net] = off; off = align_up(off + bwd_stream_bytes(P), 256);
     L.bias[net] = off; off = align_up(off + FWD_BIAS_FLOATS * sizeof(float), 256);
+    L.derived[net] = off; off = align_up(off + DERIVED_FLOATS * sizeof(float), 256);     // [Wc | bc] in float32 (scratch of the pack)
   }
   L.total = off;
   return L;
@@ -270,7 +271,8 @@ int nerfpp_pack_level(void* stream, int precision, const float* params, const in
     tbl[3 * net + 1] = tables + T.bwd[net];  outs[3 * net + 1] = out + L.bwd[net];  n[3 * net + 1] = (int64_t)BWD_FRAGS * 512;
     tbl[3 * net + 2] = tables + T.bias[net]; outs[3 * net + 2] = out + L.bias[net]; n[3 * net + 2] = FWD_BIAS_FLOATS;
   }
-  launch_pack_level(st, params, precision, tbl, outs, n);
+  float* derived[N_NET] = {(float*)(out + L.derived[0]), (float*)(out + L.derived[1])};
+  launch_pack_level(st, params, precision, tbl, outs, n, derived);
   return check_launch("pack_level");
 }
 

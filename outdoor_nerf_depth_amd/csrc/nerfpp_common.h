@@ -64,12 +64,21 @@ constexpr int LEVEL_PARAMS = FG_PARAMS + BG_PARAMS;   // 1 202 440
 static_assert(FG_PARAMS == 595844 && BG_PARAMS == 606596, "reference parameter count");
 
 // ---- forward stages ---------------------------------------------------------------------------
+// The remap layer (nerf_network.py:131, no activation) is FOLDED into the colour head in the MLP kernels: with
+//   Wc = Wrgb0[:, :256] * Wremap  (128 x 256),   bc = brgb0 + Wrgb0[:, :256] * bremap
+// G_pre = Wc h7 + Wrgb0[:, 256:] dirs + bc, and dH7 = Wc^T dG + wsigma dsigma -- one 256 x 256 GEMM per sample less in the
+// forward and one in the dX chain.  Wc / bc are derived parameters, recomputed from the float32 masters at every re-pack
+// (fold_remap_kernel); their gradients dWc = dG^T H7 = M and dbc = sum dG are what the weight-gradient GEMMs produce, and
+// remap_fixup_kernel turns them into the gradients of the reference's parameters (exact chain rule: nerfpp_optim.hip).
+// FS_REMAP keeps its place in the enumerations (bias slots, gradient slab) with zero weight fragments.
 enum FwdStage { FS_L0 = 0, FS_L5 = 5, FS_REMAP = 8, FS_SIG = 9, FS_RGB0 = 10, FS_RGB1 = 11, FS_COUNT = 12 };
 __host__ __device__ constexpr int fs_nob(int s) { return s <= FS_REMAP ? 8 : s == FS_RGB0 ? 4 : 1; }
 __host__ __device__ constexpr int fs_nkc(int net, int s) {
-  return s == FS_L0 ? kpe(net) : s == FS_L5 ? kpe(net) + 16 : s <= FS_REMAP ? 16
+  return s == FS_L0 ? kpe(net) : s == FS_L5 ? kpe(net) + 16 : s == FS_REMAP ? 0 : s < FS_REMAP ? 16
        : s == FS_SIG ? 16 : s == FS_RGB0 ? 20 : 16;
 }
+constexpr int DERIVED_WC = 128 * 256;               // derived parameters of one net: [Wc | bc], addressed in the pack tables
+constexpr int DERIVED_FLOATS = DERIVED_WC + 128;    // as net_params(net) + index
 __host__ __device__ constexpr int fs_frags(int net, int s) { return fs_nob(s) * fs_nkc(net, s); }
 __host__ __device__ constexpr int fs_frag_off(int net, int s) {
   int off = 0;
@@ -86,11 +95,11 @@ constexpr int FWD_BIAS_FLOATS = fs_bias_off(FS_COUNT);
 static_assert(fwd_frags(0) % BLK_FRAGS == 0 && fwd_frags(1) % BLK_FRAGS == 0, "block aligned");
 
 // ---- backward (dX chain) stages -----------------------------------------------------------------
-// B0: dG = Wrgb1^T dP | B1: dR = Wrgb0[:, :256]^T dG | B2: dH7 = Wremap^T dR + wsig dsig |
+// B0: dG = Wrgb1^T dP | B1: (dR: folded away, no fragments) | B2: dH7 = Wc^T dG + wsig dsig (8 dG chunks + 2 for dsig) |
 // B3..B9: dH_{l-1} = W_l^T dZ_l for l = 7..1 (l = 5 uses only the hidden-input columns)
 enum BwdStage { BS_DG = 0, BS_DR = 1, BS_DH7 = 2, BS_COUNT = 10 };
 __host__ __device__ constexpr int bs_nob(int s) { return s == BS_DG ? 4 : 8; }
-__host__ __device__ constexpr int bs_nkc(int s) { return s == BS_DG ? 4 : s == BS_DR ? 8 : s == BS_DH7 ? 18 : 16; }
+__host__ __device__ constexpr int bs_nkc(int s) { return s == BS_DG ? 4 : s == BS_DR ? 0 : s == BS_DH7 ? 10 : 16; }
 __host__ __device__ constexpr int bs_frags(int s) { return bs_nob(s) * bs_nkc(s); }
 __host__ __device__ constexpr int bs_frag_off(int s) {
   int off = 0;

@@ -90,8 +90,9 @@ void launch_mlp_bwd_pair(hipStream_t st, int P, const nerfpp::MlpBwdArgs& a_fg, 
 // nerfpp_dw.hip
 void launch_dw(hipStream_t st, int P, const nerfpp::DwArgs& a);
 // nerfpp_optim.hip
+// derived[net]: DERIVED_FLOATS floats of scratch for the net's folded colour-head parameters (filled here, then packed)
 void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t* const* tbl, void* const* out,
-                       const int64_t* n);
+                       const int64_t* n, float* const* derived);
 void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats,
                          const nerfpp::DwPlan& plan, const int32_t* const* tbl, float* const* m_out, float scale,
                          float* grads_lvl);

@@ -426,6 +426,15 @@ __device__ __forceinline__ void handoff_flush_chunks(const char* region, int lan
       store_nt16(frag_addr(base + p * plane, ld, row0, c, lane), *(const uint4*)(region + ((c * P + p) * 64 + lane) * 16));
 }
 
+// region chunk cr -> tensor chunk ct (a hand-off that carries the chunks of two tensors back to back)
+template <int P>
+__device__ __forceinline__ void handoff_flush_one(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int cr, int ct) {
+  if constexpr ((probe::DBG & 16) != 0) return;
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    store_nt16(frag_addr(base + p * plane, ld, row0, ct, lane), *(const uint4*)(region + ((cr * P + p) * 64 + lane) * 16));
+}
+
 // dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
 template <int NOB, int P>
 __device__ __forceinline__ void mask_to_frags(const f32x16 (&acc)[NOB], const uint4 bits, Frag<P> (&dz)[2 * NOB]) {
@@ -656,16 +665,18 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
       save_frags<16, P>(base, plane_rows * 256, 256, wrow0, lane, frags);
     }
   };
-  auto psave_h = [&](int blk, const Frag<P> (&frags)[16], __bf16* base, int mask_stage) __attribute__((always_inline)) {
+  // (cpb_c: chunks per block of the storers; the colour head that consumes h7 has 5 / 10 blocks, not 8 / 16)
+  auto psave_hc = [&](int blk, const Frag<P> (&frags)[16], __bf16* base, int mask_stage, auto cpb_c) __attribute__((always_inline)) {
+    constexpr int CPBH = decltype(cpb_c)::value;
     if constexpr (TRAIN && ROLES) {
       if (loader) {
         if (blk == 0) handoff_write<16, P>(region, lane, frags);
       } else {
         if constexpr ((probe::DBG & 2) == 0) {
-          if (blk * CPB < 16) {
+          if (blk * CPBH < 16) {
 #pragma unroll
-            for (int i = 0; i < CPB; ++i)
-              store_chunk<P>(base, plane_rows * 256, 256, wrow0, lane, CPB * blk + i, frags[CPB * blk + i]);
+            for (int i = 0; i < CPBH; ++i)
+              store_chunk<P>(base, plane_rows * 256, 256, wrow0, lane, CPBH * blk + i, frags[CPBH * blk + i]);
           }
         }
         if constexpr (P == 1) {
@@ -678,6 +689,9 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
           mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
       }
     }
+  };
+  auto psave_h = [&](int blk, const Frag<P> (&frags)[16], __bf16* base, int mask_stage) __attribute__((always_inline)) {
+    psave_hc(blk, frags, base, mask_stage, std::integral_constant<int, CPB>{});
   };
   // save one tensor of this stage: storer waves write their own tile, the loader hands its tile over
   auto save = [&](auto nch_c, __bf16* base, int ld, auto& frags, bool has_mask, uint4 bits, int mask_stage) __attribute__((always_inline)) {
@@ -697,20 +711,53 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
       save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags);
     }
   };
-  const uint4 nobits = make_uint4(0, 0, 0, 0);
 
   float x[4], vd[3], depth_real;
   sample_point<NET>(a.geom, row, a.S, x, vd, &depth_real);
   Frag<P> pe[KPE];
   encode_point<NET, P>(x, hi, pe);
-  save(std::integral_constant<int, KPE>{}, a.ws.t[T_X], kpew(NET), pe, false, nobits, 0);
+  if constexpr (TRAIN) {
+    // The encoded point and the encoded view direction are saved together: storers write both tensors, the loader hands
+    // its KPE + 2 chunks over in one piece and the helper waves write them out in L0's first block (flush_xd).  (The view
+    // direction used to go out next to the colour head, in the slot of the hand-off region that h7 needs there now.)
+    Frag<P> df0[2];
+    encode_dir<P>(vd, hi, df0);
+    if (tail) { zero_invalid(pe, valid); zero_invalid(df0, valid); }
+    bool direct = true;
+    if constexpr (ROLES) {
+      if (loader) {
+        Frag<P> xd[KPE + 2];
+#pragma unroll
+        for (int c = 0; c < KPE; ++c) xd[c] = pe[c];
+        xd[KPE] = df0[0]; xd[KPE + 1] = df0[1];
+        handoff_write<KPE + 2, P>(region, lane, xd);
+        direct = false;
+      }
+    }
+    if (direct) {
+      save_frags<KPE, P>(a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), wrow0, lane, pe);
+      save_frags<2, P>(a.ws.t[T_DIRX], plane_rows * 32, 32, wrow0, lane, df0);
+    }
+  }
+  auto flush_xd = [&](int blk) __attribute__((always_inline)) {
+    if constexpr (TRAIN && ROLES) {
+      if (blk == 0 && wave >= 1 && wave <= H) {
+#pragma unroll
+        for (int c = 0; c < KPE + 2; ++c)
+          if ((c % H) == wave - 1) {
+            if (c < KPE) handoff_flush_one<P>(region, lane, a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), tile_row0, c, c);
+            else handoff_flush_one<P>(region, lane, a.ws.t[T_DIRX], plane_rows * 32, 32, tile_row0, c, c - KPE);
+          }
+      }
+    }
+  };
   stash_frags<KPE, P>(pe_stash, lane, pe);
 
   f32x16 acc[8];
   Frag<P> h[16];
   // L0
   bias_init8(acc, fs_bias_off(FS_L0));
-  stage_gemm<8, KPE, P>(pipe, acc, pe, HOOK(flush(blk, IC(KPE), a.ws.t[T_X], kpew(NET), -1)));
+  stage_gemm<8, KPE, P>(pipe, acc, pe, HOOK(flush_xd(blk)));
   {
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     finish_h(a.ws.t[T_H0], h, bits, 0);
@@ -745,29 +792,25 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
     const uint4 bits = acc_to_frags_relu_bits<8, P>(acc, h);
     finish_h(TRAIN ? a.ws.t[T_H0 + l] : nullptr, h, bits, l);
   }
-  // remap (no activation) and sigma, both from h7                       nerf_network.py:131-136
-  // (R is not saved: the weight gradients that need it are derived from M = dG^T H7, nerfpp_optim.hip)
-  Frag<P> rm[16];
-  bias_init8(acc, fs_bias_off(FS_REMAP));
-  stage_gemm<8, 16, P>(pipe, acc, h, HOOK(psave_h(blk, h, a.ws.t[T_H0 + 7], 7)));
-  acc_to_frags<8, P, ACT_NONE>(acc, rm);
+  // sigma from h7                                                        nerf_network.py:131-136
+  // (the remap layer is folded into the colour head: nerfpp_common.h, forward stages.  R is not a tensor here.)
   f32x16 acc1[1];
   bias_init1(acc1, fs_bias_off(FS_SIG));
   stage_gemm<1, 16, P>(pipe, acc1, h, NoHook{});
   const float sigma_raw = acc1[0][0];
-  // colour head                                                         nerf_network.py:137-138
+  // colour head: relu(Wc h7 + Wrgb0[:, 256:] dirs + bc)                  nerf_network.py:131,137-138
   Frag<P> g[8];
   {
     Frag<P> in[20];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) in[c] = rm[c];
+    for (int c = 0; c < 16; ++c) in[c] = h[c];
     Frag<P> df[2];
     encode_dir<P>(vd, hi, df);
-    save(std::integral_constant<int, 2>{}, a.ws.t[T_DIRX], 32, df, false, nobits, 0);
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
     bias_init4(acc4, fs_bias_off(FS_RGB0));
-    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(flush(blk, IC(2), a.ws.t[T_DIRX], 32, -1)));
+    // h7 goes out under this stage (5 blocks of 16 fragments, 10 of 8 in split-bf16 training): 4 / 2 chunks per block
+    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(psave_hc(blk, h, a.ws.t[T_H0 + 7], 7, IC(P == 1 ? 4 : 2))));
     const uint4 bits = acc_to_frags_relu_bits<4, P>(acc4, g);
     save(std::integral_constant<int, 8>{}, a.ws.t[T_G], 128, g, true, bits, 8);
   }
@@ -906,20 +949,16 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a, const int bid)
   }
   f32x16 acc[8];
   Frag<P> dz[16];
-  // B1: dR = Wrgb0[:, :256]^T dG  (no activation on the remap layer; dR is not saved, see nerfpp_optim.hip)
-  init_zero<8>(acc);
-  // (the barrier just passed ends every wave's use of sign words 8: their slot takes words 6)
-  stage_gemm<8, 8, P>(pipe, acc, dg, HOOK(psave(blk, IC(8), dg, a.ws.t[T_DG], DSG_LD); if (blk == 0) issue_masks(6)));
-  acc_to_frags<8, P, ACT_NONE>(acc, dz);
-  // B2: dH7 = Wremap^T dR + wsigma * dsigma, masked by H7 > 0
+  // B2: dH7 = Wc^T dG + wsigma * dsigma, masked by H7 > 0  (B1, dR = Wrgb0[:, :256]^T dG, is folded into Wc: nerfpp_common.h)
   {
-    Frag<P> in[18];
+    Frag<P> in[10];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) in[c] = dz[c];
-    in[16] = zero_frag<P>(); in[17] = zero_frag<P>();
-    if (hi == 0) set_slot<P>(in[16], 0, d.w);
+    for (int c = 0; c < 8; ++c) in[c] = dg[c];
+    in[8] = zero_frag<P>(); in[9] = zero_frag<P>();
+    if (hi == 0) set_slot<P>(in[8], 0, d.w);
     init_zero<8>(acc);
-    stage_gemm<8, 18, P>(pipe, acc, in, NoHook{});
+    // (the barrier just passed ends every wave's use of sign words 8: their slot takes words 6)
+    stage_gemm<8, 10, P>(pipe, acc, in, HOOK(psave(blk, IC(8), dg, a.ws.t[T_DG], DSG_LD); if (blk == 0) issue_masks(6)));
     mask_to_frags<8, P>(acc, get_mask(7), dz);
     save(std::integral_constant<int, 16>{}, a.ws.t[T_DZ0 + 7], 256, dz);
   }

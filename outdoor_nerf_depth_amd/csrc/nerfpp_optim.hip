@@ -18,8 +18,31 @@ struct PackSegs {
   void* out[N];
   int64_t n[N];
   int pbase[N];                   // offset of the net's parameters in the level's flat buffer
+  int np[N];                      // parameters of the net: table entries >= np address its derived parameters
+  const float* derived[N];        // [Wc | bc] of the net (fold_remap_kernel)
   int is_f32[N];
 };
+// Wc = Wrgb0[:, :256] * Wremap, bc = brgb0 + Wrgb0[:, :256] * bremap (nerfpp_common.h, forward stages): float32, fixed order.
+// thread = (net, o, f): Wrgb0[o][j] is a broadcast, Wremap[j][f] coalesced over f.
+__global__ void fold_remap_kernel(const float* __restrict__ params_lvl, float* __restrict__ d0, float* __restrict__ d1) {
+  const int net = blockIdx.y;
+  const float* params = params_lvl + (net ? FG_PARAMS : 0);
+  float* out = net ? d1 : d0;
+  const int w_g = ref_w_off(net, RT_RGB0), b_g = ref_b_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);
+  const int w_r = ref_w_off(net, RT_REMAP), b_r = ref_b_off(net, RT_REMAP);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < DERIVED_WC) {
+    const int o = t >> 8, f = t & 255;
+    float acc = 0.f;
+    for (int j = 0; j < 256; ++j) acc += params[w_g + o * ldg + j] * params[w_r + j * 256 + f];
+    out[t] = acc;
+  } else if (t < DERIVED_FLOATS) {
+    const int o = t - DERIVED_WC;
+    float acc = params[b_g + o];
+    for (int j = 0; j < 256; ++j) acc += params[w_g + o * ldg + j] * params[b_r + j];
+    out[t] = acc;
+  }
+}
 template <int P>
 __global__ void pack_level_kernel(const float* __restrict__ params, PackSegs sg) {
   int seg = 0;
@@ -29,7 +52,7 @@ __global__ void pack_level_kernel(const float* __restrict__ params, PackSegs sg)
   const int64_t e = (int64_t)((int)blockIdx.x - blk0) * blockDim.x + threadIdx.x;
   if (e >= sg.n[seg]) return;
   const int32_t src = sg.tbl[seg][e];
-  const float v = src >= 0 ? params[sg.pbase[seg] + src] : 0.f;
+  const float v = src < 0 ? 0.f : src < sg.np[seg] ? params[sg.pbase[seg] + src] : sg.derived[seg][src - sg.np[seg]];
   if (sg.is_f32[seg]) {
     ((float*)sg.out[seg])[e] = v;
     return;
@@ -163,7 +186,8 @@ void launch_remap_fixup(hipStream_t st, float* grads_lvl, const float* params_lv
 
 // segs: per net {fwd stream, bwd stream, bias}; tables / outs / sizes in that order
 void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t* const* tbl, void* const* out,
-                       const int64_t* n) {
+                       const int64_t* n, float* const* derived) {
+  hipLaunchKernelGGL(fold_remap_kernel, dim3((DERIVED_FLOATS + 255) / 256, N_NET), dim3(256), 0, st, params, derived[0], derived[1]);
   PackSegs sg{};
   int blk = 0;
   for (int k = 0; k < PackSegs::N; ++k) {
@@ -173,6 +197,8 @@ void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t
     sg.out[k] = out[k];
     sg.n[k] = n[k];
     sg.pbase[k] = (k / 3) == 0 ? 0 : FG_PARAMS;
+    sg.np[k] = net_params(k / 3);
+    sg.derived[k] = derived[k / 3];
     sg.is_f32[k] = (k % 3) == 2;
   }
   if (P == 1) hipLaunchKernelGGL(pack_level_kernel<1>, dim3(blk), dim3(256), 0, st, params, sg);

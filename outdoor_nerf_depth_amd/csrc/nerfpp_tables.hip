@@ -38,6 +38,13 @@ int fwd_weff_ref(int net, int s, int o, int f) {
   return (o < 3 && f < 128) ? ref_w_off(net, RT_RGB1) + o * 128 + f : -1;
 }
 
+// what the PACKED forward stream holds at W_eff[o][f] of stage s: the reference parameter, or -- the h7 columns of the
+// colour head -- the derived Wc (index net_params(net) + o * 256 + f, nerfpp_common.h)
+int fwd_wsrc(int net, int s, int o, int f) {
+  if (s == FS_RGB0 && o < 128 && f < 256) return net_params(net) + o * 256 + f;
+  return fwd_weff_ref(net, s, o, f);
+}
+
 int fwd_beff_ref(int net, int s, int o) {
   if (s < 8) return ref_b_off(net, s) + o;
   if (s == FS_REMAP) return ref_b_off(net, RT_REMAP) + o;
@@ -46,13 +53,19 @@ int fwd_beff_ref(int net, int s, int o) {
   return o < 3 ? ref_b_off(net, RT_RGB1) + o : -1;
 }
 
+int fwd_bsrc(int net, int s, int o) {
+  if (s == FS_RGB0 && o < 128) return net_params(net) + DERIVED_WC + o;       // bc
+  if (s == FS_REMAP) return -1;                                               // (folded into bc; the slots stay, zero)
+  return fwd_beff_ref(net, s, o);
+}
+
 // backward stage s: Wt_eff[o][f] = d(stage input f) / d(stage output o) weight
 int bwd_weff_ref(int net, int s, int o, int f) {
   if (s == BS_DG) return (o < 128 && f < 3) ? ref_w_off(net, RT_RGB1) + f * 128 + o : -1;
-  if (s == BS_DR) return f < 128 ? ref_w_off(net, RT_RGB0) + f * ref_in(net, RT_RGB0) + o : -1;
+  if (s == BS_DR) return -1;                                                  // (folded: no fragments)
   if (s == BS_DH7) {
-    if (f < 256) return ref_w_off(net, RT_REMAP) + f * 256 + o;
-    if (f == 256) return ref_w_off(net, RT_SIGMA) + o;
+    if (f < 128) return net_params(net) + f * 256 + o;                        // Wc[f][o] (derived)
+    if (f == 128) return ref_w_off(net, RT_SIGMA) + o;
     return -1;
   }
   const int l = bs_layer(s);
@@ -87,12 +100,12 @@ int nerfpp_build_tables(int net, int32_t* fwd_tbl, int32_t* bias_tbl, int32_t* b
         const int64_t F = fs_frag_off(net, s) + kc * nob + ob;
         for (int l = 0; l < 64; ++l)
           for (int t = 0; t < 8; ++t)
-            fwd_tbl[F * 512 + l * 8 + t] = fwd_weff_ref(net, s, ob * 32 + (l & 31), kslot(kc, l >> 5, t));
+            fwd_tbl[F * 512 + l * 8 + t] = fwd_wsrc(net, s, ob * 32 + (l & 31), kslot(kc, l >> 5, t));
       }
     for (int ob = 0; ob < nob; ++ob)
       for (int hi = 0; hi < 2; ++hi)
         for (int r = 0; r < 16; ++r)
-          bias_tbl[fs_bias_off(s) + ob * 32 + hi * 16 + r] = fwd_beff_ref(net, s, dfeat(ob, hi, r));
+          bias_tbl[fs_bias_off(s) + ob * 32 + hi * 16 + r] = fwd_bsrc(net, s, dfeat(ob, hi, r));
   }
   for (int s = 0; s < BS_COUNT; ++s) {
     const int nob = bs_nob(s), nkc = bs_nkc(s);

@@ -14,6 +14,8 @@ from . import _lib as L
 from . import ops
 from .model import init_level_params
 
+# (what the reference computes.  The MLP kernels execute 65 536 fewer per net in the forward and in the dX chain: the remap layer
+# is folded into the colour head, csrc/nerfpp_common.h.)
 ALGO_MACS = {            # dense MACs per sample (SURVEY.md 8a / BASELINE.md section 2)
     'fwd': (593408, 604160),         # fg, bg forward (= weight-gradient MACs)
     'dx': (557696, 557696),          # backward dX chain (no dX for L0, raw-input part of L5, dirs)
@@ -251,7 +253,9 @@ class NerfppTrainer(object):
                 # Level 1 needs level 0's FORWARD only (its weights, detached: ddp_train_nerf.py:452-457): level 0's backward, weight
                 # gradients and update run on their own stream under level 1's sampling and forward (HBM-bound weight gradients
                 # next to the forward kernels).  Measured: -1.1 % per step; the last level's backward under the NEXT step's
-                # level 0 as well: no further gain (+-0.5 %).  _update_end(m) / flush() order later readers.  A step that carries
+                # level 0 as well: no further gain (+-0.5 %); level 0's loss head + compositing backward moved to that stream too (25 us off
+                # the path to level 1's forward): 2.331 vs 2.328 ms in one process (round 4) -- the step is bound by the sum of
+                # the work, not by this chain.  _update_end(m) / flush() order later readers.  A step that carries
                 # event taps runs inline, so that a tap times its kernel group alone on the GPU.
                 stream = self.level_streams[m]
                 fwd_done = torch.cuda.Event()

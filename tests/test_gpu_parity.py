@@ -256,7 +256,10 @@ def test_level_gradients_match_reference(ops, golden, levels, mode, prec):
             l2_tol = GRAD_TOL[prec][1] * (3 if mine.size <= 3 else 1)
             assert rel_l2 <= l2_tol or err <= 1e-3, (k, m, rel_l2)
             n_mine = np.linalg.norm(grads[k].astype(np.float64))
-            assert abs(n_mine - g['L%d.%s.norm64' % (m, k)]) <= (0.06 if prec == 2 else 0.3) * g['L%d.%s.norm64' % (m, k)] + 1e-12, k
+            # (the norm of a 1- or 3-element tensor IS its single cancelling sums: the same 3x as above.  bg sigma bias,
+            # bf16: 2.7e-6 before the remap layer was folded into the colour head, 1.3e-6 after, 2.9e-6 in float64)
+            n_tol = (0.06 if prec == 2 else 0.3) * (3 if mine.size <= 3 else 1)
+            assert abs(n_mine - g['L%d.%s.norm64' % (m, k)]) <= n_tol * g['L%d.%s.norm64' % (m, k)] + 1e-12, k
 
 
 def test_backward_matches_oracle_elementwise(ops, golden, levels):

@@ -79,10 +79,11 @@ KPE = {0: 4, 1: 6}
 # forward stages: (nob, nkc)
 def fwd_stages(net):
     k = KPE[net]
-    return [(8, k)] + [(8, 16)] * 4 + [(8, k + 16)] + [(8, 16)] * 2 + [(8, 16), (1, 16), (4, 20), (1, 16)]
+    # (stage 8, the remap layer, has no fragments: it is folded into the colour head, stage 10 -- nerfpp_common.h)
+    return [(8, k)] + [(8, 16)] * 4 + [(8, k + 16)] + [(8, 16)] * 2 + [(8, 0), (1, 16), (4, 20), (1, 16)]
 
 
-BWD_STAGES = [(4, 4), (8, 8), (8, 18)] + [(8, 16)] * 7
+BWD_STAGES = [(4, 4), (8, 0), (8, 10)] + [(8, 16)] * 7
 
 
 def frag_matrix(stream_vals, frag0, nob, nkc):
@@ -141,14 +142,34 @@ def test_packed_streams_reproduce_the_oracle_mlp(level0, net):
     fwd_tbl, bias_tbl, bwd_tbl, unpack_tbl, slab_floats = L.build_net_tables(net)
     p = flat_net(level0, net)
     assert p.size == (L.FG_PARAMS, L.BG_PARAMS)[net]
-    gather = lambda tbl: np.where(tbl >= 0, p[np.maximum(tbl, 0)], 0).astype(np.float32)
+    pre = 'fg_net.' if net == 0 else 'bg_net.'
+    pn = {k[len(pre):]: v for k, v in level0.items() if k.startswith(pre)}
+    # derived parameters (table entries >= the net's parameter count): the remap layer folded into the colour head,
+    # Wc = Wrgb0[:, :256] Wremap, bc = brgb0 + Wrgb0[:, :256] bremap (fold_remap_kernel)
+    Wg, bg = pn['rgb_layers.0.weight'].astype(np.float64), pn['rgb_layers.0.bias'].astype(np.float64)
+    Wr, br = pn['base_remap_layers.0.weight'].astype(np.float64), pn['base_remap_layers.0.bias'].astype(np.float64)
+    derived = np.concatenate([(Wg[:, :256] @ Wr).reshape(-1), bg + Wg[:, :256] @ br]).astype(np.float32)
+    assert derived.size == 128 * 256 + 128
+    pd = np.concatenate([p, derived])
+    gather = lambda tbl: np.where(tbl >= 0, pd[np.maximum(tbl, 0)], 0).astype(np.float32)
     fwd, bias, bwd = gather(fwd_tbl), gather(bias_tbl), gather(bwd_tbl)
+    assert max(fwd_tbl.max(), bias_tbl.max(), bwd_tbl.max()) < pd.size
 
-    # every parameter appears in the forward stream + bias stream exactly... at least once
-    seen = np.zeros(p.size, bool)
+    # every parameter appears in the forward stream + bias stream at least once -- except the ones that only enter through
+    # the derived Wc / bc: the remap layer and the h7 columns / bias of rgb_layers.0
+    seen = np.zeros(pd.size, bool)
     seen[fwd_tbl[fwd_tbl >= 0]] = True
     seen[bias_tbl[bias_tbl >= 0]] = True
-    assert seen.all()
+    assert seen[p.size:].all()
+    names, off, folded = O.mlp_param_names(), 0, np.zeros(p.size, bool)
+    for n in names:
+        sz = pn[n].size
+        if n.startswith('base_remap_layers.0') or n == 'rgb_layers.0.bias':
+            folded[off:off + sz] = True
+        elif n == 'rgb_layers.0.weight':
+            folded[off:off + sz] = (np.arange(sz) % pn[n].shape[1]) < 256
+        off += sz
+    assert off == p.size and (seen[:p.size] == ~folded).all()
     assert sorted(set(unpack_tbl.tolist())) == sorted(unpack_tbl.tolist())       # injective
     assert unpack_tbl.min() >= 0 and unpack_tbl.max() < slab_floats
 
@@ -157,8 +178,6 @@ def test_packed_streams_reproduce_the_oracle_mlp(level0, net):
     in_ch = (63, 84)[net]
     x_enc = (rs.rand(R, in_ch).astype(np.float32) * 2 - 1)
     d_enc = (rs.rand(R, 27).astype(np.float32) * 2 - 1)
-    pre = 'fg_net.' if net == 0 else 'bg_net.'
-    pn = {k[len(pre):]: v for k, v in level0.items() if k.startswith(pre)}
     cache = {}
     rgb_ref, sigma_ref = O.mlp_forward(pn, np.concatenate([x_enc, d_enc], 1), in_ch, 27, cache=cache)
 
@@ -179,10 +198,10 @@ def test_packed_streams_reproduce_the_oracle_mlp(level0, net):
     h = relu(np.concatenate([X, h], 1) @ mats[5].T + biases[5]); hs.append(h)
     for l in (6, 7):
         h = relu(h @ mats[l].T + biases[l]); hs.append(h)
-    rm = h @ mats[8].T + biases[8]
+    rm = h @ Wr.T.astype(np.float32) + br.astype(np.float32)      # (only the weight-gradient bookkeeping below uses it)
     sig = (h @ mats[9].T + biases[9])[:, 0]
     pad = lambda a, w: np.concatenate([a, np.zeros((a.shape[0], w - a.shape[1]), np.float32)], 1)
-    g = relu(pad(np.concatenate([rm, Dx], 1), 320) @ mats[10].T + biases[10])
+    g = relu(pad(np.concatenate([h, Dx], 1), 320) @ mats[10].T + biases[10])
     rgb_pre = (pad(g, 256) @ mats[11].T + biases[11])[:, :3]
     np.testing.assert_allclose(np.abs(sig), sigma_ref, rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(1 / (1 + np.exp(-rgb_pre)), rgb_ref, rtol=2e-4, atol=1e-5)
@@ -200,9 +219,9 @@ def test_packed_streams_reproduce_the_oracle_mlp(level0, net):
         bm.append(frag_matrix(bwd, f0, nob, nkc)); f0 += nob * nkc
     dPp = pad(dP, 64)
     dG = (dPp @ bm[0].T) * (g > 0)
-    dR = pad(dG, 128) @ bm[1].T
+    dR = dG @ Wg[:, :256].astype(np.float32)                      # (weight-gradient bookkeeping only: the chain skips it)
     dSp = np.zeros((R, 32), np.float32); dSp[:, 0] = dS
-    dH = np.concatenate([dR, dSp], 1) @ bm[2].T
+    dH = np.concatenate([dG, dSp], 1) @ bm[2].T
     dZ = {7: dH * (hs[7] > 0)}
     for s, l in zip(range(3, 10), range(7, 0, -1)):
         dZ[l - 1] = (dZ[l] @ bm[s].T) * (hs[l - 1] > 0)
