@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hip.so')   # override: diagnostic builds
 
 OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2
 PREC_SPLIT_FWD = 3        # host-side combination: split-bf16 forward, bf16 backward (ops.LevelEngine)
 LOSS_RGB_ONLY, LOSS_MSE, LOSS_L1, LOSS_KL = 0, 1, 2, 3

@@ -760,7 +760,7 @@ __global__ void gather_rays_kernel(int n, int W, const float* __restrict__ cam, 
 // rejected against a value which is itself rejected later equals the earlier final value that one collided with).
 // ------------------------------------------------------------------------------------------------
 namespace nerfpp {
-constexpr int PIX_MAX_K = 8192, PIX_THREADS = 1024;
+constexpr int PIX_THREADS = 1024;
 __global__ __launch_bounds__(PIX_THREADS) void sample_pixels_kernel(RngKey rng, uint32_t n, int k, int kp, int64_t* __restrict__ pix) {
   extern __shared__ __attribute__((aligned(16))) char pix_smem[];
   unsigned long long* keys = (unsigned long long*)pix_smem;            // [kp]  (value << 32) | index, padding = ~0
