@@ -45,6 +45,7 @@ constexpr int LDS_PREFETCH = 4;        // weight fragments in flight ahead of th
 constexpr int HOOK_ORDER = 1;          // saves issued after a block's MFMAs by every wave
 constexpr int WAVES_P1 = 8;            // waves per workgroup of the bf16 kernels (256-sample tiles)
 constexpr int LOADER_SLEEP = 0;        // (probes: idle cycles / 64 added to the loader wave per weight block)
+constexpr int LDS_REUSE = 1;           // (probes: MFMAs per weight-fragment read)
 __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   const u32x4_ vv = {v.x, v.y, v.z, v.w};
@@ -217,15 +218,25 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
     if (probe::HOOK_ORDER == 2 || (probe::HOOK_ORDER == 0 && pipe.wave >= 4)) hook(blk);
 #pragma unroll
     for (int kl = 0; kl < KPB; ++kl) {
+      if constexpr (probe::LDS_REUSE > 1 && P == 1) {      // (probes: one weight-fragment read per LDS_REUSE MFMAs -- garbage results)
+        bf16x8 w{};
 #pragma unroll
-      for (int ob = 0; ob < NOB; ++ob)
-        mfma_p<P>(acc[ob], l + (kl * NOB + ob) * P * FRAG_BYTES, b[blk * KPB + kl]);
+        for (int ob = 0; ob < NOB; ++ob) {
+          if (ob % probe::LDS_REUSE == 0) w = *(const bf16x8*)(l + (kl * NOB + ob) * P * FRAG_BYTES);
+          acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b[blk * KPB + kl].v[0], acc[ob], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+          mfma_p<P>(acc[ob], l + (kl * NOB + ob) * P * FRAG_BYTES, b[blk * KPB + kl]);
+      }
     }
     if (probe::HOOK_ORDER == 1 || (probe::HOOK_ORDER == 0 && pipe.wave < 4)) hook(blk);
     if constexpr (P == 1 && probe::LDS_PREFETCH > 0) {
       // shape the block's schedule: LDS_PREFETCH weight fragments in flight ahead of the MFMA
       // that consumes them (LDS latency is ~2-4 MFMA slots; the default schedule keeps only 1-2 ahead)
       constexpr int D = probe::LDS_PREFETCH, N = NOB * KPB;
+      static_assert(probe::LDS_REUSE == 1 || probe::LDS_PREFETCH == 0, "the reuse probe runs on the default schedule");
 #pragma unroll
       for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll

@@ -12,6 +12,8 @@
 //   NERFPP_HOOK_ORDER      0 the two waves of a SIMD save at opposite ends of a block | 1 after the MFMAs | 2 before
 //   NERFPP_LDS_PREFETCH    weight fragments in flight ahead of their MFMA (default 4)
 //   NERFPP_WAVES_P1        waves per workgroup of the bf16 kernels (default 8; 4 = 128-sample tiles)
+//   NERFPP_LDS_REUSE=n     one weight-fragment LDS read per n MFMAs (build with NERFPP_LDS_PREFETCH=0): what would halving the
+//                          LDS reads per MFMA -- 64-row waves -- buy?
 //   NERFPP_LOADER_SLEEP=n  the loader wave idles 64 n cycles per weight block (does added latency cost time, or only cycles?)
 //   NERFPP_STAMPS=k        per-block cycle stamps (s_memtime at arrival at / release from every block barrier, per wave) of
 //                          workgroups 0-3 and 400-403 (fg tiles) of kernel instantiation k (NERFPP_MLP_PART numbering: 2 = bf16
@@ -38,6 +40,9 @@
 #ifndef NERFPP_LOADER_SLEEP
 #define NERFPP_LOADER_SLEEP 0
 #endif
+#ifndef NERFPP_LDS_REUSE
+#define NERFPP_LDS_REUSE 1
+#endif
 
 namespace nerfpp { namespace probe {
 
@@ -56,6 +61,7 @@ constexpr int LDS_PREFETCH = NERFPP_LDS_PREFETCH;
 constexpr int HOOK_ORDER = NERFPP_HOOK_ORDER;
 constexpr int WAVES_P1 = NERFPP_WAVES_P1;
 constexpr int LOADER_SLEEP = NERFPP_LOADER_SLEEP;
+constexpr int LDS_REUSE = NERFPP_LDS_REUSE;       // 2: one weight-fragment read per two MFMAs (what 64-row waves would need); with NERFPP_LDS_PREFETCH=0
 
 #if (NERFPP_DBG & 32)
 __device__ char* dbg_sink;      // timing experiment: every activation store folded into a 2 MiB window of out_raw
