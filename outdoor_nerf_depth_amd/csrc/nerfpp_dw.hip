@@ -19,12 +19,14 @@
 //     1152 B = 32 banks further: conflict-free.  Both operands use the same sample->slot map, so the contraction is
 //     exact whatever that map is.
 //   * 8 waves; full 256x256 jobs: wave (wo = w>>2, wi = w&3) owns out-blocks [4wo, 4wo+4) x in-blocks
-//     [2wi, 2wi+2), 8 accumulators of 32x32 (128 VGPRs); narrow jobs deal their blocks round-robin.
-//     32-row chunks through an LDS ring (inline-asm DMA, counted vmcnt), one raw barrier per chunk.
+//     [2wi, 2wi+2), 8 accumulators of 32x32 (128 VGPRs); every other ("narrow") job shape has its own instantiation
+//     (NarrowShape / narrow_pass below): wave = block index on the longer axis of the output, two input tensors side by
+//     side where jobs share their dZ operand.  32-row chunks through an LDS ring (inline-asm DMA, counted vmcnt), one raw
+//     barrier per chunk.
 //   * the number of row slices is per job (dw_plan, nerfpp_common.h): every launch fills the 256 CUs
-//     once with workgroups that move about the same number of bytes.
+//     once with workgroups that finish at about the same time.
 //   * bias gradients: VALU column sums of the A fragments, split over the waves that share them.
-// Rows beyond `rows` up to the next multiple of 32 are zero in every saved tensor (the MLP kernels
+// Rows beyond `rows` up to rows_padded (a multiple of 256) are zero in every saved tensor (the MLP kernels
 // zero-fill their tile tails), so no masking is needed.
 #include "probe_env.h"
 #include <hip/hip_runtime.h>
@@ -398,7 +400,7 @@ struct DwSched {
 };
 // bid: index of this workgroup among the launch's workgroups of its kind (full / narrow)
 template <int P, bool FULL>
-__device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int dbg, uint32_t lds_bytes, const int bid) {
+__device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int dbg, const int bid) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
   int job_id = 0;
@@ -458,8 +460,9 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
   // this kernel's main loop are LDS-DMA loads (same type, in-order), so a COUNTED vmcnt is exact:
   // "at most k*DMA_PER_CHUNK outstanding" == "chunk c has landed" when k younger chunks were issued.
   // Raw s_barrier (a __syncthreads() would drain vmcnt to 0 and kill the overlap).
-  if constexpr (FULL) {
+  {
     constexpr int NBUF = P == 1 ? 4 : 2;         // LDS ring depth (P=1: 4 x 36 KiB, P=2: 2 x 72 KiB)
+    static_assert(NBUF * 2 * P * OPER_BYTES == DW_LDS_BYTES, "the full jobs' ring fills the launch's LDS");
     auto issue = [&](int c) {
       if (c >= nchunk || dbg == 2) return;
       const size_t tile = (size_t)((r_begin >> 5) + c);
@@ -516,11 +519,11 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
 // bg MLP kernels of a level share a launch since then: 2.426 vs 2.411 ms per step in alternating runs on one box, i.e. 0.6 %
 // SLOWER, the weight-gradient group 0.634 vs 0.620 ms; profiles/r04_pair_launch.md.  Two launches it stays.)
 template <int P, bool FULL>
-__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg, uint32_t lds_bytes) {
+__global__ __launch_bounds__(512) void dw_kernel(DwArgs a, DwSched sc, int dbg) {
 #ifndef NERFPP_PROBES
   dbg = 0;                 // (1: DMA only, 2: MFMA only -- diagnostic builds)
 #endif
-  dw_body<P, FULL>(a, sc, dbg, lds_bytes, (int)blockIdx.x);
+  dw_body<P, FULL>(a, sc, dbg, (int)blockIdx.x);
 }
 
 }  // namespace nerfpp
@@ -552,13 +555,13 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   const DwSched sf = make_sched(a.plan, true), sn = make_sched(a.plan, false);
   dim3 gfull(sf.wg_end[sf.njobs - 1]), gnarrow(sn.wg_end[sn.njobs - 1]);
   dim3 block(512);
-  const size_t lds = (size_t)(P == 1 ? 4 : 2) * 2 * P * OPER_BYTES;     // 144 KiB
+  const size_t lds = DW_LDS_BYTES;                                      // 144 KiB
   static const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
   if (P == 1) {
-    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);
-    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg, (uint32_t)lds);
+    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg);
+    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg);
   } else {
-    hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, sf, dbg, (uint32_t)lds);
-    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, lds, st, a, sn, dbg, (uint32_t)lds);
+    hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, sf, dbg);
+    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, lds, st, a, sn, dbg);
   }
 }

@@ -687,7 +687,8 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
           if (blk * CPBH < 16) {
 #pragma unroll
             for (int i = 0; i < CPBH; ++i)
-              store_chunk<P>(base, plane_rows * 256, 256, wrow0, lane, CPBH * blk + i, frags[CPBH * blk + i]);
+              if (CPBH * blk + i < 16)
+                store_chunk<P>(base, plane_rows * 256, 256, wrow0, lane, CPBH * blk + i, frags[CPBH * blk + i]);
           }
         }
         if constexpr (P == 1) {
@@ -807,7 +808,11 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
   // (the remap layer is folded into the colour head: nerfpp_common.h, forward stages.  R is not a tensor here.)
   f32x16 acc1[1];
   bias_init1(acc1, fs_bias_off(FS_SIG));
-  stage_gemm<1, 16, P>(pipe, acc1, h, NoHook{});
+  // h7 goes out under the two stages that consume it, three chunks per block: sigma (1 block) and the colour head (5 blocks).
+  // A/B on one box (gpurun_out/r04v): 2.267 ms per step against 2.280 with four chunks per block under the colour head alone;
+  // split-bf16 training (2 + 10 blocks of 8 fragments, two chunks per block) measured 0.5 % faster with the colour head alone.
+  constexpr int SIG_BLKS = P == 1 ? 1 : 0;
+  stage_gemm<1, 16, P>(pipe, acc1, h, HOOK(if constexpr (P == 1) psave_hc(blk, h, a.ws.t[T_H0 + 7], 7, IC(3))));
   const float sigma_raw = acc1[0][0];
   // colour head: relu(Wc h7 + Wrgb0[:, 256:] dirs + bc)                  nerf_network.py:131,137-138
   Frag<P> g[8];
@@ -820,8 +825,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
     bias_init4(acc4, fs_bias_off(FS_RGB0));
-    // h7 goes out under this stage (5 blocks of 16 fragments, 10 of 8 in split-bf16 training): 4 / 2 chunks per block
-    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(psave_hc(blk, h, a.ws.t[T_H0 + 7], 7, IC(P == 1 ? 4 : 2))));
+    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(psave_hc(blk + SIG_BLKS, h, a.ws.t[T_H0 + 7], 7, IC(P == 1 ? 3 : 2))));
     const uint4 bits = acc_to_frags_relu_bits<4, P>(acc4, g);
     save(std::integral_constant<int, 8>{}, a.ws.t[T_G], 128, g, true, bits, 8);
   }
