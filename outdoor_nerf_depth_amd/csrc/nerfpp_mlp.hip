@@ -204,10 +204,14 @@ struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // registers) one quarter-tile per block pair, so the LDS transpose and the global stores sit in the
 // shadow of this stage's MFMAs instead of in an epilogue where every wave of the CU idles the matrix
 // pipe at once; wave 1 flushes the loader's tile there and the loader queues the next sign-word DMA.
-template <int NOB, int NKC, int P, typename Pipe, typename Hook>
+// LIVE < NKC: the stage's k-chunks from LIVE on are block-alignment padding whose operand fragments are zero (the 3 colour
+// gradients occupy one chunk of the 4 that make B0 a whole block, the colour head's 18 live chunks are padded to 20, ...): their
+// weight fragments travel with the block, their MFMAs are not issued.
+template <int NOB, int NKC, int P, int LIVE = NKC, typename Pipe, typename Hook>
 __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const Frag<P> (&b)[NKC], const Hook& hook) {
   constexpr int KPB = Pipe::BLKF / NOB;           // k-chunks per block
   static_assert(NKC % KPB == 0, "stage must be block aligned");
+  static_assert(LIVE >= 1 && LIVE <= NKC, "live k-chunks");
 #pragma unroll
   for (int blk = 0; blk < NKC / KPB; ++blk) {
     const char* l = pipe.acquire();
@@ -218,6 +222,7 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
     if (probe::HOOK_ORDER == 2 || (probe::HOOK_ORDER == 0 && pipe.wave >= 4)) hook(blk);
 #pragma unroll
     for (int kl = 0; kl < KPB; ++kl) {
+      if (blk * KPB + kl >= LIVE) continue;          // (compile-time after unrolling)
       if constexpr (probe::LDS_REUSE > 1 && P == 1) {      // (probes: one weight-fragment read per LDS_REUSE MFMAs -- garbage results)
         bf16x8 w{};
 #pragma unroll
@@ -235,8 +240,10 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
     if constexpr (P == 1 && probe::LDS_PREFETCH > 0) {
       // shape the block's schedule: LDS_PREFETCH weight fragments in flight ahead of the MFMA
       // that consumes them (LDS latency is ~2-4 MFMA slots; the default schedule keeps only 1-2 ahead)
-      constexpr int D = probe::LDS_PREFETCH, N = NOB * KPB;
+      const int live_kl = LIVE - blk * KPB < KPB ? (LIVE - blk * KPB < 0 ? 0 : LIVE - blk * KPB) : KPB;
+      const int D = probe::LDS_PREFETCH, N = NOB * live_kl;
       static_assert(probe::LDS_REUSE == 1 || probe::LDS_PREFETCH == 0, "the reuse probe runs on the default schedule");
+      if (N < D) continue;
 #pragma unroll
       for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
@@ -825,7 +832,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
     in[16] = df[0]; in[17] = df[1]; in[18] = zero_frag<P>(); in[19] = zero_frag<P>();
     f32x16 acc4[4];
     bias_init4(acc4, fs_bias_off(FS_RGB0));
-    stage_gemm<4, 20, P>(pipe, acc4, in, HOOK(psave_hc(blk + SIG_BLKS, h, a.ws.t[T_H0 + 7], 7, IC(P == 1 ? 3 : 2))));
+    stage_gemm<4, 20, P, 18>(pipe, acc4, in, HOOK(psave_hc(blk + SIG_BLKS, h, a.ws.t[T_H0 + 7], 7, IC(P == 1 ? 3 : 2))));
     const uint4 bits = acc_to_frags_relu_bits<4, P>(acc4, g);
     save(std::integral_constant<int, 8>{}, a.ws.t[T_G], 128, g, true, bits, 8);
   }
@@ -836,7 +843,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
 #pragma unroll
     for (int c = 8; c < 16; ++c) in[c] = zero_frag<P>();
     bias_init1(acc1, fs_bias_off(FS_RGB1));
-    stage_gemm<1, 16, P>(pipe, acc1, in, HOOK(flush(blk, IC(8), a.ws.t[T_G], 128, 8)));
+    stage_gemm<1, 16, P, 8>(pipe, acc1, in, HOOK(flush(blk, IC(8), a.ws.t[T_G], 128, 8)));
   }
   if (valid && hi == 0) {
     float4 o;
@@ -958,7 +965,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a, const int bid)
     if (hi == 0) { set_slot<P>(in[0], 0, d.x); set_slot<P>(in[0], 1, d.y); set_slot<P>(in[0], 2, d.z); }
     f32x16 acc4[4];
     init_zero<4>(acc4);
-    stage_gemm<4, 4, P>(pipe, acc4, in, NoHook{});
+    stage_gemm<4, 4, P, 1>(pipe, acc4, in, NoHook{});
     mask_to_frags<4, P>(acc4, get_mask(8), dg);
     save(std::integral_constant<int, 8>{}, a.ws.t[T_DG], DSG_LD, dg);
   }
@@ -973,7 +980,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a, const int bid)
     if (hi == 0) set_slot<P>(in[8], 0, d.w);
     init_zero<8>(acc);
     // (the barrier just passed ends every wave's use of sign words 8: their slot takes words 6)
-    stage_gemm<8, 10, P>(pipe, acc, in, HOOK(psave(blk, IC(8), dg, a.ws.t[T_DG], DSG_LD); if (blk == 0) issue_masks(6)));
+    stage_gemm<8, 10, P, 9>(pipe, acc, in, HOOK(psave(blk, IC(8), dg, a.ws.t[T_DG], DSG_LD); if (blk == 0) issue_masks(6)));
     mask_to_frags<8, P>(acc, get_mask(7), dz);
     save(std::integral_constant<int, 16>{}, a.ws.t[T_DZ0 + 7], 256, dz);
   }
