@@ -307,7 +307,7 @@ __host__ __device__ constexpr int slab_job_index(const SlabMap& m, int net, int 
 // to 4.9 and the table below is their measurement.)
 struct DwPlan { int k[N_NET][DW_JOBS]; };
 constexpr int dw_narrow_cost(const DwJob& j) {        // shader cycles per 32-row tile, bf16 (dw_kernel<1, false>, per-shape loops)
-  return j.n_o == DSG_LD ? 2250 : j.n_o == 256 ? (j.n_i == 64 ? 1338 : j.n_i == 96 ? 1358 : j.n_i == 320 ? 2909 : 3030) : 764;
+  return j.n_o == DSG_LD ? 2258 : j.n_o == 256 ? (j.n_i == 64 ? 1426 : j.n_i == 96 ? 1534 : j.n_i == 320 ? 2927 : 3133) : 775;
 }
 inline DwPlan dw_plan(int64_t rows) {
   const JobTable jt = build_all_jobs();
