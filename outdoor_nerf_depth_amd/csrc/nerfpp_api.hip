@@ -390,8 +390,10 @@ static void reduce_grads(hipStream_t st, const nerfpp_backward_args* a, const Ws
     utbl[net] = a->tables + T.unpack[net];
     m_out[net] = (float*)(ws + L.fix_m[net]);
   }
-  launch_unpack_grads(st, slabs, slab_floats, plan, utbl, m_out, a->grad_scale, a->grads);
-  launch_remap_fixup(st, a->grads, a->params, m_out[0], m_out[1]);
+  // (diagnostic builds: NERFPP_REDUCE_SKIP = 1 drops the slab sum, 2 the fix-up, 3 both -- what does each cost the step?)
+  static const int skip = PROBE_GETENV("NERFPP_REDUCE_SKIP") ? atoi(PROBE_GETENV("NERFPP_REDUCE_SKIP")) : 0;
+  if (!(skip & 1)) launch_unpack_grads(st, slabs, slab_floats, plan, utbl, m_out, a->grad_scale, a->grads);
+  if (!(skip & 2)) launch_remap_fixup(st, a->grads, a->params, m_out[0], m_out[1]);
 }
 
 extern "C" {

@@ -87,12 +87,14 @@ __global__ void unpack_grads_kernel(UnpackArgs a, float scale, float* __restrict
   const int ksplit = job >= 0 ? a.plan.k[net][job] : 0;        // remap stage: filled in by remap_fixup_kernel
   float acc = 0.f;                                               // fixed summation order: deterministic
   int s = 0;
+  // (non-temporal loads: the ~117 MB of slabs of a level are read once; streamed through the L2 with the default policy they
+  // evict the packed weight streams the MLP kernels running next to this launch re-read for every tile)
   for (; s + 4 <= ksplit; s += 4) {                              // 4 independent loads in flight
-    const float v0 = sl[(size_t)s * sf + src], v1 = sl[(size_t)(s + 1) * sf + src];
-    const float v2 = sl[(size_t)(s + 2) * sf + src], v3 = sl[(size_t)(s + 3) * sf + src];
+    const float v0 = __builtin_nontemporal_load(sl + (size_t)s * sf + src), v1 = __builtin_nontemporal_load(sl + (size_t)(s + 1) * sf + src);
+    const float v2 = __builtin_nontemporal_load(sl + (size_t)(s + 2) * sf + src), v3 = __builtin_nontemporal_load(sl + (size_t)(s + 3) * sf + src);
     acc += (v0 + v1) + (v2 + v3);
   }
-  for (; s < ksplit; ++s) acc += sl[(size_t)s * sf + src];
+  for (; s < ksplit; ++s) acc += __builtin_nontemporal_load(sl + (size_t)s * sf + src);
   acc *= scale;
   grads[gi] = acc;
   const int w_g = ref_w_off(net, RT_RGB0), ldg = ref_in(net, RT_RGB0);
