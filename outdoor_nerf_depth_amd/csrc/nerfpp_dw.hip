@@ -2,7 +2,8 @@
 //
 // The contraction runs over the SAMPLE axis (rows = n_rays*S, 65k..1.5M) and the output is at most
 // 256x256 per job, so this is a split-K problem: a workgroup owns the whole output of one job over one
-// slice of the rows and writes its partial result to that slice's slab; unpack_grads_kernel sums the
+// slice of the rows and writes its partial result to that slice's slab (non-temporal stores: ~117 MB per level that nothing
+// re-reads from the L2; level 0's launches run next to level 1's forward, whose weight streams live there); unpack_grads_kernel sums the
 // slabs in a fixed order (deterministic) and maps the internal feature order back to the reference's
 // parameter layout.  Every operand tensor is read exactly once per job.
 //
@@ -361,7 +362,7 @@ __device__ __forceinline__ void narrow_pass(const DwArgs& a, const DwJob& job, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = 32 * sbo + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        slab[s_off + o * s_ld + 32 * bi + li] = acc[k][r];
+        __builtin_nontemporal_store(acc[k][r], slab + s_off + o * s_ld + 32 * bi + li);
       }
     }
     if (has_bias && wave < S::N_OB) {                     // wave w holds the column sums of out-block w (both mappings)
@@ -370,7 +371,7 @@ __device__ __forceinline__ void narrow_pass(const DwArgs& a, const DwJob& job, i
       const int sbo = seg2 ? bo - job.o_split : bo;
       const int s_gb = seg2 ? job.gb_off2 : job.gb_off;
       const float tot = bsum + __shfl_xor(bsum, 32, 64);
-      if (hi == 0) slab[gw_floats(net) + s_gb + 32 * sbo + li] = tot;
+      if (hi == 0) __builtin_nontemporal_store(tot, slab + gw_floats(net) + s_gb + 32 * sbo + li);
     }
   }
   DW_STAMP(false, 2, __builtin_readcyclecounter());
@@ -504,12 +505,12 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = ob + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        slab[job.gw_off + o * job.gw_ld + ib + li] = acc[bo][bi][r];
+        __builtin_nontemporal_store(acc[bo][bi][r], slab + job.gw_off + o * job.gw_ld + ib + li);
       }
     }
     if (do_bias && bo == wi) {                       // lane (li, hi) holds feature ob + li, half of the samples
       const float tot = bsum[bo] + __shfl_xor(bsum[bo], 32, 64);
-      if (hi == 0) slab[gw_floats(net) + job.gb_off + ob + li] = tot;
+      if (hi == 0) __builtin_nontemporal_store(tot, slab + gw_floats(net) + job.gb_off + ob + li);
     }
   }
   DW_STAMP(FULL, 2, __builtin_readcyclecounter());

@@ -387,6 +387,9 @@ __device__ __forceinline__ void lds_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) { probe::store16(gptr, v); }
+// (The ReLU sign words -- 16 B per lane per stage, 113 MB per level-1 launch -- keep the DEFAULT policy on both sides: written
+// non-temporally they come back from HBM instead of the Infinity Cache and the backward kernel loses 0.035 ms per level-1
+// launch to its sign-word DMA; a non-temporal DMA of default-policy words measures the same as the default.  gpurun_out/r04ae.)
 
 // Saved tensors are FRAGMENT-MAJOR (nerfpp_common.h, "saved tensors"): the 16 bytes lane (j, hi) holds of chunk c of a
 // wave's 32-row tile go to byte ((tile32 * (ld / 16) + c) * 1024 + (2 j + hi) * 16) of the tensor (hi plane, then the

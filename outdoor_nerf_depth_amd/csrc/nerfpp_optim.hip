@@ -51,7 +51,7 @@ __global__ void pack_level_kernel(const float* __restrict__ params, PackSegs sg)
   const int blk0 = seg == 0 ? 0 : sg.blk_end[seg - 1];
   const int64_t e = (int64_t)((int)blockIdx.x - blk0) * blockDim.x + threadIdx.x;
   if (e >= sg.n[seg]) return;
-  const int32_t src = sg.tbl[seg][e];
+  const int32_t src = __builtin_nontemporal_load(sg.tbl[seg] + e);       // (the gather tables: 10 MB per level, read once per pack)
   const float v = src < 0 ? 0.f : src < sg.np[seg] ? params[sg.pbase[seg] + src] : sg.derived[seg][src - sg.np[seg]];
   if (sg.is_f32[seg]) {
     ((float*)sg.out[seg])[e] = v;
@@ -80,7 +80,7 @@ __global__ void unpack_grads_kernel(UnpackArgs a, float scale, float* __restrict
   if (gi >= LEVEL_PARAMS) return;
   const int net = gi >= FG_PARAMS;
   const int i = (int)(gi - (net ? FG_PARAMS : 0));
-  const int32_t src = a.tbl[net][i];
+  const int32_t src = __builtin_nontemporal_load(a.tbl[net] + i);
   const float* sl = a.slabs[net];
   const int64_t sf = a.slab_floats[net];
   const int job = slab_job_index(c_slab_map, net, src);
@@ -113,14 +113,16 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   // device-side predicate (nerfpp_adam_step: skip_if_nonzero): the reference raises BEFORE the step when a camera is
   // outside the unit sphere (ddp_train_nerf.py:62-63); here that count is read later, so the update must not happen
   if (skip != nullptr && *skip != 0.f) return;
-  const float gi = g[i];
-  float mi = m[i], vi = v[i];
+  // (streamed once per step, on a side stream next to the MLP kernels: non-temporal, so that 24 MB per level do not pass
+  // through the L2 lines the packed weight streams live in.  The parameters themselves are re-read by the fold / re-pack.)
+  const float gi = __builtin_nontemporal_load(g + i);
+  float mi = __builtin_nontemporal_load(m + i), vi = __builtin_nontemporal_load(v + i);
   mi = mi + (gi - mi) * one_minus_b1;                   // exp_avg.lerp_(grad, 1 - beta1)
   vi = vi * b2 + one_minus_b2 * gi * gi;                // exp_avg_sq.mul_(beta2).addcmul_(...)
   const float denom = sqrtf(vi) / sqrt_bias2 + eps;      // (sqrt(v) / sqrt(bias2)).add_(eps)
   p[i] = p[i] - step_size * (mi / denom);
-  m[i] = mi;
-  v[i] = vi;
+  __builtin_nontemporal_store(mi, m + i);
+  __builtin_nontemporal_store(vi, v + i);
 }
 
 // The remap layer has no activation, so with M = dG^T * H7 (what the weight-gradient GEMM leaves in
