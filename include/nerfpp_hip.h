@@ -169,7 +169,9 @@ int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, i
 
 typedef struct {
   int32_t n_rays, n_samples;       /* S = 64 (level 0) or 192 (level 1) in the reference */
-  int32_t precision, training;     /* training != 0 keeps what nerfpp_level_backward needs */
+  int32_t precision, training;     /* training != 0 keeps what nerfpp_level_backward needs; 2 (precision 2 only): the
+                                      backward will run at precision 1 (workspace_precision 2 there), so only the hi planes
+                                      of the saved tensors are written -- half the store traffic of the forward */
   const float* ray_o;              /* [n,3] */
   const float* ray_d;              /* [n,3] un-normalised */
   const float* fg_far;             /* [n]   fg_z_max */

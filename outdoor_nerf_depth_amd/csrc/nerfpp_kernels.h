@@ -26,6 +26,7 @@ struct MlpFwdArgs {
   float* depth_real;             // [rows] (background only)
   NetWs ws;
   uint4* masks;                  // ReLU sign bits [9 stages][rows_padded/32][64 lanes] (training)
+  int save_lo;                   // split-bf16 training: 0 = write the hi planes of the saved tensors only (bf16 backward)
 };
 
 struct MlpBwdArgs {

@@ -410,19 +410,21 @@ __device__ __forceinline__ char* frag_addr(__bf16* base, int ld, size_t wave_row
   return (char*)base + blk * FRAG_BYTES + ((((lane & 31) << 1) | (lane >> 5)) << 4);
 }
 template <int P>
-__device__ __forceinline__ void store_chunk(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, int c, const Frag<P>& f) {
+// np < P: only the first np planes are written (a split-bf16 forward whose backward is single-pass bf16 reads the hi planes only)
+__device__ __forceinline__ void store_chunk(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, int c, const Frag<P>& f, int np = P) {
 #pragma unroll
-  for (int p = 0; p < P; ++p) store_nt16(frag_addr(base + p * plane, ld, wave_row0, c, lane), *(const uint4*)&f.v[p]);
+  for (int p = 0; p < P; ++p)
+    if (p < np) store_nt16(frag_addr(base + p * plane, ld, wave_row0, c, lane), *(const uint4*)&f.v[p]);
 }
 template <int NCH, int P>
-__device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, const Frag<P> (&h)[NCH]) {
+__device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, const Frag<P> (&h)[NCH], int np = P) {
   if constexpr ((probe::DBG & 2) != 0) return;
   // Scheduling fences on both sides: the LDS-staged save this replaces was a fence by construction (wave barriers);
   // without one the scheduler starts the next stage's accumulator set while this stage's is still being converted and
   // stored (the split-bf16 backward went from 371 to 512 registers + spills).
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) store_chunk<P>(base, plane, ld, wave_row0, lane, c, h[c]);
+  for (int c = 0; c < NCH; ++c) store_chunk<P>(base, plane, ld, wave_row0, lane, c, h[c], np);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -438,22 +440,22 @@ __device__ __forceinline__ void handoff_write(char* region, int lane, const Frag
 }
 // chunks [c0, c0 + n) of the loader's tile (tile rows row0 .. row0 + 31): region -> HBM (plane p at base + p * plane elements)
 template <int P>
-__device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int c0, int n) {
+__device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int c0, int n, int np = P) {
   if constexpr ((probe::DBG & 16) != 0) return;
 #pragma unroll 4
   for (int c = c0; c < c0 + n; ++c)
 #pragma unroll
     for (int p = 0; p < P; ++p)
-      store_nt16(frag_addr(base + p * plane, ld, row0, c, lane), *(const uint4*)(region + ((c * P + p) * 64 + lane) * 16));
+      if (p < np) store_nt16(frag_addr(base + p * plane, ld, row0, c, lane), *(const uint4*)(region + ((c * P + p) * 64 + lane) * 16));
 }
 
 // region chunk cr -> tensor chunk ct (a hand-off that carries the chunks of two tensors back to back)
 template <int P>
-__device__ __forceinline__ void handoff_flush_one(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int cr, int ct) {
+__device__ __forceinline__ void handoff_flush_one(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int cr, int ct, int np = P) {
   if constexpr ((probe::DBG & 16) != 0) return;
 #pragma unroll
   for (int p = 0; p < P; ++p)
-    store_nt16(frag_addr(base + p * plane, ld, row0, ct, lane), *(const uint4*)(region + ((cr * P + p) * 64 + lane) * 16));
+    if (p < np) store_nt16(frag_addr(base + p * plane, ld, row0, ct, lane), *(const uint4*)(region + ((cr * P + p) * 64 + lane) * 16));
 }
 
 // dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
@@ -632,6 +634,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)bid * (NW * 32) + wave * 32;                 // this wave's first tile row
   const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
+  const int NPS = (P == 2 && !a.save_lo) ? 1 : P;            // planes of the saved tensors that are written out (wave-uniform)
   probe::kernel_prologue(a.out_raw);
   const bool tail = wrow0 + 32 > (size_t)a.rows;                            // wave-uniform
   char* region = smem + LD::REGION;
@@ -663,7 +666,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
       if (blk == 0 && wave >= 1 && wave <= H) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
-          if ((c % H) == wave - 1) handoff_flush_chunks<P>(region, lane, base, plane_rows * ld, ld, tile_row0, c, 1);
+          if ((c % H) == wave - 1) handoff_flush_chunks<P>(region, lane, base, plane_rows * ld, ld, tile_row0, c, 1, NPS);
         if (partner && mask_stage >= 0)
           mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
       }
@@ -683,7 +686,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
       else mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
     } else {
       mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
-      save_frags<16, P>(base, plane_rows * 256, 256, wrow0, lane, frags);
+      save_frags<16, P>(base, plane_rows * 256, 256, wrow0, lane, frags, NPS);
     }
   };
   // (cpb_c: chunks per block of the storers; the colour head that consumes h7 has 5 / 10 blocks, not 8 / 16)
@@ -698,14 +701,14 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
 #pragma unroll
             for (int i = 0; i < CPBH; ++i)
               if (CPBH * blk + i < 16)
-                store_chunk<P>(base, plane_rows * 256, 256, wrow0, lane, CPBH * blk + i, frags[CPBH * blk + i]);
+                store_chunk<P>(base, plane_rows * 256, 256, wrow0, lane, CPBH * blk + i, frags[CPBH * blk + i], NPS);
           }
         }
         if constexpr (P == 1) {
-          if (wave <= H && blk == 2) handoff_flush_chunks<P>(region, lane, base, plane_rows * 256, 256, tile_row0, Q * (wave - 1), Q);
+          if (wave <= H && blk == 2) handoff_flush_chunks<P>(region, lane, base, plane_rows * 256, 256, tile_row0, Q * (wave - 1), Q, NPS);
         } else {
           if (wave <= H && blk >= 2 && blk < 2 + Q && Q * (wave - 1) + blk - 2 < 16)
-            handoff_flush_chunks<P>(region, lane, base, plane_rows * 256, 256, tile_row0, Q * (wave - 1) + blk - 2, 1);
+            handoff_flush_chunks<P>(region, lane, base, plane_rows * 256, 256, tile_row0, Q * (wave - 1) + blk - 2, 1, NPS);
         }
         if (partner && blk == 1)
           mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
@@ -726,11 +729,11 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
         if (has_mask) *(uint4*)(region + RMASK + lane * 16) = bits;
       } else {
         if (has_mask) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
-        save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags);
+        save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags, NPS);
       }
     } else {
       if (has_mask) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
-      save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags);
+      save_frags<NCH, P>(base, plane_rows * ld, ld, wrow0, lane, frags, NPS);
     }
   };
 
@@ -757,8 +760,8 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
       }
     }
     if (direct) {
-      save_frags<KPE, P>(a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), wrow0, lane, pe);
-      save_frags<2, P>(a.ws.t[T_DIRX], plane_rows * 32, 32, wrow0, lane, df0);
+      save_frags<KPE, P>(a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), wrow0, lane, pe, NPS);
+      save_frags<2, P>(a.ws.t[T_DIRX], plane_rows * 32, 32, wrow0, lane, df0, NPS);
     }
   }
   auto flush_xd = [&](int blk) __attribute__((always_inline)) {
@@ -767,8 +770,8 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
 #pragma unroll
         for (int c = 0; c < KPE + 2; ++c)
           if ((c % H) == wave - 1) {
-            if (c < KPE) handoff_flush_one<P>(region, lane, a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), tile_row0, c, c);
-            else handoff_flush_one<P>(region, lane, a.ws.t[T_DIRX], plane_rows * 32, 32, tile_row0, c, c - KPE);
+            if (c < KPE) handoff_flush_one<P>(region, lane, a.ws.t[T_X], plane_rows * kpew(NET), kpew(NET), tile_row0, c, c, NPS);
+            else handoff_flush_one<P>(region, lane, a.ws.t[T_DIRX], plane_rows * 32, 32, tile_row0, c, c - KPE, NPS);
           }
       }
     }

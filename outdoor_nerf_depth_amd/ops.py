@@ -259,7 +259,9 @@ class LevelEngine(object):
                 (n, S) if k in ('fg_weights', 'bg_weights', 'fg_dists') else (n,)
             out[k] = torch.empty(shape, device=dev)
         a = L.ForwardArgs()
-        a.n_rays, a.n_samples, a.precision, a.training = n, S, self.precision, int(training)
+        # training = 2: split-bf16 forward whose backward is single-pass bf16 (PREC_SPLIT_FWD) -- the kernels save hi planes only
+        hi_only = training and self.bwd_precision != self.precision
+        a.n_rays, a.n_samples, a.precision, a.training = n, S, self.precision, (2 if hi_only else int(training))
         a.ray_o, a.ray_d, a.fg_far, a.fg_z, a.bg_z = [t.data_ptr() for t in
                                                       (ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)]
         a.packed = self.packed.data_ptr()

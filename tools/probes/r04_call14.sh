@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 O=$R/gpurun_out/${1:-r04v}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 V=$R/outdoor_nerf_depth_amd/csrc/build/variants
-( cd $R && timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round3.py -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log )
+( cd $R && timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round3.py tests/test_gpu_round4.py tests/test_gpu_train_cli.py -m gpu -q -x -k "not seeds" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log )
 tail -3 $O/pytest.log
 B="--no_cpu_baseline --large_batch 0 --mip360_rays 0 --cli_steps 0 --render_frames 0"
 for rep in 1 2 3; do
