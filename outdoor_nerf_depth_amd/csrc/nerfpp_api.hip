@@ -324,6 +324,7 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     m.depth_real = (float*)(ws + L.depth_real);
     if (train) { m.ws = make_netws(ws, L, net); m.masks = (uint4*)(ws + L.masks[net]); }
     m.save_lo = a->training == 2 ? 0 : 1;          // training == 2: the backward will be single-pass bf16 (hi planes only)
+    if (const char* e = PROBE_GETENV("NERFPP_SKIP_H_RT")) m.save_lo |= atoi(e) << 8;   // (probes: tools/probes/recompute_probe.py)
   }
   if (a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
   if (split_nets()) {

@@ -23,6 +23,9 @@
 // kernels stream the fragments through a double-buffered LDS ring in blocks of BLK_FRAGS.
 #pragma once
 #include <stdint.h>
+#ifdef NERFPP_PROBES
+#include <stdlib.h>
+#endif
 
 namespace nerfpp {
 
@@ -331,6 +334,18 @@ inline DwPlan dw_plan(int64_t rows) {
       int64_t k;
       if (dw_job_is_full(job)) {
         k = 256 / n_full;
+#ifdef NERFPP_PROBES
+        // (timing experiment: NERFPP_DW_RC_K = slices of the full jobs that would recompute their input, the others share the rest)
+        if (const char* e = getenv("NERFPP_DW_RC_K")) {
+          const int kr = atoi(e);
+          const bool rcj = job.b_tensor == T_H0 || job.b_tensor == T_H0 + 2 || job.b_tensor == T_H0 + 6;
+          if (const char* e0 = getenv("NERFPP_DW_RC_K0")) {            // the H0 job separately (kr = 0: it alone differs)
+            const int k0 = atoi(e0);
+            if (kr == 0) k = job.b_tensor == T_H0 ? k0 : (256 - 2 * k0) / 10;
+            else k = job.b_tensor == T_H0 ? k0 : rcj ? kr : (256 - 2 * k0 - 4 * kr) / 6;
+          } else k = rcj ? kr : (256 - 6 * kr) / 6;
+        }
+#endif
       } else {
         const int64_t num = (int64_t)256 * dw_narrow_cost(job);
         k = num / w_narrow;

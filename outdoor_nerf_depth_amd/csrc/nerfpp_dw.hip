@@ -402,6 +402,7 @@ struct DwSched {
 // bid: index of this workgroup among the launch's workgroups of its kind (full / narrow)
 template <int P, bool FULL>
 __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int dbg, const int bid) {
+  (void)0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
   int job_id = 0;
@@ -457,6 +458,28 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
   // blocks per 32-row tile of each operand TENSOR (the job may use a leading part of it) and the tile of row r: r / 32
   const size_t tb_a = (size_t)(rb_a >> 5), tb_b = (size_t)(rb_b >> 5);
 
+#ifdef NERFPP_PROBES
+  // dbg & 4: emulate the one-layer recompute in the jobs whose input would be unsaved (H0, H2, H6; dbg & 8: every full job);
+  // dbg >> 4 = k-chunks of the recompute for the H0 job (default 16).  Garbage results.
+  // dbg & 512: the H0 job alone, and its input DMA carries only the rc_k blocks of the encoded point it would read instead.
+  const bool rc_h0only = (dbg & 512) != 0;
+  const bool rc_emul = P == 1 && (dbg & 4) != 0 &&
+                       (rc_h0only ? job.b_tensor == T_H0
+                                  : ((dbg & 8) != 0 || job.b_tensor == T_H0 || job.b_tensor == T_H0 + 2 || job.b_tensor == T_H0 + 6));
+  const int rc_k = (job.b_tensor == T_H0 && ((dbg >> 4) & 31) > 0) ? ((dbg >> 4) & 31) : 16;
+  const bool rc_short = rc_emul && rc_h0only && rc_k <= 8;       // B operand: blocks [0, rc_k) only (waves < rc_k issue one)
+  bf16x8 rc_w[16];
+  if (rc_emul) {
+#pragma unroll
+    for (int kc = 0; kc < 16; ++kc) rc_w[kc] = *(const bf16x8*)(ga + ((size_t)kc * 8 + wave) * FRAG_BYTES + lane * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  dbg &= 3;
+#else
+  constexpr bool rc_short = false;
+  constexpr int rc_k = 16;
+  (void)rc_short; (void)rc_k;
+#endif
   // Ring pipeline: chunks c+1 .. c+NBUF-2 stay in flight while chunk c is consumed.  All VMEM ops of
   // this kernel's main loop are LDS-DMA loads (same type, in-order), so a COUNTED vmcnt is exact:
   // "at most k*DMA_PER_CHUNK outstanding" == "chunk c has landed" when k younger chunks were issued.
@@ -474,6 +497,9 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
         const int op = id / (16 * P), rem = id - op * 16 * P, pl = rem >> 4, blk = rem & 15;
         const char* src = (op == 0 ? ga + pl * plane_a + (tile * tb_a + blk) * FRAG_BYTES
                                    : gb + pl * plane_b + (tile * tb_b + blk) * FRAG_BYTES) + lane * 16;
+#ifdef NERFPP_PROBES
+        if (rc_short && op == 1 && blk >= rc_k) continue;
+#endif
         glds16(src, buf + (op * P + pl) * OPER_BYTES + blk * BLKP);
       }
     };
@@ -481,12 +507,46 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
     for (int c = 0; c < NBUF - 1; ++c) issue(c);
     for (int c = 0; c < nchunk; ++c) {
       const int younger = nchunk - 1 - c < NBUF - 2 ? nchunk - 1 - c : NBUF - 2;
+#ifdef NERFPP_PROBES
+      if (rc_short) {                               // 2 (+ 1 for waves < rc_k) DMA instructions per wave and chunk
+        const int per = 2 + (wave < rc_k ? 1 : 0);
+        if (younger >= 2) { if (per == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else if (younger == 1) { if (per == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else
+#endif
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       issue(c + NBUF - 1);
       if (dbg == 1) continue;
+#ifdef NERFPP_PROBES
+      if constexpr (P == 1) {
+        if (rc_emul) {      // (timing only: wave w recomputes out-block w of relu(W H_prev + b) for the chunk)
+          f32x16 rc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rc[r] = 0.25f;
+          const int kmax = rc_k;
+#pragma unroll
+          for (int kc = 0; kc < 16; ++kc) {
+            if (kc < kmax) {
+              const bf16x8 bfrag = *(const bf16x8*)(dw_smem + (c % NBUF) * (2 * P * OPER_BYTES) + OPER_BYTES + kc * BLKP + lane * 16);
+              rc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rc_w[kc], bfrag, rc, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            bf16x8 q;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) q[t] = (__bf16)fmaxf(rc[8 * hh + t], 0.f);
+            *(bf16x8*)(dw_smem + DW_LDS_BYTES + (2 * wave + hh) * 1024 + ((2 * li + hi) << 4)) = q;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+#endif
       const lds_addr buf = (c % NBUF) * (2 * P * OPER_BYTES) + lane_off;
       compute_chunk<P, true>(buf, wo, wi, nbo, nbi, do_bias, acc, bsum);
     }
@@ -556,8 +616,12 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   const DwSched sf = make_sched(a.plan, true), sn = make_sched(a.plan, false);
   dim3 gfull(sf.wg_end[sf.njobs - 1]), gnarrow(sn.wg_end[sn.njobs - 1]);
   dim3 block(512);
+#ifdef NERFPP_PROBES
+  const size_t lds = DW_LDS_BYTES + 16 * 1024;                          // + the recomputed tile of the emulation (dbg & 4)
+#else
   const size_t lds = DW_LDS_BYTES;                                      // 144 KiB
-  static const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only
+#endif
+  const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only, 4..: recompute emulation
   if (P == 1) {
     hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg);
     hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg);

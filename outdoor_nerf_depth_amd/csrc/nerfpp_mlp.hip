@@ -46,6 +46,7 @@ constexpr int HOOK_ORDER = 1;          // saves issued after a block's MFMAs by 
 constexpr int WAVES_P1 = 8;            // waves per workgroup of the bf16 kernels (256-sample tiles)
 constexpr int LOADER_SLEEP = 0;        // (probes: idle cycles / 64 added to the loader wave per weight block)
 constexpr int LDS_REUSE = 1;           // (probes: MFMAs per weight-fragment read)
+constexpr int SKIP_H = 0;              // (probes: bit l = the training forward does not write H_l out)
 __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   const u32x4_ vv = {v.x, v.y, v.z, v.w};
@@ -693,7 +694,11 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
   auto psave_hc = [&](int blk, const Frag<P> (&frags)[16], __bf16* base, int mask_stage, auto cpb_c) __attribute__((always_inline)) {
     constexpr int CPBH = decltype(cpb_c)::value;
     if constexpr (TRAIN && ROLES) {
-      if (loader) {
+      // (probes: H_l stays unsaved, its sign words go out; SKIP_H < 0: the mask comes with the launch, bits 8.. of save_lo)
+      const bool skip = P == 1 && (((probe::SKIP_H < 0 ? a.save_lo >> 8 : probe::SKIP_H) >> mask_stage) & 1);
+      if (skip) {
+        if (partner && blk == 1) mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
+      } else if (loader) {
         if (blk == 0) handoff_write<16, P>(region, lane, frags);
       } else {
         if constexpr ((probe::DBG & 2) == 0) {

@@ -14,6 +14,8 @@
 //   NERFPP_WAVES_P1        waves per workgroup of the bf16 kernels (default 8; 4 = 128-sample tiles)
 //   NERFPP_LDS_REUSE=n     one weight-fragment LDS read per n MFMAs (build with NERFPP_LDS_PREFETCH=0): what would halving the
 //                          LDS reads per MFMA -- 64-row waves -- buy?
+//   NERFPP_SKIP_H=mask     bit l: the bf16 training forward does not write H_l (its sign words still go out) -- garbage gradients;
+//                          -1: the mask is read per launch from the environment variable NERFPP_SKIP_H_RT (nerfpp_api.hip)
 //   NERFPP_LOADER_SLEEP=n  the loader wave idles 64 n cycles per weight block (does added latency cost time, or only cycles?)
 //   NERFPP_STAMPS=k        per-block cycle stamps (s_memtime at arrival at / release from every block barrier, per wave) of
 //                          workgroups 0-3 and 400-403 (fg tiles) of kernel instantiation k (NERFPP_MLP_PART numbering: 2 = bf16
@@ -43,6 +45,9 @@
 #ifndef NERFPP_LDS_REUSE
 #define NERFPP_LDS_REUSE 1
 #endif
+#ifndef NERFPP_SKIP_H
+#define NERFPP_SKIP_H 0
+#endif
 
 namespace nerfpp { namespace probe {
 
@@ -61,6 +66,7 @@ constexpr int LDS_PREFETCH = NERFPP_LDS_PREFETCH;
 constexpr int HOOK_ORDER = NERFPP_HOOK_ORDER;
 constexpr int WAVES_P1 = NERFPP_WAVES_P1;
 constexpr int LOADER_SLEEP = NERFPP_LOADER_SLEEP;
+constexpr int SKIP_H = NERFPP_SKIP_H;             // bit l: the bf16 training forward leaves H_l unsaved (what would one-layer recompute in dw_kernel buy?)
 constexpr int LDS_REUSE = NERFPP_LDS_REUSE;       // 2: one weight-fragment read per two MFMAs (what 64-row waves would need); with NERFPP_LDS_PREFETCH=0
 
 #if (NERFPP_DBG & 32)

@@ -522,6 +522,60 @@ def ref_render_frame(nets, rays, cascade, dtype=torch.float32, chunk=1024):
     return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
 
 
+def run_ref_trajectory(mode, dtype, n_steps, seed=0, tag=None):
+    """The imported reference's training loop (ddp_train_nerf.py:417-498) on the BASELINE config-1 scene on replayed batches and
+    uniforms (tests/trajectory_common.py: seeds only; seed s shifts the numpy streams by 100000 s, the same rule
+    tests/test_gpu_round4.py: _trajectory uses).  Returns the scalars logged every LOG_EVERY steps, the rgb losses of the last
+    LOG_EVERY steps, and the frame rendered at the end with deterministic sampling."""
+    import time
+    import trajectory_common as TC
+    smp = TC.sampler(mode)
+    full = {k: np.ascontiguousarray(v, np.float32) for k, v in smp.get_all().items() if isinstance(v, np.ndarray)}
+    sigma = TC.DEPTH_SIGMA * float(smp.get_depth_scale() or 1.0)
+    nets = [n.to(dtype) for n in make_levels(2)]
+    optims = [torch.optim.Adam(n.parameters(), lr=5e-4) for n in nets]
+    logs = {k: [] for k in ('loss0', 'loss1', 'rgb0', 'rgb1', 'depth0', 'depth1')}
+    tail = []
+    t0 = time.time()
+    for step in range(1, n_steps + 1):
+        b, uni = TC.step_batch(smp, step + 100000 * seed), TC.step_uniforms(step + 100000 * seed)
+        bt = {k: T(v).to(dtype) for k, v in b.items()}
+        N = bt['ray_o'].shape[0]
+        row = {}
+        with _ReplayRand([T(uni[k]) for k in ('t_fg', 't_bg', 'u_fg', 'u_bg')]):
+            for m in range(2):                                      # :432-498
+                S = TC.CASCADE[m]
+                if m == 0:
+                    far = R.intersect_sphere(bt['ray_o'], bt['ray_d'])
+                    near = bt['min_depth']
+                    stp = (far - near) / (S - 1)
+                    fg = torch.stack([near + i * stp for i in range(S)], dim=-1)
+                    fg = R.perturb_samples(fg)
+                    bg = torch.linspace(0., 1., S).view(1, S).expand(N, S).to(dtype)
+                    bg = R.perturb_samples(bg)
+                else:
+                    fgw = ret['fg_weights'].clone().detach()[..., 1:-1]
+                    fs = R.sample_pdf(bins=.5 * (fg[..., 1:] + fg[..., :-1]), weights=fgw, N_samples=S, det=False)
+                    fg, _ = torch.sort(torch.cat((fg, fs), dim=-1))
+                    bgw = ret['bg_weights'].clone().detach()[..., 1:-1]
+                    bs = R.sample_pdf(bins=.5 * (bg[..., 1:] + bg[..., :-1]), weights=bgw, N_samples=S, det=False)
+                    bg, _ = torch.sort(torch.cat((bg, bs), dim=-1))
+                optims[m].zero_grad()
+                ret, loss, rgb_loss, depth_loss = ref_level_step(nets[m], bt, far, fg, bg, mode, TC.LAMBDA_DEPTH, sigma)
+                optims[m].step()
+                row['loss%d' % m], row['rgb%d' % m] = loss.item(), rgb_loss.item()
+                row['depth%d' % m] = depth_loss.item() if depth_loss is not None else 0.0
+        if step % TC.LOG_EVERY == 0:
+            for k in logs:
+                logs[k].append(row[k])
+            print(tag, step, row, '%.0f s' % (time.time() - t0), flush=True)
+        if step > n_steps - TC.LOG_EVERY:
+            tail.append([row['rgb0'], row['rgb1']])
+    rgb, depth = ref_render_frame(nets, full, TC.CASCADE, dtype)
+    mse = float(np.mean((rgb - full['rgb'].astype(np.float64)) ** 2))
+    return logs, np.array(tail, np.float64), rgb, depth, mse
+
+
 def gen_trajectory(dtypes=(torch.float32, torch.float64), modes=None):
     """the imported reference's training loop (ddp_train_nerf.py:417-498) on the BASELINE config-1
     scene -- one 64x64 frame, --cascade_samples 32,64, N_rand 256, 200 steps -- rgb-only and with the gt / mse depth
@@ -533,57 +587,13 @@ def gen_trajectory(dtypes=(torch.float32, torch.float64), modes=None):
     import trajectory_common as TC
     path = os.path.join(HERE, 'trajectory.npz')
     arrs = dict(np.load(path)) if (modes and os.path.exists(path)) else {}      # extend the fixture: earlier modes are kept as they are
-    import time
     for mode in (modes or TC.MODES):
-        smp = TC.sampler(mode)
-        full = {k: np.ascontiguousarray(v, np.float32) for k, v in smp.get_all().items() if isinstance(v, np.ndarray)}
-        sigma = TC.DEPTH_SIGMA * float(smp.get_depth_scale() or 1.0)
         for dtype in dtypes:
             tag = '%s.%s' % (mode, 'f32' if dtype == torch.float32 else 'f64')
-            nets = [n.to(dtype) for n in make_levels(2)]
-            optims = [torch.optim.Adam(n.parameters(), lr=5e-4) for n in nets]
-            logs = {k: [] for k in ('loss0', 'loss1', 'rgb0', 'rgb1', 'depth0', 'depth1')}
-            tail = []
-            t0 = time.time()
-            for step in range(1, TC.N_STEPS + 1):
-                b, uni = TC.step_batch(smp, step), TC.step_uniforms(step)
-                bt = {k: T(v).to(dtype) for k, v in b.items()}
-                N = bt['ray_o'].shape[0]
-                row = {}
-                with _ReplayRand([T(uni[k]) for k in ('t_fg', 't_bg', 'u_fg', 'u_bg')]):
-                    for m in range(2):                                      # :432-498
-                        S = TC.CASCADE[m]
-                        if m == 0:
-                            far = R.intersect_sphere(bt['ray_o'], bt['ray_d'])
-                            near = bt['min_depth']
-                            stp = (far - near) / (S - 1)
-                            fg = torch.stack([near + i * stp for i in range(S)], dim=-1)
-                            fg = R.perturb_samples(fg)
-                            bg = torch.linspace(0., 1., S).view(1, S).expand(N, S).to(dtype)
-                            bg = R.perturb_samples(bg)
-                        else:
-                            fgw = ret['fg_weights'].clone().detach()[..., 1:-1]
-                            fs = R.sample_pdf(bins=.5 * (fg[..., 1:] + fg[..., :-1]), weights=fgw, N_samples=S, det=False)
-                            fg, _ = torch.sort(torch.cat((fg, fs), dim=-1))
-                            bgw = ret['bg_weights'].clone().detach()[..., 1:-1]
-                            bs = R.sample_pdf(bins=.5 * (bg[..., 1:] + bg[..., :-1]), weights=bgw, N_samples=S, det=False)
-                            bg, _ = torch.sort(torch.cat((bg, bs), dim=-1))
-                        optims[m].zero_grad()
-                        ret, loss, rgb_loss, depth_loss = ref_level_step(nets[m], bt, far, fg, bg, mode, TC.LAMBDA_DEPTH, sigma)
-                        optims[m].step()
-                        row['loss%d' % m], row['rgb%d' % m] = loss.item(), rgb_loss.item()
-                        row['depth%d' % m] = depth_loss.item() if depth_loss is not None else 0.0
-                if step % TC.LOG_EVERY == 0:
-                    for k in logs:
-                        logs[k].append(row[k])
-                    print(tag, step, row, '%.0f s' % (time.time() - t0), flush=True)
-                if step > TC.N_STEPS - TC.LOG_EVERY:
-                    tail.append([row['rgb0'], row['rgb1']])
+            logs, tail, rgb, depth, mse = run_ref_trajectory(mode, dtype, TC.N_STEPS, 0, tag)
             for k, v in logs.items():
                 arrs['%s.%s' % (tag, k)] = np.array(v, np.float64)
-            arrs['%s.tail_rgb_mse' % tag] = np.array(tail, np.float64)
-            rgb, depth = ref_render_frame(nets, full, TC.CASCADE, dtype)
-            mse = float(np.mean((rgb - full['rgb'].astype(np.float64)) ** 2))
+            arrs['%s.tail_rgb_mse' % tag] = tail
             arrs['%s.render_mse' % tag] = np.float64(mse)
             arrs['%s.render_psnr' % tag] = np.float64(RU.mse2psnr(mse))
             if dtype == torch.float32:
@@ -593,10 +603,48 @@ def gen_trajectory(dtypes=(torch.float32, torch.float64), modes=None):
     save('trajectory', **arrs)
 
 
+SEED_STEPS = 1000
+
+
+def gen_trajectory_seeds(mode, seeds, part_dir):
+    """the float32 reference trained SEED_STEPS steps on the config-1 scene for several seeds of the batch /
+    uniform streams -- the reference's own seed spread at convergence, and paired reference runs for the HIP trainer's replay
+    (tests/test_gpu_round5.py).  One part file per (mode, seed) so that several processes can share the ~2 h of CPU;
+    `trajectory_seeds merge` collects them into tests/golden/trajectory_seeds.npz."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.makedirs(part_dir, exist_ok=True)
+    for seed in seeds:
+        tag = '%s.s%d' % (mode, seed)
+        logs, tail, rgb, depth, mse = run_ref_trajectory(mode, torch.float32, SEED_STEPS, seed, tag)
+        arrs = {'%s.%s' % (tag, k): np.array(v, np.float64) for k, v in logs.items() if k in ('rgb0', 'rgb1', 'depth1')}
+        arrs['%s.tail_rgb_mse' % tag] = tail
+        arrs['%s.render_mse' % tag] = np.float64(mse)
+        arrs['%s.render_psnr' % tag] = np.float64(RU.mse2psnr(mse))
+        np.savez_compressed(os.path.join(part_dir, tag + '.npz'), **arrs)
+        print(tag, 'render psnr', arrs['%s.render_psnr' % tag], flush=True)
+
+
+def merge_trajectory_seeds(part_dir):
+    arrs = {}
+    for f in sorted(os.listdir(part_dir)):
+        if f.endswith('.npz'):
+            arrs.update(dict(np.load(os.path.join(part_dir, f))))
+    arrs['steps'] = np.int64(SEED_STEPS)
+    save('trajectory_seeds', **arrs)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':      # ~30 min of CPU: on request only
         torch.set_num_threads(8)
         gen_trajectory(modes=tuple(sys.argv[2:]) or None)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == 'trajectory_seeds':    # ~15 min of CPU per (mode, seed): on request only
+        part_dir = os.environ.get('TRAJ_PART_DIR', '/tmp/traj_seed_parts')
+        if sys.argv[2] == 'merge':
+            merge_trajectory_seeds(part_dir)
+        else:                                                       # trajectory_seeds <mode> <seed> [<seed> ...]
+            torch.set_num_threads(int(os.environ.get('TRAJ_THREADS', '4')))
+            gen_trajectory_seeds(sys.argv[2], [int(x) for x in sys.argv[3:]], part_dir)
         sys.exit(0)
     gen_sampling()
     gen_embed()

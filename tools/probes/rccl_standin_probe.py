@@ -46,6 +46,8 @@ def main():
     p.add_argument('--blocks', type=int, default=5)
     p.add_argument('--steps', type=int, default=60)
     p.add_argument('--out', default='rccl_standin.json')
+    p.add_argument('--wgs', default='8,16,32', help='held workgroups (= RCCL channels) to try')
+    p.add_argument('--usecs', default='150,300')
     a = p.parse_args()
     dev = torch.device('cuda:0')
     scene = SyntheticKitti()
@@ -53,8 +55,8 @@ def main():
     batches = [batch_to_device(scene.random_batch(1024, rng), dev) for _ in range(a.steps)]
     GHZ = 2.0                                              # shader cycles per ns, nominal: the hold times below are +-10 %
     variants = {'none': None}
-    for n_wg in (8, 16, 32):
-        for usec in (150, 300):
+    for n_wg in [int(x) for x in a.wgs.split(',')]:
+        for usec in [int(x) for x in a.usecs.split(',')]:
             variants['%dwg_%dus' % (n_wg, usec)] = (n_wg, int(usec * 1e3 * GHZ))
     trainers = {}
     for k, v in variants.items():
