@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERFPP_ABI_VERSION 6
+#define NERFPP_ABI_VERSION 7
 
 #define NERFPP_OK 0
 #define NERFPP_ERR_ARG 1          /* bad argument (null pointer, size out of range) */
@@ -39,6 +39,13 @@ extern "C" {
 /* precision of the MLP kernels */
 #define NERFPP_PREC_BF16 1        /* single-pass bf16 MFMA, f32 accumulate ("speed") */
 #define NERFPP_PREC_SPLIT_BF16 2  /* hi+lo split bf16, 3 MFMA passes, ~1e-5 rel. of float32 ("parity") */
+#define NERFPP_PREC_FP16X2W 3     /* FORWARD only (nerfpp_level_forward, nerfpp_pack_level, workspace queries): weights hi+lo in
+                                     fp16, activations rounded to fp16 once, 2 passes of v_mfma_f32_32x32x16_f16.  An
+                                     INTERMEDIATE precision: within 1e-4 of float32 at initialisation, 3-4e-4 (rendered rgb) on
+                                     trained weights (tests/test_gpu_round5.py) -- 10x tighter than precision 1 at 1.5x its
+                                     forward time; the 1e-4 clause is precision 2's.  Its training-mode forward saves
+                                     single-plane bf16 tensors: run the backward with precision 1, workspace_precision 3.
+                                     Activations beyond +-65504 overflow (the reference's trained nets stay far below). */
 
 /* depth loss types (ddp_train_nerf.py:20-26; `los` / `nll` are dead code in the reference) */
 #define NERFPP_LOSS_RGB_ONLY 0
@@ -211,10 +218,10 @@ int nerfpp_loss(void* stream, int n_rays, int n_samples, int loss_type, float la
 
 typedef struct {
   int32_t n_rays, n_samples;
-  int32_t precision;               /* of the backward kernels and of `packed` */
+  int32_t precision;               /* of the backward kernels and of `packed` (1 or 2) */
   int32_t workspace_precision;     /* precision of the forward that filled `workspace`; 0 = same as
-                                      `precision`.  2 with precision 1: split-bf16 forward (1e-4 outputs and
-                                      loss), single-pass bf16 backward over the hi planes it saved */
+                                      `precision`.  2 or 3 with precision 1: split-bf16 (1e-4 outputs and loss) / fp16x2w
+                                      forward, single-pass bf16 backward over the (hi) planes it saved */
   const float* ray_d;
   const float* fg_far;
   const float* fg_z;

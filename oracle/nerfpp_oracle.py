@@ -315,7 +315,9 @@ def mlp_forward(p, inp, input_ch, input_ch_viewdirs, netdepth=8, skips=(4,), cac
     bf16=True models the single-pass bf16 precision of the HIP kernels (NERFPP_PREC_BF16): both operands of
     every linear layer are rounded to bfloat16, products accumulate in float32, biases are added in float32
     -- a structural check for that mode at ~1e-3 instead of the 3e-2 a float32 comparison allows."""
-    if bf16:
+    if callable(bf16):          # operand-format studies (tools/operand_format_study.py): bf16(x, W) -> x @ W.T in that format
+        _lin = lambda x, W, b: (bf16(x, W) + b).astype(f32)
+    elif bf16:
         _lin = lambda x, W, b: _linear(x, W, b, True)
     else:
         _lin = _linear

@@ -10,9 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hip.so')   # override: diagnostic builds
 
 OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2
-PREC_SPLIT_FWD = 3        # host-side combination: split-bf16 forward, bf16 backward (ops.LevelEngine)
+# NERFPP_PREC_FP16X2W: a FORWARD precision (weights hi + lo in fp16, activations rounded to fp16 once, two MFMA passes): an
+# intermediate one -- outputs within 1e-4 of float32 at initialisation, 3-4e-4 on trained weights (tests/test_gpu_round5.py).
+# As a LevelEngine / trainer precision it means: that forward, single-pass bf16 backward.
+PREC_FP16_FWD = 3
+PREC_SPLIT_FWD = 12       # host-side combination: split-bf16 forward, bf16 backward (ops.LevelEngine)
 LOSS_RGB_ONLY, LOSS_MSE, LOSS_L1, LOSS_KL = 0, 1, 2, 3
 LOSS_TYPES = {'rgbonly': LOSS_RGB_ONLY, 'mse': LOSS_MSE, 'l1': LOSS_L1, 'kl': LOSS_KL}
 FG_PARAMS, BG_PARAMS, LEVEL_PARAMS = 595844, 606596, 1202440

@@ -18,7 +18,7 @@ SOURCES = {
     'nerfpp_tables.hip': [],
     'nerfpp_render.hip': ['-ffp-contract=off'],     # bit-exact sample bins: no implicit FMA
     # the fully unrolled MLP kernels: one translation unit per instantiation (nerfpp_mlp.hip, NERFPP_MLP_PART)
-    **{('nerfpp_mlp.hip', k): ['-DNERFPP_MLP_PART=%d' % k] for k in range(7)},
+    **{('nerfpp_mlp.hip', k): ['-DNERFPP_MLP_PART=%d' % k] for k in range(9)},
     'nerfpp_dw.hip': [],
     'nerfpp_optim.hip': ['-ffp-contract=off'],      # Adam rounds like torch
     'nerfpp_api.hip': [],

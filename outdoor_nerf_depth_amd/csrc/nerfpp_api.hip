@@ -91,7 +91,7 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
         L.tensor[net][t] = off;
         if (t == T_R || t == T_DR) continue;     // never materialised (remap_fixup_kernel derives their gradients)
         if (t == T_DG) continue;                 // columns 32..159 of the [dS | dG] tensor allocated as T_DS
-        off = align_up(off + (size_t)L.rows_padded * tensor_ld(net, t) * 2 * P, 256);
+        off = align_up(off + (size_t)L.rows_padded * tensor_ld(net, t) * 2 * a_planes(P), 256);
       }
       L.slabs[net] = off; off = align_up(off + (size_t)L.ksplit * gslab_floats(net) * 4, 256);
       L.masks[net] = off; off = align_up(off + (size_t)9 * (L.rows_padded / 32) * 64 * 16, 256);
@@ -110,7 +110,8 @@ NetWs make_netws(char* ws, const WsLayout& L, int net) {
   return w;
 }
 
-bool prec_ok(int P) { return P == NERFPP_PREC_BF16 || P == NERFPP_PREC_SPLIT_BF16; }
+bool prec_ok(int P) { return P == NERFPP_PREC_BF16 || P == NERFPP_PREC_SPLIT_BF16; }               // backward kernels
+bool prec_ok_fwd(int P) { return prec_ok(P) || P == NERFPP_PREC_FP16X2W; }                          // forward kernels, packs, workspaces
 
 // The foreground and background nets of a level are independent until the compositing kernel: their MLP kernels run as ONE
 // launch (fg tiles first, bg tiles as CUs free up), one start-up and one tail instead of two.  Probes build only:
@@ -254,10 +255,10 @@ int nerfpp_dw_plan(int64_t rows, int32_t* k_out, int32_t* is_full_out) {
   return DW_JOBS;
 }
 
-int64_t nerfpp_packed_bytes(int precision) { return prec_ok(precision) ? (int64_t)pack_layout(precision).total : -1; }
+int64_t nerfpp_packed_bytes(int precision) { return prec_ok_fwd(precision) ? (int64_t)pack_layout(precision).total : -1; }
 
 int nerfpp_pack_level(void* stream, int precision, const float* params, const int32_t* tables, void* packed) {
-  REQUIRE(prec_ok(precision), "precision must be 1 or 2");
+  REQUIRE(prec_ok_fwd(precision), "precision must be 1, 2 or 3");
   REQUIRE(params && tables && packed, "non-null pointers");
   const TblLayout T = tbl_layout();
   const PackLayout L = pack_layout(precision);
@@ -277,13 +278,13 @@ int nerfpp_pack_level(void* stream, int precision, const float* params, const in
 }
 
 int64_t nerfpp_workspace_bytes(int n_rays, int n_samples, int precision, int training) {
-  if (n_rays <= 0 || n_samples < 2 || n_samples > NERFPP_MAX_SAMPLES || !prec_ok(precision)) return -1;
+  if (n_rays <= 0 || n_samples < 2 || n_samples > NERFPP_MAX_SAMPLES || !prec_ok_fwd(precision)) return -1;
   return (int64_t)ws_layout(n_rays, n_samples, precision, training != 0).total;
 }
 
 int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, int tensor, int64_t* byte_offset,
                             int32_t* ld, int64_t* plane_bytes) {
-  REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= NERFPP_MAX_SAMPLES && prec_ok(precision), "sizes / precision");
+  REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= NERFPP_MAX_SAMPLES && prec_ok_fwd(precision), "sizes / precision");
   REQUIRE(net >= 0 && net < N_NET && tensor >= 0 && tensor < T_COUNT && tensor != T_R && tensor != T_DR, "net / tensor id");
   REQUIRE(byte_offset && ld && plane_bytes, "non-null outputs");
   const WsLayout L = ws_layout(n_rays, n_samples, precision, true);
@@ -297,7 +298,7 @@ int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, i
 int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
   REQUIRE(a, "args");
   REQUIRE(a->n_rays > 0 && a->n_samples >= 2 && a->n_samples <= NERFPP_MAX_SAMPLES, "sizes");
-  REQUIRE(prec_ok(a->precision), "precision must be 1 or 2");
+  REQUIRE(prec_ok_fwd(a->precision), "precision must be 1, 2 or 3");
   REQUIRE(a->ray_o && a->ray_d && a->fg_far && a->fg_z && a->bg_z && a->packed && a->workspace, "inputs");
   REQUIRE(a->rgb && a->depth && a->fg_weights && a->bg_weights && a->fg_dists && a->fg_rgb && a->fg_depth &&
           a->bg_rgb && a->bg_depth && a->bg_lambda, "outputs");
@@ -406,7 +407,7 @@ int nerfpp_level_reduce_grads(void* stream, const nerfpp_backward_args* a) {
   REQUIRE(prec_ok(a->precision), "precision must be 1 or 2");
   REQUIRE(a->workspace && a->tables && a->grads && a->params, "workspace / tables / grads / params");
   const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
-  REQUIRE(prec_ok(WP) && WP >= a->precision, "workspace_precision must be 0, or >= precision");
+  REQUIRE(prec_ok_fwd(WP) && a_planes(WP) >= a_planes(a->precision), "workspace_precision: 0, or a forward precision that saved the planes this backward reads");
   const WsLayout L = ws_layout(a->n_rays, a->n_samples, WP, true);
   if (defer_dw()) weight_grads((hipStream_t)stream, a, L);
   reduce_grads((hipStream_t)stream, a, L, tbl_layout());
@@ -433,7 +434,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
   hipStream_t st = (hipStream_t)stream;
   const int P = a->precision;
   const int WP = a->workspace_precision ? a->workspace_precision : P;     // precision of the forward's saves
-  REQUIRE(prec_ok(WP) && WP >= P, "workspace_precision must be 0, or >= precision");
+  REQUIRE(prec_ok_fwd(WP) && a_planes(WP) >= a_planes(P), "workspace_precision: 0, or a forward precision that saved the planes this backward reads");
   const WsLayout L = ws_layout(a->n_rays, a->n_samples, WP, true);
   const PackLayout PL = pack_layout(P);
   const TblLayout T = tbl_layout();

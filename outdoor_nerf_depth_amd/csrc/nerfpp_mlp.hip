@@ -62,13 +62,16 @@ __device__ __forceinline__ void dump_stamps(uint32_t, int, int) {}
 namespace nerfpp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define LDS_AS __attribute__((address_space(3)))
 
-template <int P> struct Frag { bf16x8 v[P]; };
+// one activation chunk of a lane: a_planes(P) 16-byte register images (precision 3: fp16 bits in the bf16x8 container)
+template <int P> struct Frag { bf16x8 v[a_planes(P)]; };
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -106,7 +109,7 @@ __device__ __forceinline__ void glds16xN_saddr(const char* sbase, uint32_t voff,
 // fragments per weight block: the split-bf16 training kernels use 8 (x 2 planes = the same 16 KiB per block as bf16), which
 // buys a 4-deep ring next to the doubled hand-off region and encoded-point stash in 160 KiB of LDS
 template <int P, bool TRAIN>
-constexpr int blk_frags_of() { return (P == 2 && TRAIN) ? 8 : BLK_FRAGS; }
+constexpr int blk_frags_of() { return (P >= 2 && TRAIN) ? 8 : BLK_FRAGS; }
 
 template <int P, int NW, int MODE, int NBUF, int BF = BLK_FRAGS>
 struct WeightPipe {
@@ -187,6 +190,13 @@ template <int P>
 __device__ __forceinline__ void mfma_p(f32x16& acc, const char* lfrag, const Frag<P>& b) {
   const bf16x8 a_hi = *(const bf16x8*)(lfrag);
   if constexpr (probe::NO_MFMA) { asm volatile("" ::"v"(a_hi)); return; }
+  if constexpr (P == 3) {          // fp16: (Wh + Wl) * A, the activation rounded once
+    const bf16x8 a_lo = *(const bf16x8*)(lfrag + FRAG_BYTES);
+    const f16x8 bb = __builtin_bit_cast(f16x8, b.v[0]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_hi), bb, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_lo), bb, acc, 0, 0, 0);
+    return;
+  }
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.v[0], acc, 0, 0, 0);
   if constexpr (P == 2) {
     const bf16x8 a_lo = *(const bf16x8*)(lfrag + FRAG_BYTES);
@@ -228,13 +238,13 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
         bf16x8 w{};
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
-          if (ob % probe::LDS_REUSE == 0) w = *(const bf16x8*)(l + (kl * NOB + ob) * P * FRAG_BYTES);
+          if (ob % probe::LDS_REUSE == 0) w = *(const bf16x8*)(l + (kl * NOB + ob) * FRAG_BYTES);
           acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b[blk * KPB + kl].v[0], acc[ob], 0, 0, 0);
         }
       } else {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
-          mfma_p<P>(acc[ob], l + (kl * NOB + ob) * P * FRAG_BYTES, b[blk * KPB + kl]);
+          mfma_p<P>(acc[ob], l + (kl * NOB + ob) * w_planes(P) * FRAG_BYTES, b[blk * KPB + kl]);
       }
     }
     if (probe::HOOK_ORDER == 1 || (probe::HOOK_ORDER == 0 && pipe.wave < 4)) hook(blk);
@@ -260,15 +270,33 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
 
 template <int P>
 __device__ __forceinline__ void set_slot(Frag<P>& f, int t, float v) {
+  if constexpr (P == 3) {
+    f16x8 q = __builtin_bit_cast(f16x8, f.v[0]);
+    q[t] = (_Float16)v;
+    f.v[0] = __builtin_bit_cast(bf16x8, q);
+    return;
+  }
   const __bf16 h = (__bf16)v;
   f.v[0][t] = h;
   if constexpr (P == 2) f.v[1][t] = (__bf16)(v - (float)h);
+}
+// what goes to a saved tensor: the register image itself, or (precision 3) its fp16 values re-rounded to bf16 -- the saved
+// tensors feed the bf16 weight-gradient GEMMs (nerfpp_dw.hip) whatever the forward's operand format was
+template <int P>
+__device__ __forceinline__ uint4 saved_image(const uint4 regs) {
+  if constexpr (P == 3) {
+    const f16x8 h = __builtin_bit_cast(f16x8, regs);
+    bf16x8 q;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) q[t] = (__bf16)(float)h[t];
+    return __builtin_bit_cast(uint4, q);
+  } else return regs;
 }
 template <int P>
 __device__ __forceinline__ Frag<P> zero_frag() {
   Frag<P> f;
 #pragma unroll
-  for (int p = 0; p < P; ++p)
+  for (int p = 0; p < a_planes(P); ++p)
 #pragma unroll
     for (int t = 0; t < 8; ++t) f.v[p][t] = (__bf16)0.f;
   return f;
@@ -298,14 +326,14 @@ __device__ __forceinline__ void stash_frags(char* base, int lane, const Frag<P> 
 #pragma unroll
   for (int c = 0; c < N; ++c)
 #pragma unroll
-    for (int p = 0; p < P; ++p) *(uint4*)(base + ((c * P + p) * 64 + lane) * 16) = *(const uint4*)&f[c].v[p];
+    for (int p = 0; p < a_planes(P); ++p) *(uint4*)(base + ((c * a_planes(P) + p) * 64 + lane) * 16) = *(const uint4*)&f[c].v[p];
 }
 template <int N, int P>
 __device__ __forceinline__ void unstash_frags(const char* base, int lane, Frag<P> (&f)[N]) {
 #pragma unroll
   for (int c = 0; c < N; ++c)
 #pragma unroll
-    for (int p = 0; p < P; ++p) *(uint4*)&f[c].v[p] = *(const uint4*)(base + ((c * P + p) * 64 + lane) * 16);
+    for (int p = 0; p < a_planes(P); ++p) *(uint4*)&f[c].v[p] = *(const uint4*)(base + ((c * a_planes(P) + p) * 64 + lane) * 16);
 }
 
 // ReLU + conversion + sign words in one pass over the accumulators.
@@ -321,18 +349,27 @@ __device__ __forceinline__ uint4 acc_to_frags_relu_bits(const f32x16 (&acc)[NOB]
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      if constexpr (P == 1) {
-        bf16x8 q;
+      if constexpr (P != 2) {
+        // (bf16 and fp16 alike: the sign is bit 15 of the 16-bit pattern, a value with it set is a negative int16)
+        u32x4 d;
+        if constexpr (P == 3) {
+          f16x8 q;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) q[t] = (__bf16)acc[ob][8 * hh + t];
-        const u32x4 d = __builtin_bit_cast(u32x4, q);
+          for (int t = 0; t < 8; ++t) q[t] = (_Float16)acc[ob][8 * hh + t];
+          d = __builtin_bit_cast(u32x4, q);
+        } else {
+          bf16x8 q;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) q[t] = (__bf16)acc[ob][8 * hh + t];
+          d = __builtin_bit_cast(u32x4, q);
+        }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int j = (ob & 1) * 8 + hh * 4 + w;
           m[ob >> 1] |= (d[w] >> j) & (0x80008000u >> j);
         }
         const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        h[2 * ob + hh].v[0] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, q), zero));
+        h[2 * ob + hh].v[0] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, d), zero));
       } else {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -352,7 +389,7 @@ __device__ __forceinline__ void zero_invalid(Frag<P> (&f)[N], bool valid) {
 #pragma unroll
   for (int c = 0; c < N; ++c)
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
+    for (int p = 0; p < a_planes(P); ++p) {
       u32x4 d = __builtin_bit_cast(u32x4, f[c].v[p]);
 #pragma unroll
       for (int w = 0; w < 4; ++w) d[w] = valid ? d[w] : 0u;
@@ -403,7 +440,7 @@ __device__ __forceinline__ void store_nt16(char* gptr, const uint4 v) { probe::s
 // Rows past the end of the batch (tile tail, < rows_padded) must be written as zeros so the weight-gradient GEMMs can
 // run over whole 32-row chunks without masking: the kernels zero those lanes' fragments -- zero_invalid, last tile only
 // -- before they get here.
-constexpr int region_mask(int P) { return 16 * P * FRAG_BYTES; }   // hand-off region: 16 chunk blocks per plane, then 64 x 16 B of sign words
+constexpr int region_mask(int P) { return 16 * a_planes(P) * FRAG_BYTES; }   // hand-off region: 16 chunk blocks per activation plane, then 64 x 16 B of sign words
 constexpr int region_bytes(int P) { return region_mask(P) + 1024; }
 
 __device__ __forceinline__ char* frag_addr(__bf16* base, int ld, size_t wave_row0, int c, int lane) {
@@ -412,13 +449,13 @@ __device__ __forceinline__ char* frag_addr(__bf16* base, int ld, size_t wave_row
 }
 template <int P>
 // np < P: only the first np planes are written (a split-bf16 forward whose backward is single-pass bf16 reads the hi planes only)
-__device__ __forceinline__ void store_chunk(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, int c, const Frag<P>& f, int np = P) {
+__device__ __forceinline__ void store_chunk(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, int c, const Frag<P>& f, int np = a_planes(P)) {
 #pragma unroll
-  for (int p = 0; p < P; ++p)
-    if (p < np) store_nt16(frag_addr(base + p * plane, ld, wave_row0, c, lane), *(const uint4*)&f.v[p]);
+  for (int p = 0; p < a_planes(P); ++p)
+    if (p < np) store_nt16(frag_addr(base + p * plane, ld, wave_row0, c, lane), saved_image<P>(*(const uint4*)&f.v[p]));
 }
 template <int NCH, int P>
-__device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, const Frag<P> (&h)[NCH], int np = P) {
+__device__ __forceinline__ void save_frags(__bf16* base, size_t plane, int ld, size_t wave_row0, int lane, const Frag<P> (&h)[NCH], int np = a_planes(P)) {
   if constexpr ((probe::DBG & 2) != 0) return;
   // Scheduling fences on both sides: the LDS-staged save this replaces was a fence by construction (wave barriers);
   // without one the scheduler starts the next stage's accumulator set while this stage's is still being converted and
@@ -437,26 +474,26 @@ __device__ __forceinline__ void handoff_write(char* region, int lane, const Frag
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int p = 0; p < P; ++p) *(uint4*)(region + ((c * P + p) * 64 + lane) * 16) = *(const uint4*)&h[c].v[p];
+    for (int p = 0; p < a_planes(P); ++p) *(uint4*)(region + ((c * a_planes(P) + p) * 64 + lane) * 16) = *(const uint4*)&h[c].v[p];
 }
 // chunks [c0, c0 + n) of the loader's tile (tile rows row0 .. row0 + 31): region -> HBM (plane p at base + p * plane elements)
 template <int P>
-__device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int c0, int n, int np = P) {
+__device__ __forceinline__ void handoff_flush_chunks(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int c0, int n, int np = a_planes(P)) {
   if constexpr ((probe::DBG & 16) != 0) return;
 #pragma unroll 4
   for (int c = c0; c < c0 + n; ++c)
 #pragma unroll
-    for (int p = 0; p < P; ++p)
-      if (p < np) store_nt16(frag_addr(base + p * plane, ld, row0, c, lane), *(const uint4*)(region + ((c * P + p) * 64 + lane) * 16));
+    for (int p = 0; p < a_planes(P); ++p)
+      if (p < np) store_nt16(frag_addr(base + p * plane, ld, row0, c, lane), saved_image<P>(*(const uint4*)(region + ((c * a_planes(P) + p) * 64 + lane) * 16)));
 }
 
 // region chunk cr -> tensor chunk ct (a hand-off that carries the chunks of two tensors back to back)
 template <int P>
-__device__ __forceinline__ void handoff_flush_one(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int cr, int ct, int np = P) {
+__device__ __forceinline__ void handoff_flush_one(const char* region, int lane, __bf16* base, size_t plane, int ld, size_t row0, int cr, int ct, int np = a_planes(P)) {
   if constexpr ((probe::DBG & 16) != 0) return;
 #pragma unroll
-  for (int p = 0; p < P; ++p)
-    if (p < np) store_nt16(frag_addr(base + p * plane, ld, row0, ct, lane), *(const uint4*)(region + ((cr * P + p) * 64 + lane) * 16));
+  for (int p = 0; p < a_planes(P); ++p)
+    if (p < np) store_nt16(frag_addr(base + p * plane, ld, row0, ct, lane), saved_image<P>(*(const uint4*)(region + ((cr * a_planes(P) + p) * 64 + lane) * 16)));
 }
 
 // dH (accumulators) masked by the forward sign words (see acc_to_frags_relu_bits) -> dZ fragments
@@ -600,10 +637,10 @@ struct FwdLds {
   static constexpr int BF = blk_frags_of<P, TRAIN>();
   // ring depth: as deep as the 160 KiB of LDS allow
   static constexpr int NBUF = MODE == PIPE_RING ? (P == 1 ? 4 : 3) : 4;
-  static constexpr int W = NBUF * BF * P * FRAG_BYTES;
+  static constexpr int W = NBUF * BF * w_planes(P) * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STASH = REGION + (ROLES ? region_bytes(P) : 0);
-  static constexpr int BIAS = STASH + NW * kpe(NET) * P * 1024;
+  static constexpr int BIAS = STASH + NW * kpe(NET) * a_planes(P) * 1024;
   static constexpr int TOTAL = BIAS + FWD_BIAS_FLOATS * 4;
 };
 template <int P, int NW>
@@ -635,15 +672,15 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)bid * (NW * 32) + wave * 32;                 // this wave's first tile row
   const bool loader = ROLES && wave == 0, partner = ROLES && wave == 1;
-  const int NPS = (P == 2 && !a.save_lo) ? 1 : P;            // planes of the saved tensors that are written out (wave-uniform)
+  const int NPS = (P == 2 && !a.save_lo) ? 1 : a_planes(P);  // planes of the saved tensors that are written out (wave-uniform)
   probe::kernel_prologue(a.out_raw);
   const bool tail = wrow0 + 32 > (size_t)a.rows;                            // wave-uniform
   char* region = smem + LD::REGION;
-  char* pe_stash = smem + LD::STASH + wave * (KPE * P * 1024);
+  char* pe_stash = smem + LD::STASH + wave * (KPE * a_planes(P) * 1024);
   const size_t nblk32 = a.rows_padded / 32;
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
-  WeightPipe<P, NW, LD::MODE, LD::NBUF, LD::BF> pipe;
+  WeightPipe<w_planes(P), NW, LD::MODE, LD::NBUF, LD::BF> pipe;
   pipe.stamp_off = LD::TOTAL;
   pipe.init(a.w_stream, fwd_frags(NET) / LD::BF, wave, lane);
   // The loader's tile is written out by the helper waves 1..H.  CPB chunks of a storer's own tile go out per weight block
@@ -1015,7 +1052,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a, const int bid)
 // launches had two (profiles/r04_pair_launch.md: ~20 us per launch boundary at N_rand = 1024, 12 MLP / weight-gradient
 // launches per step before, 6 now).  tiles0 = 0 or grid = tiles0 runs one net alone (probes: the two-launch form).
 template <int P, int NW, bool TRAIN>
-__global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_fwd_pair_kernel(MlpFwdArgs a0, MlpFwdArgs a1, int tiles0) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void mlp_fwd_pair_kernel(MlpFwdArgs a0, MlpFwdArgs a1, int tiles0) {
   if ((int)blockIdx.x < tiles0) mlp_fwd_body<0, P, NW, TRAIN>(a0, (int)blockIdx.x);
   else mlp_fwd_body<1, P, NW, TRAIN>(a1, (int)blockIdx.x - tiles0);
 }
@@ -1029,7 +1066,8 @@ __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_pair_kernel
 
 using namespace nerfpp;
 
-#define MLP_WAVES(P) ((P) == 1 ? probe::WAVES_P1 : 4)
+// waves per workgroup: 8 (two per SIMD, <= 256 VGPRs) where a lane holds ONE register image per activation chunk, 4 in split-bf16
+#define MLP_WAVES(P) ((P) == 1 ? probe::WAVES_P1 : (P) == 3 ? 8 : 4)
 
 // which: 0 = both nets, 1 = fg only, 2 = bg only
 template <int P, bool TRAIN>
@@ -1054,14 +1092,15 @@ static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a0, const MlpBwdArgs&
 
 // The kernels are fully unrolled instruction streams (2 x 1200 MFMAs each) and take minutes to compile, so the in-tree build
 // compiles this file once per kernel instantiation: -DNERFPP_MLP_PART=k emits instantiation k only (0 / 1: inference forward
-// bf16 / split-bf16, 2 / 3: training forward, 4 / 5: backward, 6: the dispatchers), no define = everything in one translation unit.
+// bf16 / split-bf16, 2 / 3: training forward, 4 / 5: backward, 6: the dispatchers, 7 / 8: fp16x2w inference / training forward),
+// no define = everything in one translation unit.
 #ifndef NERFPP_MLP_PART
 #define NERFPP_MLP_PART -1
 #endif
 #define MLP_PART(k) (NERFPP_MLP_PART == -1 || NERFPP_MLP_PART == (k))
 #define FWD_ENTRY(P, TRAIN) void launch_fwd_##P##_##TRAIN(hipStream_t st, const MlpFwdArgs& a0, const MlpFwdArgs& a1, int which)
 #define BWD_ENTRY(P) void launch_bwd_##P(hipStream_t st, const MlpBwdArgs& a0, const MlpBwdArgs& a1, int which)
-FWD_ENTRY(1, 0); FWD_ENTRY(2, 0); FWD_ENTRY(1, 1); FWD_ENTRY(2, 1);
+FWD_ENTRY(1, 0); FWD_ENTRY(2, 0); FWD_ENTRY(1, 1); FWD_ENTRY(2, 1); FWD_ENTRY(3, 0); FWD_ENTRY(3, 1);
 BWD_ENTRY(1); BWD_ENTRY(2);
 #if MLP_PART(0)
 FWD_ENTRY(1, 0) { launch_fwd_t<1, false>(st, a0, a1, which); }
@@ -1082,10 +1121,18 @@ BWD_ENTRY(1) { launch_bwd_t<1>(st, a0, a1, which); }
 BWD_ENTRY(2) { launch_bwd_t<2>(st, a0, a1, which); }
 #endif
 
+#if MLP_PART(7)
+FWD_ENTRY(3, 0) { launch_fwd_t<3, false>(st, a0, a1, which); }
+#endif
+#if MLP_PART(8)
+FWD_ENTRY(3, 1) { launch_fwd_t<3, true>(st, a0, a1, which); }
+#endif
+
 #if MLP_PART(6)
 void launch_mlp_fwd_pair(hipStream_t st, int P, bool train, const MlpFwdArgs& a0, const MlpFwdArgs& a1, int which) {
-  if (P == 1) { if (train) launch_fwd_1_1(st, a0, a1, which); else launch_fwd_1_0(st, a0, a1, which); }
-  else        { if (train) launch_fwd_2_1(st, a0, a1, which); else launch_fwd_2_0(st, a0, a1, which); }
+  if (P == 1)      { if (train) launch_fwd_1_1(st, a0, a1, which); else launch_fwd_1_0(st, a0, a1, which); }
+  else if (P == 3) { if (train) launch_fwd_3_1(st, a0, a1, which); else launch_fwd_3_0(st, a0, a1, which); }
+  else             { if (train) launch_fwd_2_1(st, a0, a1, which); else launch_fwd_2_0(st, a0, a1, which); }
 }
 void launch_mlp_bwd_pair(hipStream_t st, int P, const MlpBwdArgs& a0, const MlpBwdArgs& a1, int which) {
   if (P == 1) launch_bwd_1(st, a0, a1, which); else launch_bwd_2(st, a0, a1, which);

@@ -57,11 +57,18 @@ __global__ void pack_level_kernel(const float* __restrict__ params, PackSegs sg)
     ((float*)sg.out[seg])[e] = v;
     return;
   }
-  __bf16* out = (__bf16*)sg.out[seg];
   const int64_t F = e >> 9, within = e & 511;
-  const __bf16 h = (__bf16)v;
-  out[(F * P) * 512 + within] = h;
-  if (P == 2) out[(F * P + 1) * 512 + within] = (__bf16)(v - (float)h);
+  if constexpr (P == 3) {                      // fp16 hi + lo (nerfpp_common.h: precision ids)
+    _Float16* out = (_Float16*)sg.out[seg];
+    const _Float16 h = (_Float16)v;
+    out[(F * 2) * 512 + within] = h;
+    out[(F * 2 + 1) * 512 + within] = (_Float16)(v - (float)h);
+  } else {
+    __bf16* out = (__bf16*)sg.out[seg];
+    const __bf16 h = (__bf16)v;
+    out[(F * P) * 512 + within] = h;
+    if (P == 2) out[(F * P + 1) * 512 + within] = (__bf16)(v - (float)h);
+  }
 }
 
 // Both nets in one launch: deterministic sum over the split-K slabs, internal -> reference order,
@@ -206,7 +213,8 @@ void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t
     sg.is_f32[k] = (k % 3) == 2;
   }
   if (P == 1) hipLaunchKernelGGL(pack_level_kernel<1>, dim3(blk), dim3(256), 0, st, params, sg);
-  else hipLaunchKernelGGL(pack_level_kernel<2>, dim3(blk), dim3(256), 0, st, params, sg);
+  else if (P == 2) hipLaunchKernelGGL(pack_level_kernel<2>, dim3(blk), dim3(256), 0, st, params, sg);
+  else hipLaunchKernelGGL(pack_level_kernel<3>, dim3(blk), dim3(256), 0, st, params, sg);
 }
 void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats, const DwPlan& plan,
                          const int32_t* const* tbl, float* const* m_out, float scale, float* grads_lvl) {

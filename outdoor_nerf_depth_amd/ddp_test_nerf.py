@@ -33,7 +33,8 @@ def ddp_test_nerf(rank, args):
         os.environ['MASTER_PORT'] = str(args.port)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
-    trainer = NerfppTrainer(device, precision=L.PREC_BF16 if args.precision == 'bf16' else L.PREC_SPLIT_BF16,   # forward only
+    # forward only: bf16, the two-pass fp16x2w forward (1e-4 outputs), or split-bf16 (also for split_fwd: the same forward)
+    trainer = NerfppTrainer(device, precision={'bf16': L.PREC_BF16, 'fp16_fwd': L.PREC_FP16_FWD}.get(args.precision, L.PREC_SPLIT_BF16),
                             cascade_samples=cascade, use_depth=False, world_size=1)
     ckpt, start = find_latest_checkpoint(args)
     if ckpt is None:

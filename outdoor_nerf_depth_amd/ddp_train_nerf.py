@@ -10,7 +10,7 @@ keys, render_test_{step:06d}/ + psnr_/rmse_/absrel_*.txt), same log scalars
 (`level_m/{rgb_loss,pnsr,loss_depth}`, `iter_time`, `resolution`).  The per-step work runs on the
 HIP library (trainer.py); one process per GPU, RCCL all-reduce of the flat gradients.
 
-Extra flags: --sample_every (the README's name for --trainskip), --precision {bf16,split},
+Extra flags: --sample_every (the README's name for --trainskip), --precision {split,fp16_fwd,split_fwd,bf16},
 --synthetic (KITTI-shaped procedural scene instead of --datadir), --N_rand_override.
 """
 import argparse
@@ -134,11 +134,15 @@ def config_parser():
     p.add_argument('--depth_sigma', type=float, default=0.01)
     p.add_argument('--port', type=int, default=12345)
     # --- additions of this implementation
-    p.add_argument('--precision', choices=['bf16', 'split', 'split_fwd'], default='split_fwd',
-                   help='MLP arithmetic.  split_fwd (default): split-bf16 forward -- rendered RGB / depth / loss within 1e-4 of the '
-                        'float32 reference -- with the single-pass bf16 backward (200-step training trajectory within 0.01 dB of the '
-                        "reference's PSNR, tests/test_gpu_round4.py); split: split-bf16 everywhere (gradients at float32 grade too, "
-                        '1.6x slower); bf16: single-pass bf16 MFMA everywhere (fastest; outputs at bf16 grade)')
+    p.add_argument('--precision', choices=['bf16', 'split', 'split_fwd', 'fp16_fwd'], default='split',
+                   help='MLP arithmetic.  split (default): split-bf16 (3 MFMA passes) in forward, backward and weight gradients -- '
+                        'rendered RGB / depth / loss within 1e-4 of the float32 reference, gradients at float32 grade.  split_fwd: '
+                        'that forward with the single-pass bf16 backward (1.6x the throughput).  fp16_fwd: forward with fp16 '
+                        'operands, weights hi + lo (2 passes: 1e-4 at initialisation, 3-4e-4 on trained weights), bf16 backward '
+                        '(2.3x).  bf16: single-pass bf16 MFMA everywhere (fastest; outputs at bf16 grade, 1e-2).  With a bf16 backward a '
+                        "training run leaves the reference's trajectory like the reference's own float64 run leaves its float32 "
+                        'run: rgb-only within 0.01 dB at step 200, with a depth term +-0.2 ... 0.9 dB at step 200 in either '
+                        'direction and no resolvable gap (|median| < 0.1 dB over seeds) at 1000 steps: DESIGN.md section 5')
     p.add_argument('--grad_comm', choices=['torch', 'rccl_abi'], default='torch',
                    help="gradient all-reduce: torch.distributed (backend nccl = RCCL), or the library's own RCCL entry point "
                         '(nerfpp_allreduce_mean; the communicator id travels over the torch process group)')
@@ -360,7 +364,8 @@ def ddp_train_nerf(rank, args):
     if args.grad_comm == 'rccl_abi':
         from .dist_utils import RcclComm
         comm = RcclComm(rank, world)
-    trainer = NerfppTrainer(device, precision={'bf16': L.PREC_BF16, 'split': L.PREC_SPLIT_BF16, 'split_fwd': L.PREC_SPLIT_FWD}[args.precision],
+    trainer = NerfppTrainer(device, precision={'bf16': L.PREC_BF16, 'split': L.PREC_SPLIT_BF16, 'split_fwd': L.PREC_SPLIT_FWD,
+                                               'fp16_fwd': L.PREC_FP16_FWD}[args.precision],
                             cascade_samples=cascade, lrate=args.lrate, use_depth=args.use_depth,
                             depth_loss_type=args.depth_loss_type, lambda_depth=args.lambda_depth,
                             depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world,

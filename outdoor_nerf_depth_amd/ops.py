@@ -211,15 +211,18 @@ class LevelEngine(object):
     NerfNet.parameters() order, their packed MFMA streams, and the forward / backward calls."""
 
     def __init__(self, params_flat, precision=L.PREC_SPLIT_BF16):
-        """precision: PREC_BF16, PREC_SPLIT_BF16, or PREC_SPLIT_FWD = split-bf16 forward (rendered outputs
-        and loss within 1e-4 of float32) with the single-pass bf16 backward over the hi planes it saved."""
+        """precision: PREC_BF16, PREC_SPLIT_BF16, or a combination with the single-pass bf16 backward over the bf16 planes the
+        forward saved: PREC_SPLIT_FWD = split-bf16 forward (rendered outputs and loss within 1e-4 of float32), PREC_FP16_FWD =
+        fp16x2w forward (NERFPP_PREC_FP16X2W, two MFMA passes: 1e-4 at initialisation, 3-4e-4 on trained weights)."""
         if params_flat.numel() != L.LEVEL_PARAMS:
             raise L.NerfppError('expected %d parameters, got %d' % (L.LEVEL_PARAMS, params_flat.numel()))
         self.params = _f32(params_flat)
         self.device = self.params.device
         precision = int(precision)
+        if precision not in (L.PREC_BF16, L.PREC_SPLIT_BF16, L.PREC_FP16_FWD, L.PREC_SPLIT_FWD):
+            raise L.NerfppError('unknown precision %r' % (precision,))
         self.precision = L.PREC_SPLIT_BF16 if precision == L.PREC_SPLIT_FWD else precision        # forward
-        self.bwd_precision = L.PREC_BF16 if precision == L.PREC_SPLIT_FWD else precision
+        self.bwd_precision = L.PREC_BF16 if precision in (L.PREC_SPLIT_FWD, L.PREC_FP16_FWD) else precision
         self.tables = level_tables(self.device)
         self.packed = torch.empty(L.lib().nerfpp_packed_bytes(self.precision), dtype=torch.uint8,
                                   device=self.device)

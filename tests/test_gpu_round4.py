@@ -138,6 +138,22 @@ def _dump(name, report):
 # the first four (steps 25-100).  Measured (profiles/r04_trajectory_*.json): split-bf16 <= 0.0017 / 0.0135, split_fwd <= 0.0024 /
 # 0.037, bf16 <= 0.0098 / 0.0675 -- the trajectories coincide with the reference's and then separate exponentially.
 EARLY_GATE = {'split_bf16': (5e-3, 4e-2), 'split_fwd': (1e-2, 1e-1), 'bf16': (3e-2, 2e-1)}
+# PSNR tolerance at the end of the 200-step run, in units of the reference's OWN float64 - float32 spread on the same run (its
+# noise floor: a 1e-7 perturbation of the float32 reference moves its final PSNR by that much).  split-bf16 reproduces the
+# reference's arithmetic to 1e-5 and is held to 2 x the spread (this gate stays where it was when it was
+# introduced); the modes whose GRADIENTS are single-pass bf16 (split_fwd, fp16_fwd, bf16) perturb every step at the 1e-2 level
+# of the gradient and get 3 x -- their measured gaps on gt + mse are +0.17 / +0.25 dB (split_fwd) and +0.19 / +0.28 dB (bf16)
+# against a spread of 0.10 dB, and re-draw with every change of a kernel's summation order.  Floor: north_star's 0.05 dB.
+PSNR_SPREADS = {'split_bf16': 2.0, 'split_fwd': 3.0, 'fp16_fwd': 3.0, 'bf16': 3.0}
+
+
+def psnr_tolerances(g, mode, name):
+    import trajectory_common as TC
+    ref_tail = float(np.mean(TC.psnr(g[mode + '.f32.tail_rgb_mse'][:, 1])))
+    f64_tail = float(np.mean(TC.psnr(g[mode + '.f64.tail_rgb_mse'][:, 1])))
+    f64_gap = abs(float(g[mode + '.f64.render_psnr']) - float(g[mode + '.f32.render_psnr']))
+    k = PSNR_SPREADS[name]
+    return max(0.05, k * f64_gap), max(0.05, k * abs(f64_tail - ref_tail))
 
 
 @pytest.mark.parametrize('mode', ['rgbonly', 'mse', 'l1', 'kl'])
@@ -146,8 +162,9 @@ def test_training_trajectory_psnr_against_reference(mode):
     and with each depth term of the BASELINE configs (gt + mse, stereo_crop + l1, mono_crop + kl); the HIP trainer replays the
     same batches and uniforms in every precision mode.
     Gates, all modes: the logged rgb loss follows the reference's over the first 100 steps (EARLY_GATE).
-    rgb-only and gt + mse: every precision ends within max(0.05 dB, 2 x the reference's own float64-float32 spread) of the
-    float32 reference in render PSNR and in the mean in-loop PSNR of the last 25 steps (north_star's PSNR clause).
+    rgb-only and gt + mse: every precision ends within max(0.05 dB, k x the reference's own float64-float32 spread) of the
+    float32 reference in render PSNR and in the mean in-loop PSNR of the last 25 steps (north_star's PSNR clause); k = 2 for
+    split-bf16, 3 for the bf16-gradient modes (PSNR_SPREADS above).
     stereo_crop + l1 and mono_crop + kl: at step 200 these runs are in the steep part of training (25 -> 35 dB between steps 200
     and 1000) and ANY perturbation moves the PSNR AT A FIXED STEP by tenths of a dB to 2 dB in either direction -- split-bf16,
     which reproduces the reference's arithmetic to 1e-5, ends -0.70 / -0.24 dB (kl) and +0.02 / -0.03 dB (l1) from it, the
@@ -173,14 +190,13 @@ def test_training_trajectory_psnr_against_reference(mode):
                         'logged_rgb0_mse_rel_dev': [float(x) for x in np.abs(logged[:, 0] / g[mode + '.f32.rgb0'] - 1.0)],
                         'image_rms_vs_reference': float(np.sqrt(np.mean((im.reshape(-1, 3) - g[mode + '.f32.render_rgb']) ** 2)))}
     # With a depth term the 200-step trajectory is chaotic at the 0.1 dB level even for the reference -- its own float64 run
-    # ends 0.09-0.14 dB from its float32 run (a 1e-7 perturbation) -- so the tolerance is 3 x that spread: nothing can be
-    # pinned to the float32 run tighter than the reference pins itself, and every change of the summation order inside a
-    # kernel re-draws these gaps (gt + mse, bf16: +0.09 / +0.13 dB before the remap layer was folded, +0.19 / +0.28 after).
+    # ends 0.09-0.14 dB from its float32 run (a 1e-7 perturbation): nothing can be pinned to the float32 run tighter than the
+    # reference pins itself, and every change of the summation order inside a kernel re-draws these gaps (gt + mse, bf16:
+    # +0.09 / +0.13 dB before the remap layer was folded, +0.19 / +0.28 after).  Tolerances: psnr_tolerances above.
     f64_tail = float(np.mean(TC.psnr(g[mode + '.f64.tail_rgb_mse'][:, 1])))
     steep = mode in ('l1', 'kl')
-    tol_r = max(0.05, 3.0 * f64_gap)
-    tol_t = max(0.05, 3.0 * abs(f64_tail - ref_tail))
-    report['gate'] = {'render_tolerance_db': tol_r, 'tail_tolerance_db': tol_t, 'reference_f64_gap_db': f64_gap,
+    tols = {name: psnr_tolerances(g, mode, name) for name in ('split_bf16', 'split_fwd', 'bf16')}
+    report['gate'] = {'tolerances_db_render_tail': tols, 'spreads': PSNR_SPREADS, 'reference_f64_gap_db': f64_gap,
                       'reference_f64_tail_gap_db': f64_tail - ref_tail, 'early': EARLY_GATE,
                       'psnr_gated': [] if steep else ['split_bf16', 'split_fwd', 'bf16']}
     _dump('trajectory_%s.json' % mode, report)
@@ -190,8 +206,8 @@ def test_training_trajectory_psnr_against_reference(mode):
             assert dev_log[0] <= EARLY_GATE[name][0] and max(dev_log[:4]) <= EARLY_GATE[name][1], (name, key, dev_log)
         if steep:
             continue
-        assert abs(report[name]['render_gap_db']) <= tol_r, (name, report[name], tol_r)
-        assert abs(report[name]['tail_gap_db']) <= tol_t, (name, report[name], tol_t)
+        assert abs(report[name]['render_gap_db']) <= tols[name][0], (name, report[name], tols[name])
+        assert abs(report[name]['tail_gap_db']) <= tols[name][1], (name, report[name], tols[name])
 
 
 @pytest.mark.parametrize('mode', ['l1', 'kl'])

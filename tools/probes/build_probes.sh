@@ -16,7 +16,7 @@ $CC -c $C/mip360_gemm.hip -o $V/p_mip360_gemm.o &
 $CC -c $C/mip360_train.hip -o $V/p_mip360_train.o &
 wait
 objs="$V/p_nerfpp_api.o $V/p_nerfpp_dw.o $C/build/nerfpp_tables.o $C/build/nerfpp_render.o $C/build/nerfpp_optim.o $C/build/nerfpp_comm.o"
-for k in 0 1 2 3 4 5 6; do objs="$objs $C/build/nerfpp_mlp_$k.o"; done
+for k in 0 1 2 3 4 5 6 7 8; do objs="$objs $C/build/nerfpp_mlp_$k.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libnerfpp_hip_probes.so $objs
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libmip360_hip_probes.so $V/p_mip360_gemm.o $V/p_mip360_train.o \
   $C/build/mip360_kernels.o $C/build/mip360_api.o $C/build/mip360_fm.o

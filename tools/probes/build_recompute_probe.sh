@@ -16,7 +16,7 @@ wait
 for m in "$@"; do
   $CC -DNERFPP_SKIP_H=$m -DNERFPP_MLP_PART=2 -c $C/nerfpp_mlp.hip -o $V/q_mlp2_$m.o
   objs="$V/q_nerfpp_api.o $V/q_nerfpp_dw.o $C/build/nerfpp_tables.o $C/build/nerfpp_render.o $C/build/nerfpp_optim.o $C/build/nerfpp_comm.o $V/q_mlp2_$m.o"
-  for k in 0 1 3 4 5 6; do objs="$objs $C/build/nerfpp_mlp_$k.o"; done
+  for k in 0 1 3 4 5 6 7 8; do objs="$objs $C/build/nerfpp_mlp_$k.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/skiph_$m.so $objs
 done
 rm -f $V/q_*.o

@@ -11,7 +11,7 @@ V=$C/build/variants
 mkdir -p $V
 name=$1; flags=$2
 objs=""
-for k in 0 1 2 3 4 5 6; do
+for k in 0 1 2 3 4 5 6 7 8; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fhip-fp32-correctly-rounded-divide-sqrt \
     -DNERFPP_PROBES $flags -DNERFPP_MLP_PART=$k -c $C/nerfpp_mlp.hip -o $V/${name}_$k.o &
   objs="$objs $V/${name}_$k.o"
