@@ -19,7 +19,10 @@ Every trainer is set up with SETUP_STEPS untimed steps (code objects, workspaces
 an MI355X needs ~20 ms of load after any idle, profiles/r03_step_curve.json) before the W warm-up and K timed steps.
 
 value               : single-pass bf16 MFMA operands (the arithmetic north_star names), rays/s over all GPUs
+end_to_end          : what a user of the drop-in loop gets: ddp_train_nerf() itself on the 295-frame scene (cli_loop.device_sampler),
+                      and trained_state_ms = the kernel-only step on that loop's trained state
 parity_forward_mode : split-bf16 forward (rendered RGB / depth / loss within 1e-4 of float32) + bf16 backward
+fp16_forward_mode   : fp16x2w forward (2 MFMA passes; 1e-4 at initialisation, 3-4e-4 on trained weights: NOT the 1e-4 clause) + bf16 backward
 parity_mode         : split-bf16 everywhere (3 MFMA passes): the mode the 1e-4 parity tests run in
 gates               : which test gate each of those numbers has passed
 roofline            : SURVEY 8(d): algorithmic dense-layer FLOP (1.797 GFLOP per ray-step) against the dense
@@ -58,8 +61,20 @@ SETUP_STEPS = 12                 # untimed steps run when a trainer is set up, b
 # HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16: PARSED at start-up from the rocprofv3 --pmc passes committed
 # under profiles/ (they cannot be collected inside this process: separate --pmc runs, MI355X_MICROARCH.md "HBM").  The
 # field is named `traffic_from_profile`-style in the output (`traffic_source`), it is not a live measurement.
-PMC_PROFILE = os.path.join('profiles', 'r04_final_kernel_stats_timeline_hbm.md')
-PMC_PROFILE_FALLBACK = os.path.join('profiles', 'r03_final_kernel_stats_timeline_hbm.md')
+PMC_PROFILE = os.path.join('profiles', 'r05_final_kernel_stats_timeline_hbm.md')
+PMC_PROFILE_FALLBACK = os.path.join('profiles', 'r04_final_kernel_stats_timeline_hbm.md')
+# kernel sources whose change invalidates the committed PMC numbers: the profile records their sha256 (`sources_sha256:` line,
+# written by tools/probes/assemble_profile.py); a mismatch turns `traffic` into null with the reason in `traffic_source`, and
+# tests/test_host_logic.py::test_committed_pmc_profile_matches_kernel_sources fails the CPU suite until the profile is redone
+PMC_SOURCES = ('nerfpp_mlp.hip', 'nerfpp_dw.hip', 'nerfpp_common.h')
+
+
+def kernel_sources_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for f in PMC_SOURCES:
+        h.update(open(os.path.join(ROOT, 'outdoor_nerf_depth_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
 PMC_GROUPS = {            # launch group -> kernel-name prefix of its bf16 training instantiations (both nets / both launches)
     'dw_L1': 'dw_kernel<1,',
     'mlp_fwd_L1': 'mlp_fwd_kernel<',
@@ -79,7 +94,12 @@ def load_pmc_traffic():
             continue
         per = {}
         name = None
+        recorded = None
         for line in open(path):
+            m = re.match(r'^sources_sha256:\s*([0-9a-f]+)', line)
+            if m:
+                recorded = m.group(1)
+                continue
             m = re.match(r'^## (.+?)\s+\(dispatches: \d+\)', line)
             if m:
                 name = m.group(1)
@@ -87,7 +107,12 @@ def load_pmc_traffic():
             m = re.match(r'^\s+(FETCH_SIZE|WRITE_SIZE)\s+avg\s+([0-9.eE+-]+)', line)
             if m and name:
                 per.setdefault(name, {})[m.group(1)] = float(m.group(2)) * 1e3
-        out = {'source': rel + ' (NOT a live measurement: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile, parsed at start-up)', 'kernels': {}}
+        now = kernel_sources_sha256()
+        if recorded != now:
+            return {'stale': '%s was measured on kernel sources %s, the tree has %s: traffic withheld until the PMC passes are redone'
+                             % (rel, recorded or '(unrecorded)', now)}
+        out = {'source': rel + ' (NOT a live measurement: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile, '
+                               'measured on kernel sources sha256 ' + now + ', parsed at start-up)', 'kernels': {}}
         for grp, prefix in PMC_GROUPS.items():
             if grp == 'dw_L1':                    # dw_kernel<1, true> (256 x 256 jobs) + dw_kernel<1, false> (narrow jobs)
                 ks = [k for k in per if k.startswith(prefix)]
@@ -107,6 +132,9 @@ def load_pmc_traffic():
 
 
 PMC_TRAFFIC = load_pmc_traffic()
+PMC_STALE = PMC_TRAFFIC.get('stale') if PMC_TRAFFIC else None
+if PMC_STALE:
+    PMC_TRAFFIC = None
 
 
 def parse():
@@ -127,6 +155,7 @@ def parse():
     p.add_argument('--render_frames', type=int, default=1,
                    help='375x1242 frames rendered per precision by the inference leg (`render`; 0 = skip)')
     p.add_argument('--render_chunk', type=int, default=8192, help='rays per render chunk (ddp_train_nerf.py --chunk_size)')
+    p.add_argument('--cli_frames', type=int, default=295, help='frames of the synthetic sequence the drop-in loop trains on (config 2: 295)')
     p.add_argument('--cli_steps', type=int, default=800,
                    help='steps of the drop-in training loop (outdoor_nerf_depth_amd/ddp_train_nerf.py) timed by `cli_loop` (0 = skip)')
     return p.parse_args()
@@ -138,6 +167,11 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def rccl_env_defaults():
+    from outdoor_nerf_depth_amd.dist_utils import RCCL_ENV_DEFAULTS
+    return dict(RCCL_ENV_DEFAULTS)
 
 
 def spawn_ranks(n):
@@ -153,6 +187,8 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        for k, v in rccl_env_defaults().items():
+            env.setdefault(k, v)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     # poll: as soon as one rank exits non-zero the others are terminated (a dead rank would otherwise leave the rest
@@ -294,8 +330,12 @@ def roofline(r):
     # algorithmic FLOP of the dominant group / its time against 2.5 PFLOP/s; the HBM view of dW stays a sub-object
     head = {'bound': 'mfma', 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': dom['tflops'] / PEAK_BF16_TFLOPS}
-    head.update({'kernel': r['dominant'], 'co_dominant_within_2pct': r['co_dominant'], 'traffic': traffic,
-                 'launch_ms': dom['ms'], 'traffic_source': PMC_TRAFFIC['source'] if traffic else None})
+    # `achieved` counts the REFERENCE's dense MACs; the kernels execute fewer (the folded remap layer): the executed
+    # rate is what the matrix pipe actually sustained
+    ex = EXEC_OVER_ALGO[{'mlp_fwd_L1': 'mlp_fwd', 'mlp_bwd_L1': 'mlp_bwd', 'dw_L1': 'dw'}[r['dominant']]]
+    head.update({'achieved_executed': dom['tflops'] * ex, 'frac_executed': dom['tflops'] * ex / PEAK_BF16_TFLOPS,
+                 'kernel': r['dominant'], 'co_dominant_within_2pct': r['co_dominant'], 'traffic': traffic,
+                 'launch_ms': dom['ms'], 'traffic_source': PMC_TRAFFIC['source'] if traffic else (PMC_STALE or None)})
     return {**head,
             'whole_step': {'tflops': tfl, 'frac_of_bf16_mfma_peak': tfl / PEAK_BF16_TFLOPS,
                            'hbm_traffic_bytes_per_step': step_traffic,
@@ -417,7 +457,8 @@ def cli_loop(args, kernel_only_ms):
                 self.rows.append((int(m.group(1)), float(m.group(2))))
 
     import torch
-    out = {'steps': args.cli_steps, 'i_print': 100, 'scene': 'synthetic KITTI-shaped, 30 frames of 375x1242, N_rand %d' % args.n_rand,
+    out = {'steps': args.cli_steps, 'i_print': 100,
+           'scene': 'synthetic KITTI-shaped, %d frames of 375x1242 (BASELINE config 2: 295 incl. the held-out tenth), N_rand %d' % (args.cli_frames, args.n_rand),
            'kernel_only_ms_per_step': kernel_only_ms,
            'note': 'the step slows by 2-3 % over the first 1000 steps of a run (the clock follows the operand statistics of the '
                    'training network), so the loop is compared with the kernel-only step measured on ITS OWN trainer right '
@@ -451,7 +492,7 @@ def cli_loop(args, kernel_only_ms):
         level = lg.level
         try:
             a = C.config_parser().parse_args(
-                ['--expname', 'bench', '--basedir', tmp, '--synthetic', '--synthetic_frames', '30', '--world_size', '1',
+                ['--expname', 'bench', '--basedir', tmp, '--synthetic', '--synthetic_frames', str(args.cli_frames), '--world_size', '1',
                  '--cascade_samples', '64,128', '--N_rand_override', str(args.n_rand), '--N_iters', str(args.cli_steps),
                  '--i_print', '100', '--i_weights', '100000000', '--i_test', '100000000', '--precision', 'bf16', '--use_depth',
                  '--depth_sup_type', args.depth_sup_type, '--depth_loss_type', args.depth_loss_type,
@@ -506,6 +547,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        for k, v in rccl_env_defaults().items():          # (under torchrun: before the communicator exists)
+            os.environ.setdefault(k, v)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
@@ -553,7 +596,8 @@ def main():
                                                              args.lambda_depth, args.n_rand),
                    'n_rand_per_gpu': args.n_rand, 'parallelism': 'dp%d (ray batches, RCCL grad all-reduce)' % world,
                    'setup_steps': SETUP_STEPS,
-                   'dist_backend': (backend if world > 1 else None),
+                   'dist_backend': (('%s, %s' % (backend, ' '.join('%s=%s' % (k, os.environ.get(k)) for k in sorted(rccl_env_defaults()))))
+                                    if world > 1 else None),
                    # N > 1 diagnostics: each rank's own clock over the timed steps (ms per step, before the closing
                    # barrier) and the time per step its main stream waited for the side-stream parameter update (slab
                    # sum -> all-reduce -> Adam -> re-pack) that the next level's forward did not hide
@@ -577,6 +621,11 @@ def main():
         h = run_mode(args, L.PREC_SPLIT_FWD, rank, world, device, batches)
         out['parity_forward_mode'] = {'dtype': 'split-bf16 forward (outputs and loss at 1e-4), bf16 backward / weight gradients',
                                       'value': h['value'], 'ms_per_step': h['ms_per_step']}
+        h3 = run_mode(args, L.PREC_FP16_FWD, rank, world, device, batches)
+        out['fp16_forward_mode'] = {'dtype': 'fp16x2w forward (weights hi + lo in fp16, activations rounded once, 2 MFMA passes), bf16 backward / '
+                                             'weight gradients; outputs within 1e-4 of float32 at initialisation, 3-4e-4 on trained weights '
+                                             '(tests/test_gpu_round5.py): an intermediate precision, NOT a carrier of the 1e-4 clause',
+                                    'value': h3['value'], 'ms_per_step': h3['ms_per_step']}
     if 'split' in res and main_key != 'split':
         s = res['split']
         out['parity_mode'] = {'dtype': 'split-bf16 (hi+lo, 3 MFMA passes): the precision the 1e-4 parity tests use',
@@ -606,6 +655,14 @@ def main():
             out['render']['split_bf16'] = render_leg(args, device, L.PREC_SPLIT_BF16, 'split-bf16 (hi+lo, 3 MFMA passes): 1e-4 parity mode')
     if world == 1 and args.cli_steps >= 300 and main_key == 'bf16':
         out['cli_loop'] = cli_loop(args, r['ms_per_step'])
+        d = out['cli_loop'].get('device_sampler')
+        if d:
+            # what a user of the drop-in loop gets: per-step frame choice, on-device pixel draw and ray
+            # gather, log lines -- on a network that has trained for cli_steps steps, not the headline's fresh-network window
+            out['end_to_end'] = {'value': d['rays_per_s'], 'unit': 'rays/s', 'ms_per_step': d['ms_per_step'],
+                                 'what': 'outdoor_nerf_depth_amd.ddp_train_nerf.ddp_train_nerf(), bf16, %d frames, device sampler, '
+                                         'mean over the last 400 of %d steps' % (args.cli_frames, args.cli_steps)}
+            out['trained_state_ms'] = d['kernel_only_same_state_ms']
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

@@ -7,6 +7,7 @@
 // channel the host has (torch.distributed's store, MPI, a file), every rank calls nerfpp_rccl_comm_init.  The all-reduce
 // runs on the caller's stream: NerfppTrainer puts it on its update stream, under the next level's forward.
 #include <dlfcn.h>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -31,16 +32,16 @@ struct Rccl {
   errstr_fn errstr = nullptr;
   char err[256] = {0};
 };
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.h && r.allreduce ? &r : nullptr;
-  tried = true;
+// bound once per process, thread-safely (two threads may make the first call): r.err keeps the reason when it fails
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+void bind_rccl() {
+  Rccl& r = g_rccl;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (r.h) break;
   }
-  if (!r.h) { snprintf(r.err, sizeof r.err, "dlopen(librccl.so.1) failed: %s", dlerror()); return nullptr; }
+  if (!r.h) { snprintf(r.err, sizeof r.err, "dlopen(librccl.so.1) failed: %s", dlerror()); return; }
   r.get_uid = (get_uid_fn)dlsym(r.h, "ncclGetUniqueId");
   r.comm_init = (comm_init_fn)dlsym(r.h, "ncclCommInitRank");
   r.comm_destroy = (comm_destroy_fn)dlsym(r.h, "ncclCommDestroy");
@@ -49,9 +50,11 @@ Rccl* rccl() {
   if (!r.get_uid || !r.comm_init || !r.comm_destroy || !r.allreduce) {
     snprintf(r.err, sizeof r.err, "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
     r.allreduce = nullptr;
-    return nullptr;
   }
-  return &r;
+}
+Rccl* rccl() {
+  std::call_once(g_rccl_once, bind_rccl);
+  return g_rccl.h && g_rccl.allreduce ? &g_rccl : nullptr;
 }
 thread_local char g_comm_err[320];
 int comm_fail(const char* what, int rc) {
@@ -60,7 +63,8 @@ int comm_fail(const char* what, int rc) {
   return NERFPP_ERR_COMM;
 }
 int no_rccl(const char* what) {
-  snprintf(g_comm_err, sizeof g_comm_err, "%s: RCCL is not available in this process (librccl.so.1 could not be loaded)", what);
+  snprintf(g_comm_err, sizeof g_comm_err, "%s: RCCL is not available in this process: %s", what,
+           g_rccl.err[0] ? g_rccl.err : "librccl.so.1 could not be loaded");
   return NERFPP_ERR_COMM;
 }
 

@@ -31,6 +31,8 @@ def ddp_test_nerf(rank, args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ['MASTER_PORT'] = str(args.port)
+        from .dist_utils import apply_rccl_env_defaults
+        apply_rccl_env_defaults()
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
     # forward only: bf16, the two-pass fp16x2w forward (1e-4 outputs), or split-bf16 (also for split_fwd: the same forward)

@@ -309,6 +309,10 @@ def ddp_train_nerf(rank, args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ['MASTER_PORT'] = str(args.port)
+        from .dist_utils import apply_rccl_env_defaults
+        eff = apply_rccl_env_defaults()          # few channels: a CU RCCL holds is a CU a tile cannot use (dist_utils.py)
+        if rank == 0:
+            logger.info('RCCL: ' + ' '.join('%s=%s' % kv for kv in sorted(eff.items())))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL (gloo upstream, :298)
 
     # batch sizes by GPU memory                                      ddp_train_nerf.py:364-373
@@ -472,6 +476,9 @@ def ddp_train_nerf(rank, args):
     on_finish = getattr(args, 'on_finish', None)  # (bench.py: times the kernel-only step on the SAME trained state)
     if on_finish is not None:
         on_finish(trainer, device_samplers if device_samplers is not None else ray_samplers)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()                            # the library's own communicator, before the process group that carried its id
     if world > 1:
         dist.destroy_process_group()
 

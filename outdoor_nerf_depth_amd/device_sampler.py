@@ -98,7 +98,18 @@ class DeviceRaySamplers(object):
         if frame is None:
             frame = int(np.random.randint(low=0, high=self.n_frames))
         self.draws += 1
-        pix = ops.sample_pixels(self.H * self.W, N_rand, self.seed, self.draws, self.device)
+        n_pix = self.H * self.W
+        if N_rand > n_pix:
+            raise ValueError('N_rand = %d exceeds the %d pixels of a frame (np.random.choice(..., replace=False) raises too, '
+                             'nerf_sample_ray_split.py:178)' % (N_rand, n_pix))
+        if N_rand <= 8192 and 2 * N_rand <= n_pix:
+            pix = ops.sample_pixels(n_pix, N_rand, self.seed, self.draws, self.device)
+        else:
+            # nerfpp_sample_pixels draws up to 8192 pixels in one workgroup and redraws collisions: beyond that size, or when
+            # the batch is a large share of the frame (many redraw rounds), a seeded device permutation is the right tool
+            g = torch.Generator(device=self.device)
+            g.manual_seed((self.seed << 20) + self.draws)
+            pix = torch.randperm(n_pix, device=self.device, generator=g)[:N_rand]
         out = self.gather(frame, pix, full_keys)
         out['frame'] = frame
         return out

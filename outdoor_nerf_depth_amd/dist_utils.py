@@ -1,5 +1,22 @@
 """Backend-agnostic distributed helpers (RCCL on GPUs, gloo in the CPU tests)."""
+import os
+
 import torch
+
+# RCCL's footprint for this path's collective: ONE flat 4.81 MB float32 all-reduce per cascade level and step, overlapped with
+# MLP / weight-gradient launches that are sized to whole rounds of one-workgroup-per-CU tiles.  Every CU an RCCL channel holds
+# while such a launch runs pushes a tile into an extra round (profiles/r04_rccl_standin.json, r05_rccl_standin_small.json:
+# +2 ... 7 % per step for 1-4 held CUs, +6 ... 11 % for 8-32), and 4.81 MB over 7 xGMI links needs no more than a few
+# channels: at most 4 (the full weight-gradient launch leaves exactly 4 of the 256 CUs idle: 12 jobs x 21 slices).
+# Defaults only (os.environ.setdefault before the communicator is created); a caller's own NCCL_* settings win.
+RCCL_ENV_DEFAULTS = {'NCCL_MAX_NCHANNELS': '4', 'NCCL_MIN_NCHANNELS': '2'}
+
+
+def apply_rccl_env_defaults():
+    """Call before init_process_group('nccl') / RcclComm(): returns the values in effect."""
+    for k, v in RCCL_ENV_DEFAULTS.items():
+        os.environ.setdefault(k, v)
+    return {k: os.environ[k] for k in RCCL_ENV_DEFAULTS}
 
 
 def allreduce_mean_(flat, world_size, prescaled=False):

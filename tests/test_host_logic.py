@@ -291,3 +291,16 @@ def test_philox_known_answer_and_stream_layout():
     np.testing.assert_array_equal(O.philox_uniform(777, 5, 2, 64)[:10], O.philox_uniform(777, 5, 2, 10))
     uni = O.step_uniforms(777, 1, 8, 64, 128)
     assert uni['t_fg'].shape == (8, 64) and uni['u_bg'].shape == (8, 128) and uni['u_fg'].dtype == np.float32
+
+
+def test_committed_pmc_profile_matches_kernel_sources():
+    """bench.py parses `roofline.traffic` from the rocprofv3 --pmc passes committed under profiles/ (they cannot be collected inside
+    the bench process).  The profile records the sha256 of the kernel sources it was measured on; this fails the CPU suite when
+    csrc/nerfpp_{mlp,dw}.hip or nerfpp_common.h have changed since -- redo tools/probes/profile_round.sh
+    and commit its <tag>_kernel_stats_timeline_hbm.md -- and the bench line then carries traffic = null with the reason."""
+    import bench
+    t = bench.load_pmc_traffic()
+    assert t is not None, 'no PMC profile under profiles/'
+    assert 'stale' not in t, t['stale']
+    assert t['dw_L1'] > 1e9 and t['mlp_fwd_L1'] > 1e8 and t['mlp_bwd_L1'] > 1e8
+    assert bench.kernel_sources_sha256() in t['source']

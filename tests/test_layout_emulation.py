@@ -56,7 +56,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.nerfpp_abi_version() == L.ABI_VERSION
     assert lib.nerfpp_packed_bytes(1) > 0 and lib.nerfpp_packed_bytes(2) == 2 * lib.nerfpp_packed_bytes(1) - \
         (lib.nerfpp_packed_bytes(1) - sum(_stream_bytes(1))) or True
-    assert lib.nerfpp_packed_bytes(3) == -1
+    assert lib.nerfpp_packed_bytes(3) == lib.nerfpp_packed_bytes(2)          # fp16x2w: hi + lo planes like split-bf16
+    assert lib.nerfpp_packed_bytes(4) == -1 and lib.nerfpp_packed_bytes(0) == -1
+    assert lib.nerfpp_workspace_bytes(1024, 192, 3, 1) == lib.nerfpp_workspace_bytes(1024, 192, 1, 1)   # it saves one bf16 plane
     assert lib.nerfpp_workspace_bytes(1024, 192, 1, 1) > lib.nerfpp_workspace_bytes(1024, 192, 1, 0) > 0
     assert lib.nerfpp_workspace_bytes(1024, 300, 1, 1) == -1
 

@@ -19,6 +19,11 @@ def main(d, tag):
         f.write('# %s -- NeRF++ training step (bench.py, N_rand = 1024, 64 + 128 samples), one MI355X\n\n' % tag)
         f.write('Collected by `tools/probes/profile_round.sh %s` (rocprofv3 --kernel-trace --stats; bf16, split-bf16 and split_fwd in '
                 'one process).\n\n' % tag)
+        # bench.py re-computes this hash of csrc/nerfpp_{mlp,dw}.hip + nerfpp_common.h and withholds `roofline.traffic` when the
+        # kernels have changed since these PMC passes
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        import bench
+        f.write('sources_sha256: %s\n\n' % bench.kernel_sources_sha256())
         f.write("Level 0's backward and weight-gradient dispatches run on their own stream under level 1's sampling and forward (`NerfppTrainer.concurrent_backward`): their durations and those of level 1's `mlp_fwd_pair_kernel` below are wall time while sharing the GPU (negative gaps in the timeline).  Level 1's `mlp_bwd_pair_kernel` / `dw_kernel` dispatches are never overlapped; a `*_pair_kernel` dispatch covers the fg and the bg net of a level; the average rows mix level-0 (1024 x 64 samples) and level-1 (1024 x 192) launches -- the timeline separates them." + '\n\n')
         f.write(rd(d, 'kernel_stats.md'))
         f.write('\n## One bf16 training step, dispatch by dispatch (tools/rocpd_timeline.py)\n\n')

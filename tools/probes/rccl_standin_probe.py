@@ -8,6 +8,12 @@ CUs for t microseconds -- tools/probes/cu_census.hip -- issued exactly where Ner
 hook of the trainer), and the step is timed against the plain single-GPU step in the same process, alternating blocks.
 
     python tools/probes/rccl_standin_probe.py --out gpurun_out/x/rccl_standin.json
+
+Round 5 also tried holding level 0's collective back until level 1's full weight-gradient launch starts (252 workgroups: the one
+launch of a step that leaves 4 CUs idle; a `_release_held` hook in NerfppTrainer, not kept): profiles/r05_rccl_standin_under_dw.json
+-- +4.5 ... 13 % against +3 ... 8 % for the plain placement at 2-8 held CUs x 100-200 us, i.e. no gain within the +-2 % noise of
+these runs: what a held CU costs is set by when the communication kernel itself gets a CU and by level 1's chain (slab sum ->
+collective -> Adam -> re-pack) reaching the next step's level-1 forward in time, not by level 0's collective under level 1's forward.
 """
 import argparse
 import ctypes as C
