@@ -3,7 +3,8 @@
 (:23-160) on the HIP path.  Same parser as training (`--config`, `--render_splits`, `--ckpt_path`);
 for every split renders each image with the newest (or given) checkpoint -- deterministic
 sampling, no perturbation -- and writes under {basedir}/{expname}/render_{split}_{step:06d}/:
-  {idx:06d}.png, fg_*.png, bg_*.png, depth_*.png (uint16 = metres*256), and
+  {idx:06d}.png, fg_*.png, bg_*.png, depth_*.png (uint16 = metres*256), error_rgb_*.png / absrel_*.png (the min-max
+  normalised error maps of the training loop's evaluation, ddp_train_nerf.py:561-596) and
   psnr_/rmse_/absrel_{step:06d}.txt (per image, then the mean).
 PSNR = mse2psnr(mean((gt-im)^2)) on float images; depth metrics use the 80 m cap and
 1e-3 < gt < 80 validity of the reference (:87-116).
@@ -14,12 +15,11 @@ import sys
 import numpy as np
 
 from .ddp_train_nerf import (config_parser, validate_args, setup_logger, render_single_image, load_checkpoint,
-                             find_latest_checkpoint, depth_metrics, mse2psnr, to8b, logger)
+                             find_latest_checkpoint, write_eval_images, logger)
 
 
 def ddp_test_nerf(rank, args):
     import torch
-    from PIL import Image
     from .trainer import NerfppTrainer
     from .data_loader_split import load_data_split, synthetic_ray_samplers
     from . import _lib as L
@@ -59,20 +59,12 @@ def ddp_test_nerf(rank, args):
             ret = render_single_image(rank, world, trainer, sampler, args.chunk_size, keep_dists=False)   # fg_dists is never read below
             if rank != 0:
                 continue
-            fname = '{:06d}.png'.format(idx)
-            im = ret[-1]['rgb'].numpy()
-            if sampler.get_img() is not None:
-                gt_im = sampler.get_img()
-                psnrs.append(float(mse2psnr(np.mean((gt_im - im) * (gt_im - im)))))
-            if sampler.get_gt_depth_img() is not None:
-                rmse, absrel = depth_metrics(ret[-1]['depth'].numpy(), sampler)
+            psnr, rmse, absrel = write_eval_images(out_dir, idx, ret, sampler)      # incl. error_rgb_ / absrel_ (ddp_train_nerf.py:561-596)
+            if psnr is not None:
+                psnrs.append(psnr)
+            if rmse is not None:
                 rmses.append(rmse)
                 abs_rels.append(absrel)
-                d16 = ((ret[-1]['depth'].numpy() / sampler.get_depth_scale()).clip(1e-3, 80) * 256.0)
-                Image.fromarray(d16.astype(np.uint16)).save(os.path.join(out_dir, 'depth_' + fname))
-            Image.fromarray(to8b(im)).save(os.path.join(out_dir, fname))
-            Image.fromarray(to8b(ret[-1]['fg_rgb'].numpy())).save(os.path.join(out_dir, 'fg_' + fname))
-            Image.fromarray(to8b(ret[-1]['bg_rgb'].numpy())).save(os.path.join(out_dir, 'bg_' + fname))
         if rank == 0:
             for name, vals in (('psnr', psnrs), ('rmse', rmses), ('absrel', abs_rels)):
                 if vals:

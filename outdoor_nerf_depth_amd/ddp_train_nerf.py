@@ -286,14 +286,53 @@ def find_latest_checkpoint(args):
     return None, -1
 
 
-def depth_metrics(pred_depth, sampler):
-    """ddp_train_nerf.py:566-600: cap 80 m, valid 1e-3 < gt < 80, metres = value / depth_scale."""
+def depth_metrics(pred_depth, sampler, abs_err_map=None):
+    """ddp_train_nerf.py:566-600: cap 80 m, valid 1e-3 < gt < 80, metres = value / depth_scale.
+    abs_err_map: optional float array like pred_depth that receives |gt - pred| on the valid pixels (0 elsewhere), :591-592."""
     scale = sampler.get_depth_scale()
     gt = sampler.get_gt_depth_img() / scale
     pred = pred_depth / scale
     valid = (gt < 80) & (gt > 1e-3)
     vg, vp = gt[valid].clip(1e-3, 80), pred[valid].clip(1e-3, 80)
+    if abs_err_map is not None:
+        abs_err_map[...] = 0
+        abs_err_map[valid] = np.abs(vg - vp)
     return float(np.sqrt(np.mean((vg - vp) ** 2))), float(np.mean(np.abs(vg - vp) / vg))
+
+
+def minmax8(x):
+    """min-max normalised uint8 map (ddp_train_nerf.py:562-564, :593-596).  A constant map is 0 / 0 upstream (NaN cast to
+    uint8); here it is written as zeros."""
+    x = np.asarray(x, np.float32)
+    lo, hi = float(x.min()), float(x.max())
+    if not hi > lo:
+        return np.zeros(x.shape, np.uint8)
+    return (np.clip((x - lo) / (hi - lo), 0., 1.) * 255.).astype(np.uint8)
+
+
+def write_eval_images(out_dir, idx, ret, sampler):
+    """The per-image artefacts of the in-loop evaluation (ddp_train_nerf.py:549-600): {idx}.png, fg_ / bg_ composites,
+    error_rgb_ (mean absolute colour error, min-max normalised), depth_ (uint16 = metres x 256) and absrel_ (absolute depth
+    error on the valid ground-truth pixels, min-max normalised).  Returns (psnr | None, rmse | None, absrel | None)."""
+    from PIL import Image
+    fname = '{:06d}.png'.format(idx)
+    im = ret[-1]['rgb'].numpy()
+    psnr = rmse = absrel = None
+    if sampler.get_img() is not None:
+        gt_im = sampler.get_img()
+        psnr = float(mse2psnr(np.mean((gt_im - im) * (gt_im - im))))
+        Image.fromarray(minmax8(np.abs(im - gt_im).mean(-1))).save(os.path.join(out_dir, 'error_rgb_' + fname))
+    if sampler.get_gt_depth_img() is not None:
+        pred = ret[-1]['depth'].numpy()
+        err = np.zeros_like(pred, dtype=np.float32)
+        rmse, absrel = depth_metrics(pred, sampler, err)
+        d16 = ((pred / sampler.get_depth_scale()).clip(1e-3, 80) * 256.0)
+        Image.fromarray(d16.astype(np.uint16)).save(os.path.join(out_dir, 'depth_' + fname))
+        Image.fromarray(minmax8(err)).save(os.path.join(out_dir, 'absrel_' + fname))
+    Image.fromarray(to8b(im)).save(os.path.join(out_dir, fname))
+    Image.fromarray(to8b(ret[-1]['fg_rgb'].numpy())).save(os.path.join(out_dir, 'fg_' + fname))
+    Image.fromarray(to8b(ret[-1]['bg_rgb'].numpy())).save(os.path.join(out_dir, 'bg_' + fname))
+    return psnr, rmse, absrel
 
 
 def ddp_train_nerf(rank, args):
@@ -441,21 +480,12 @@ def ddp_train_nerf(rank, args):
                 ret = render_single_image(rank, world, trainer, sampler, args.chunk_size, keep_dists=False)   # fg_dists is never read below
                 if rank != 0:
                     continue
-                from PIL import Image
-                fname = '{:06d}.png'.format(idx)
-                im = ret[-1]['rgb'].numpy()
-                if sampler.get_img() is not None:
-                    gt_im = sampler.get_img()
-                    psnrs.append(float(mse2psnr(np.mean((gt_im - im) * (gt_im - im)))))
-                if sampler.get_gt_depth_img() is not None:
-                    rmse, absrel = depth_metrics(ret[-1]['depth'].numpy(), sampler)
+                psnr, rmse, absrel = write_eval_images(out_dir, idx, ret, sampler)
+                if psnr is not None:
+                    psnrs.append(psnr)
+                if rmse is not None:
                     rmses.append(rmse)
                     abs_rels.append(absrel)
-                    d16 = ((ret[-1]['depth'].numpy() / sampler.get_depth_scale()).clip(1e-3, 80) * 256.0)
-                    Image.fromarray(d16.astype(np.uint16)).save(os.path.join(out_dir, 'depth_' + fname))
-                Image.fromarray(to8b(im)).save(os.path.join(out_dir, fname))
-                Image.fromarray(to8b(ret[-1]['fg_rgb'].numpy())).save(os.path.join(out_dir, 'fg_' + fname))
-                Image.fromarray(to8b(ret[-1]['bg_rgb'].numpy())).save(os.path.join(out_dir, 'bg_' + fname))
             if rank == 0:
                 for name, vals in (('psnr', psnrs), ('rmse', rmses), ('absrel', abs_rels)):
                     if vals:

@@ -357,25 +357,63 @@ def run_train_step(ops, engines, opt, step, batch, uni, mode='mse', lambda_depth
     return logs
 
 
+# Adam's first step is -lr * g / (|g| + eps) = -lr * sign(g): an element of the HIP path can differ from the reference's by 2 lr
+# only where the SIGN of its gradient differs, i.e. where |g| is inside the gradient's own error.  The split-bf16 gradients are
+# within 5e-2 * RMS (max-norm, per tensor) of the float64 reference (test_gradients_match_reference_f64), so every element
+# whose own |g| exceeds FLOOR x the tensor's RMS must take the reference's step exactly; the others may flip and are counted.
+# Step 3 is a continuous function of three gradients: lr * m / sqrt(v) moves by <= lr * (relative gradient error), so the
+# elements above the floor in all three steps are held to STEP3_TOL with no outlier allowance.  (Until round 4 this test
+# allowed 3 % / 10 % of ALL sampled elements outside 2e-5 / 2.5e-4 = half an Adam step.)
+SIGN_FLOOR = 0.15
+# measured (MI355X, round 5): step 1 worst 7.5e-9 on the 58 % of sampled elements above the floor (3 sign flips among the rest),
+# step 3 worst 3.1e-5 on the 40 % above it in all three steps.  Gates = float rounding / 2 x measured.
+STEP1_TOL, STEP3_TOL = 1e-7, 6e-5
+
+
 def test_three_training_steps_match_reference(ops, golden, levels):
     g = golden('train_steps')
     engines = [ops.LevelEngine(T(flat(lv)), precision=2) for lv in levels]
+    init = [unflat(N(e.params).copy()) for e in engines]
     opt = [(torch.zeros_like(e.params), torch.zeros_like(e.params)) for e in engines]
+    above = [None, None]            # per level: dict name -> bool mask over the tensor, "above the floor in every step so far"
+    stats = {}
     for step in range(1, 4):
         batch = {k: g['s%d.%s' % (step, k)] for k in ('ray_o', 'ray_d', 'rgb', 'depth_sup', 'min_depth')}
         uni = {k: g['s%d.%s' % (step, k)] for k in ('t_fg', 't_bg', 'u_fg', 'u_bg')}
-        logs = run_train_step(ops, engines, opt, step, batch, uni)
+        seen = {}
+
+        def hook(m, grads):
+            seen[m] = unflat(N(grads).copy())
+            return grads
+        logs = run_train_step(ops, engines, opt, step, batch, uni, grad_hook=hook)
         for m in range(2):
             close(logs[m][0], g['s%d.L%d.loss' % (step, m)], 5e-4, 0)
             close(logs[m][2], g['s%d.L%d.depth_loss' % (step, m)], 5e-4, 0)
+            ok = {k: np.abs(v) > SIGN_FLOOR * np.sqrt(np.mean(v.astype(np.float64) ** 2)) for k, v in seen[m].items()}
+            above[m] = ok if above[m] is None else {k: above[m][k] & ok[k] for k in ok}
         if step in (1, 3):
+            tol = STEP1_TOL if step == 1 else STEP3_TOL
+            worst, n_above, n_all, n_flip = 0.0, 0, 0, 0
             for m in range(2):
                 now = unflat(N(engines[m].params))
                 for k in O.param_order():
-                    mine = now[k].reshape(-1)[g['after%d.L%d.%s.idx' % (step, m, k)]]
-                    ref = g['after%d.L%d.%s.val' % (step, m, k)]
-                    bad = np.abs(mine - ref) > (2e-5 if step == 1 else 2.5e-4)
-                    assert bad.mean() < (0.03 if step == 1 else 0.10), (k, m, bad.mean())
+                    idx = g['after%d.L%d.%s.idx' % (step, m, k)]
+                    mine, ref = now[k].reshape(-1)[idx], g['after%d.L%d.%s.val' % (step, m, k)]
+                    sel = above[m][k].reshape(-1)[idx]
+                    err = np.abs(mine - ref)
+                    if sel.any():
+                        worst = max(worst, float(err[sel].max()))
+                        assert err[sel].max() <= tol, (step, m, k, float(err[sel].max()))
+                    n_above += int(sel.sum()); n_all += sel.size
+                    n_flip += int((err[~sel] > 0.5 * 5e-4).sum()) if step == 1 else 0
+                    # nobody moves further than the Adam bound of `step` steps from where the reference is
+                    assert err.max() <= 2 * 5e-4 * step * 1.001, (step, m, k, float(err.max()))
+                    if step == 1:         # and everybody took a step of exactly lr in one direction or the other
+                        d0 = np.abs(mine - init[m][k].reshape(-1)[idx])
+                        assert np.all((np.abs(d0 - 5e-4) < 1e-6) | (d0 < 5e-4)), (m, k)
+            stats[step] = dict(worst_above_floor=worst, frac_above_floor=n_above / n_all, sign_flips_below_floor=n_flip)
+    print('three-step report', stats)
+    assert stats[1]['frac_above_floor'] > 0.5 and stats[3]['frac_above_floor'] > 0.3, stats     # the gate covers the bulk
 
 
 # ----------------------------------------------------------------------------------------- full size

@@ -100,7 +100,7 @@ def test_concurrent_backward_two_ranks_gloo(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------- training trajectory
-def _trajectory(precision, mode, n_steps=None, seed=0):
+def _trajectory(precision, mode, n_steps=None, seed=0, with_depth=False):
     """NerfppTrainer on the fixture's batches and uniforms (seed 0; other seeds shift the numpy streams); returns the logged rgb
     losses per step [n,2] and the final frame rendered by render_single_image (deterministic sampling) with its PSNR against
     the image."""
@@ -116,12 +116,15 @@ def _trajectory(precision, mode, n_steps=None, seed=0):
     for step in range(1, (n_steps or TC.N_STEPS) + 1):
         b, uni = TC.step_batch(smp, step + 100000 * seed), TC.step_uniforms(step + 100000 * seed)
         sc = tr.train_step({k: T(v, d) for k, v in b.items()}, uniforms={k: T(v, d) for k, v in uni.items()})
-        sc_all.append(torch.stack([s[1] for s in sc]))
-    rgb_mse = torch.stack(sc_all).cpu().numpy().astype(np.float64)
+        sc_all.append(torch.stack([s[1] for s in sc] + [s[2] for s in sc]))
+    logged = torch.stack(sc_all).cpu().numpy().astype(np.float64)
+    rgb_mse, depth_loss = logged[:, :2], logged[:, 2:]
     tr.check_cameras()
     ret = render_single_image(0, 1, tr, smp, 1024, keep_dists=False)
     im = ret[-1]['rgb'].numpy().astype(np.float64)
     mse = float(np.mean((im - smp.get_img().astype(np.float64)) ** 2))
+    if with_depth:
+        return rgb_mse, im, mse, float(TC.psnr(mse)), depth_loss
     return rgb_mse, im, mse, float(TC.psnr(mse))
 
 
@@ -138,6 +141,11 @@ def _dump(name, report):
 # the first four (steps 25-100).  Measured (profiles/r04_trajectory_*.json): split-bf16 <= 0.0017 / 0.0135, split_fwd <= 0.0024 /
 # 0.037, bf16 <= 0.0098 / 0.0675 -- the trajectories coincide with the reference's and then separate exponentially.
 EARLY_GATE = {'split_bf16': (5e-3, 4e-2), 'split_fwd': (1e-2, 1e-1), 'bf16': (3e-2, 2e-1)}
+# The logged DEPTH loss of both levels at the first two log lines (steps 25 and 50), relative deviation from the float32
+# reference's (only the rgb loss was gated).  Measured (profiles/r05_trajectory_depth_dev.json): gt + mse
+# -- a mean over the ~13 rays of a batch that carry a prior, the noisiest of the three -- split-bf16 <= 0.0096, split_fwd <= 0.018,
+# bf16 <= 0.048; stereo_crop + l1 and mono_crop + kl <= 0.0025 in every mode.  Gate = 2 x the measured maximum.
+DEPTH_EARLY_GATE = {'split_bf16': 2e-2, 'split_fwd': 4e-2, 'fp16_fwd': 4e-2, 'bf16': 1e-1}
 # PSNR tolerance at the end of the 200-step run, in units of the reference's OWN float64 - float32 spread on the same run (its
 # noise floor: a 1e-7 perturbation of the float32 reference moves its final PSNR by that much).  split-bf16 reproduces the
 # reference's arithmetic to 1e-5 and is held to 2 x the spread (this gate stays where it was when it was
@@ -161,7 +169,8 @@ def test_training_trajectory_psnr_against_reference(mode):
     """VERDICT r03 item 3.  The imported reference trained 200 steps on the config-1 scene (tests/golden/trajectory.npz): rgb-only
     and with each depth term of the BASELINE configs (gt + mse, stereo_crop + l1, mono_crop + kl); the HIP trainer replays the
     same batches and uniforms in every precision mode.
-    Gates, all modes: the logged rgb loss follows the reference's over the first 100 steps (EARLY_GATE).
+    Gates, all modes: the logged rgb loss follows the reference's over the first 100 steps (EARLY_GATE), the logged depth loss
+    over the first 50 (DEPTH_EARLY_GATE).
     rgb-only and gt + mse: every precision ends within max(0.05 dB, k x the reference's own float64-float32 spread) of the
     float32 reference in render PSNR and in the mean in-loop PSNR of the last 25 steps (north_star's PSNR clause); k = 2 for
     split-bf16, 3 for the bf16-gradient modes (PSNR_SPREADS above).
@@ -180,14 +189,17 @@ def test_training_trajectory_psnr_against_reference(mode):
               'reference_tail_inloop_psnr_L1': ref_tail}
     from outdoor_nerf_depth_amd import _lib as L
     for name, prec in (('split_bf16', L.PREC_SPLIT_BF16), ('split_fwd', L.PREC_SPLIT_FWD), ('bf16', L.PREC_BF16)):
-        rgb_mse, im, mse, ps = _trajectory(prec, mode)
+        rgb_mse, im, mse, ps, dl = _trajectory(prec, mode, with_depth=True)
         tail = float(np.mean(TC.psnr(rgb_mse[-TC.LOG_EVERY:, 1])))
         logged = rgb_mse[TC.LOG_EVERY - 1::TC.LOG_EVERY]
+        dlog = dl[TC.LOG_EVERY - 1::TC.LOG_EVERY]
         report[name] = {'render_psnr': ps, 'render_gap_db': ps - ref_psnr, 'tail_inloop_psnr_L1': tail,
                         'tail_gap_db': tail - ref_tail,
                         'logged_rgb_mse_rel_dev_max': float(np.max(np.abs(logged[:, 1] / g[mode + '.f32.rgb1'] - 1.0))),
                         'logged_rgb_mse_rel_dev': [float(x) for x in np.abs(logged[:, 1] / g[mode + '.f32.rgb1'] - 1.0)],
                         'logged_rgb0_mse_rel_dev': [float(x) for x in np.abs(logged[:, 0] / g[mode + '.f32.rgb0'] - 1.0)],
+                        'logged_depth1_rel_dev': ([float(x) for x in np.abs(dlog[:, 1] / g[mode + '.f32.depth1'] - 1.0)] if mode != 'rgbonly' else None),
+                        'logged_depth0_rel_dev': ([float(x) for x in np.abs(dlog[:, 0] / g[mode + '.f32.depth0'] - 1.0)] if mode != 'rgbonly' else None),
                         'image_rms_vs_reference': float(np.sqrt(np.mean((im.reshape(-1, 3) - g[mode + '.f32.render_rgb']) ** 2)))}
     # With a depth term the 200-step trajectory is chaotic at the 0.1 dB level even for the reference -- its own float64 run
     # ends 0.09-0.14 dB from its float32 run (a 1e-7 perturbation): nothing can be pinned to the float32 run tighter than the
@@ -204,6 +216,9 @@ def test_training_trajectory_psnr_against_reference(mode):
         for key in ('logged_rgb_mse_rel_dev', 'logged_rgb0_mse_rel_dev'):
             dev_log = report[name][key]
             assert dev_log[0] <= EARLY_GATE[name][0] and max(dev_log[:4]) <= EARLY_GATE[name][1], (name, key, dev_log)
+        if mode != 'rgbonly':
+            for key in ('logged_depth1_rel_dev', 'logged_depth0_rel_dev'):
+                assert max(report[name][key][:2]) <= DEPTH_EARLY_GATE[name], (name, key, report[name][key][:2])
         if steep:
             continue
         assert abs(report[name]['render_gap_db']) <= tols[name][0], (name, report[name], tols[name])

@@ -32,13 +32,23 @@ def test_train_cli_checkpoint_resume_and_eval(tmp_path):
     assert (rdir / '000000.png').exists() and (rdir / 'psnr_000005.txt').exists() and (rdir / 'rmse_000005.txt').exists()
     psnr = [float(x) for x in (rdir / 'psnr_000005.txt').read_text().split()]
     assert np.isfinite(psnr).all() and len(psnr) == 3          # 2 test frames + mean
+    # the per-image artefacts of the in-loop evaluation (ddp_train_nerf.py:549-600), for both test frames, nothing else
+    want = {pre + '%06d.png' % i for i in (0, 1) for pre in ('', 'fg_', 'bg_', 'depth_', 'error_rgb_', 'absrel_')}
+    want |= {'psnr_000005.txt', 'rmse_000005.txt', 'absrel_000005.txt'}
+    assert set(os.listdir(rdir)) == want, set(os.listdir(rdir)) ^ want
+    from PIL import Image
+    for pre in ('error_rgb_', 'absrel_'):
+        m = np.array(Image.open(rdir / (pre + '000000.png')))
+        assert m.dtype == np.uint8 and m.ndim == 2 and m.min() == 0 and m.max() == 255      # min-max normalised grayscale
+    for f in want:
+        os.remove(rdir / f)                                     # the offline entry point below re-creates the directory's contents
     # offline evaluation entry point (ddp_test_nerf.py): same parser, newest checkpoint, metric files
     from outdoor_nerf_depth_amd import ddp_test_nerf as TT
     targs = T.config_parser().parse_args(base + ['--render_splits', 'test'])
     targs.world_size = 1
     TT.ddp_test_nerf(0, targs)
     tdir = exp / 'render_test_000005'
-    assert (tdir / 'fg_000001.png').exists() and (tdir / 'depth_000001.png').exists()
+    assert set(os.listdir(tdir)) == want, set(os.listdir(tdir)) ^ want
     assert len((tdir / 'absrel_000005.txt').read_text().split()) == 3
     # "already trained" guard of the reference (:733-735)
     with pytest.raises(SystemExit) as e:
