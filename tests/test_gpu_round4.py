@@ -225,35 +225,45 @@ def test_training_trajectory_psnr_against_reference(mode):
         assert abs(report[name]['tail_gap_db']) <= tols[name][1], (name, report[name], tols[name])
 
 
-@pytest.mark.parametrize('mode', ['l1', 'kl'])
+def median_se(x, n_boot=2000):
+    """bootstrap standard error of the median"""
+    x = np.asarray(x, np.float64)
+    rs = np.random.RandomState(0)
+    return float(np.std([np.median(x[rs.randint(0, len(x), len(x))]) for _ in range(n_boot)]))
+
+
+@pytest.mark.parametrize('mode', ['mse', 'l1', 'kl'])
 def test_bf16_gradient_modes_match_split_bf16_over_seeds(mode):
-    """The PSNR clause of north_star for the bf16-gradient modes (split_fwd = the CLI default, bf16 = the bench headline) with
-    the depth terms whose single trajectories cannot be pinned at step 200 (see above): 8 seeds of batches / uniforms, 1000
-    steps each, every precision on identical inputs, split-bf16 standing in for the reference (it is pinned to the reference
-    on seed 0).  Gate: the MEDIAN over seeds of the paired gap of the in-loop PSNR (mean of the last 25 steps) is within
-    0.25 dB -- the paired gaps scatter with sigma 0.07-0.26 dB at 1000 steps, so this is what 8 seeds can resolve; the 0.05 dB
-    of north_star is below the run-to-run spread of the reference itself on this scene (float64 vs float32: 0.09-0.14 dB)."""
+    """The PSNR clause of north_star for the bf16-gradient modes (split_fwd, fp16_fwd, bf16 = the bench headline) at CONVERGENCE,
+    where single trajectories cannot be pinned (see above): 8 seeds of batches / uniforms, 1000 steps each, every precision on
+    identical inputs, split-bf16 standing in for the reference (it is pinned to the reference on seed 0, and
+    test_split_bf16_matches_the_reference_seeds below pairs it with the imported reference's own 1000-step runs).
+    Gate: |median paired gap of the in-loop PSNR (mean of the last 25 steps)| <= 0.05 dB + 2 SE, SE = the
+    bootstrap standard error of that median over the seeds.  With 8 seeds SE is 0.03-0.1 dB; the 32-seed run of
+    tools/probes/traj_seeds.py (profiles/r05_traj_seeds_32.json) resolves it to 0.014-0.05 dB: medians -0.07 ... +0.05 dB for
+    every mode and depth term, every one inside 0.05 + 2 SE."""
     import trajectory_common as TC
     from outdoor_nerf_depth_amd import _lib as L
     n_steps, n_seeds = 1000, 8
+    precs = (('split_bf16', L.PREC_SPLIT_BF16), ('split_fwd', L.PREC_SPLIT_FWD), ('fp16_fwd', L.PREC_FP16_FWD), ('bf16', L.PREC_BF16))
     rows = []
     for seed in range(n_seeds):
         r = {}
-        for name, prec in (('split_bf16', L.PREC_SPLIT_BF16), ('split_fwd', L.PREC_SPLIT_FWD), ('bf16', L.PREC_BF16)):
+        for name, prec in precs:
             rgb_mse, _, _, ps = _trajectory(prec, mode, n_steps=n_steps, seed=seed)
             r[name] = (ps, float(np.mean(TC.psnr(rgb_mse[-TC.LOG_EVERY:, 1]))))
         rows.append(r)
     report = {'mode': mode, 'steps': n_steps, 'runs': rows}
-    for name in ('split_fwd', 'bf16'):
+    for name in ('split_fwd', 'fp16_fwd', 'bf16'):
         tail = np.array([r[name][1] - r['split_bf16'][1] for r in rows])
         rend = np.array([r[name][0] - r['split_bf16'][0] for r in rows])
-        report[name] = {'tail_gap_db': tail.tolist(), 'tail_gap_db_median': float(np.median(tail)), 'tail_gap_db_mean': float(tail.mean()),
+        report[name] = {'tail_gap_db': tail.tolist(), 'tail_gap_db_median': float(np.median(tail)), 'tail_gap_db_se_of_median': median_se(tail),
                         'tail_gap_db_std': float(tail.std(ddof=1)), 'render_gap_db': rend.tolist(),
-                        'render_gap_db_median': float(np.median(rend)), 'render_gap_db_mean': float(rend.mean()),
+                        'render_gap_db_median': float(np.median(rend)), 'render_gap_db_se_of_median': median_se(rend),
                         'render_gap_db_std': float(rend.std(ddof=1))}
     _dump('trajectory_seeds_%s.json' % mode, report)
-    for name in ('split_fwd', 'bf16'):
-        assert abs(report[name]['tail_gap_db_median']) <= 0.25, (name, report[name])
+    for name in ('split_fwd', 'fp16_fwd', 'bf16'):
+        assert abs(report[name]['tail_gap_db_median']) <= 0.05 + 2.0 * report[name]['tail_gap_db_se_of_median'], (name, report[name])
 
 
 # ------------------------------------------------------------------------------------------- pixel draw of the ray-batch sampler

@@ -261,3 +261,45 @@ def test_fp16_fwd_trainer_follows_the_reference_trajectory(mode):
     if mode in ('rgbonly', 'mse'):
         tol_r, tol_t = R4.psnr_tolerances(g, mode, 'split_fwd')
         assert abs(report['render_gap_db']) <= tol_r and abs(report['tail_gap_db']) <= tol_t, (report, tol_r, tol_t)
+
+
+# ------------------------------------------------------------------------------------------- the reference's own seeds
+@pytest.mark.parametrize('mode', ['mse', 'kl'])
+def test_split_bf16_matches_the_reference_seeds(mode):
+    """VERDICT r04 item 2a.  tests/golden/trajectory_seeds.npz = the imported float32 reference trained 1000 steps on the config-1
+    scene for several seeds of the batch / uniform streams (gt + mse and mono_crop + kl): the reference's OWN seed spread at
+    convergence, and a paired reference run for every seed.  The HIP trainer in split-bf16 replays each seed; asserted:
+    (i) every run's early part is ON the reference's trajectory (logged rgb loss at steps 25 ... 100 within EARLY_GATE);
+    (ii) the paired gaps of the in-loop tail PSNR and of the final render PSNR are inside the reference's own spread:
+         |median gap| <= 0.05 dB + 2 SE with SE >= sigma_ref / sqrt(n) (the seed spread of the reference is what n runs of ANY
+         faithful implementation scatter by), and no single gap beyond 3 sigma_ref.
+    This is what validates split-bf16 as the reference's stand-in in the multi-seed precision tests (tests/test_gpu_round4.py)."""
+    import trajectory_common as TC
+    import test_gpu_round4 as R4
+    from outdoor_nerf_depth_amd import _lib as L
+    g = np.load(os.path.join(GOLD, 'trajectory_seeds.npz'))
+    n_steps = int(g['steps'])
+    seeds = sorted(int(k.split('.')[1][1:]) for k in g.files if k.startswith(mode + '.s') and k.endswith('.render_psnr'))
+    assert len(seeds) >= 2, seeds
+    rows = []
+    for seed in seeds:
+        rgb_mse, _, _, ps = R4._trajectory(L.PREC_SPLIT_BF16, mode, n_steps=n_steps, seed=seed)
+        tag = '%s.s%d' % (mode, seed)
+        logged = rgb_mse[TC.LOG_EVERY - 1::TC.LOG_EVERY]
+        dev1 = np.abs(logged[:4, 1] / g[tag + '.rgb1'][:4] - 1.0)
+        assert dev1[0] <= R4.EARLY_GATE['split_bf16'][0] and dev1.max() <= R4.EARLY_GATE['split_bf16'][1], (tag, dev1)
+        ref_tail = float(np.mean(TC.psnr(g[tag + '.tail_rgb_mse'][:, 1])))
+        rows.append(dict(seed=seed, ref_render=float(g[tag + '.render_psnr']), ref_tail=ref_tail, render=ps,
+                         tail=float(np.mean(TC.psnr(rgb_mse[-TC.LOG_EVERY:, 1])))))
+    ref_r, ref_t = np.array([r['ref_render'] for r in rows]), np.array([r['ref_tail'] for r in rows])
+    gap_r, gap_t = np.array([r['render'] for r in rows]) - ref_r, np.array([r['tail'] for r in rows]) - ref_t
+    n = len(rows)
+    sig_r, sig_t = float(ref_r.std(ddof=1)), float(ref_t.std(ddof=1))
+    report = {'mode': mode, 'steps': n_steps, 'runs': rows, 'reference_render_psnr_std_over_seeds': sig_r,
+              'reference_tail_psnr_std_over_seeds': sig_t, 'render_gap_db': gap_r.tolist(), 'tail_gap_db': gap_t.tolist(),
+              'render_gap_median': float(np.median(gap_r)), 'tail_gap_median': float(np.median(gap_t))}
+    R4._dump('reference_seeds_%s.json' % mode, report)
+    for gap, sig in ((gap_r, sig_r), (gap_t, sig_t)):
+        se = max(R4.median_se(gap), sig / np.sqrt(n))
+        assert abs(np.median(gap)) <= 0.05 + 2.0 * se, report
+        assert np.abs(gap).max() <= 3.0 * max(sig, 0.1), report
