@@ -285,11 +285,8 @@ __device__ __forceinline__ void set_slot(Frag<P>& f, int t, float v) {
 template <int P>
 __device__ __forceinline__ uint4 saved_image(const uint4 regs) {
   if constexpr (P == 3) {
-    const f16x8 h = __builtin_bit_cast(f16x8, regs);
-    bf16x8 q;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) q[t] = (__bf16)(float)h[t];
-    return __builtin_bit_cast(uint4, q);
+    const f32x8 f = __builtin_convertvector(__builtin_bit_cast(f16x8, regs), f32x8);
+    return __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8));
   } else return regs;
 }
 template <int P>
@@ -336,6 +333,19 @@ __device__ __forceinline__ void unstash_frags(const char* base, int lane, Frag<P
     for (int p = 0; p < a_planes(P); ++p) *(uint4*)&f[c].v[p] = *(const uint4*)(base + ((c * a_planes(P) + p) * 64 + lane) * 16);
 }
 
+// two float32 -> one dword of packed bf16 (fp16 in precision 3): ONE v_cvt_pk_* instruction.  (Element-wise `q[t] = (__bf16) x`
+// into an 8-vector made the compiler convert every element on its own and merge pairs with v_perm_b32 -- three VALU
+// instructions per dword in the per-stage epilogues, where all waves of the CU sit at once.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int P>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const f32x2 v = {a, b};
+  if constexpr (P == 3) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
 // ReLU + conversion + sign words in one pass over the accumulators.
 // Sign-word layout (uint4 per lane per stage, consumed by mask_to_frags in the backward kernel): element
 // (ob, r = 8*hh + 2*w + e) lives in word ob>>1 at bit (e ? 31 : 15) - j, j = (ob&1)*8 + hh*4 + w, and holds
@@ -352,17 +362,8 @@ __device__ __forceinline__ uint4 acc_to_frags_relu_bits(const f32x16 (&acc)[NOB]
       if constexpr (P != 2) {
         // (bf16 and fp16 alike: the sign is bit 15 of the 16-bit pattern, a value with it set is a negative int16)
         u32x4 d;
-        if constexpr (P == 3) {
-          f16x8 q;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) q[t] = (_Float16)acc[ob][8 * hh + t];
-          d = __builtin_bit_cast(u32x4, q);
-        } else {
-          bf16x8 q;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) q[t] = (__bf16)acc[ob][8 * hh + t];
-          d = __builtin_bit_cast(u32x4, q);
-        }
+        for (int w = 0; w < 4; ++w) d[w] = pack2<P>(acc[ob][8 * hh + 2 * w], acc[ob][8 * hh + 2 * w + 1]);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int j = (ob & 1) * 8 + hh * 4 + w;
@@ -505,10 +506,9 @@ __device__ __forceinline__ void mask_to_frags(const f32x16 (&acc)[NOB], const ui
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       if constexpr (P == 1) {
-        bf16x8 q;
+        u32x4 d;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) q[t] = (__bf16)acc[ob][8 * hh + t];
-        u32x4 d = __builtin_bit_cast(u32x4, q);
+        for (int w = 0; w < 4; ++w) d[w] = pack2<1>(acc[ob][8 * hh + 2 * w], acc[ob][8 * hh + 2 * w + 1]);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int j = (ob & 1) * 8 + hh * 4 + w;
@@ -569,9 +569,10 @@ __device__ __forceinline__ void sample_point(const MlpGeom& gm, size_t row, int 
 // bf16: the features are rounded to 8 mantissa bits anyway, so the hardware v_sin_f32 / v_cos_f32 (argument in
 // revolutions, reduced with v_fract; |arg| <= 512 rad = 82 rev keeps the reduction error below 2e-5 rad)
 // replace ~60 VALU instructions + a Payne-Hanek slow path per call with 4.
+// (Precision 3 rounds the features to fp16 -- 2.4e-4 at |v| ~ 1 -- an order of magnitude above the hardware path's error.)
 template <int P>
 __device__ __forceinline__ void pe_sincos(float arg, float* sn, float* cs) {
-  if constexpr (P == 1) {
+  if constexpr (P != 2) {
     const float r = __builtin_amdgcn_fractf(arg * 0.15915494309189535f);
     *sn = __builtin_amdgcn_sinf(r);
     *cs = __builtin_amdgcn_cosf(r);

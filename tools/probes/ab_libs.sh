@@ -1,8 +1,10 @@
-# A/B of two library builds on one box: alternate 3x
+#!/bin/bash
+# A/B of two library builds on one box: alternate 3x.  usage: tools/probes/ab_libs.sh <variant name under csrc/build/variants> [bench args]
+V=${1:-baseline}; shift
 for rep in 1 2 3; do
-for v in baseline_r03 NEW; do
+for v in $V NEW; do
   if [ $v = NEW ]; then unset NERFPP_HIP_LIB; else export NERFPP_HIP_LIB=$PWD/outdoor_nerf_depth_amd/csrc/build/variants/$v.so; fi
-  python bench.py --precision bf16 --no_cpu_baseline --large_batch 0 --mip360_rays 0 --render_frames 0 --steps 60 --warmup 5 2>/dev/null | python -c "
+  python bench.py --precision bf16 --no_cpu_baseline --large_batch 0 --mip360_rays 0 --render_frames 0 --cli_steps 0 --steps 60 --warmup 5 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$v', round(d['value']), round(d['ms_per_step'],4), d['roofline']['share_ms_per_step'])"
