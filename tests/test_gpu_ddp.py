@@ -272,7 +272,8 @@ def test_bench_gpus_8_shared_gpu_smoke():
     r = json.loads(lines[0])
     assert r['n_gpus'] == 8 and r['scaling'] == 'weak' and r['config']['n_rand_per_gpu'] == 128
     assert abs(r['value'] - 8 * 128 / (r['ms_per_step'] * 1e-3)) <= 1e-6 * r['value']
-    assert r['config']['dist_backend'] in ('nccl', 'gloo')
+    assert r['config']['dist_backend'].split(',')[0] in ('nccl', 'gloo')
+    assert 'NCCL_MAX_NCHANNELS=' in r['config']['dist_backend']             # RCCL's footprint is part of the configuration
     per_rank, exposed = r['config']['per_rank_ms_per_step'], r['config']['exposed_update_ms_per_step']
     assert len(per_rank) == 8 and len(exposed) == 8
     assert all(0 < t <= r['ms_per_step'] * 1.001 for t in per_rank)          # the reported time is the slowest rank's
