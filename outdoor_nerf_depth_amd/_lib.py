@@ -68,7 +68,7 @@ SYMBOLS = {
     'nerfpp_build_tables': (C.c_int, [C.c_int, _i32p, _i32p, _i32p, _i32p]),
     'nerfpp_level_tables_elems': (C.c_int64, []),
     'nerfpp_build_level_tables': (C.c_int, [_i32p]),
-    'nerfpp_dw_plan': (C.c_int, [C.c_int64, _i32p, _i32p]),
+    'nerfpp_dw_plan': (C.c_int, [C.c_int64, C.c_int, _i32p, _i32p]),
     'nerfpp_packed_bytes': (C.c_int64, [C.c_int]),
     'nerfpp_pack_level': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp]),
     'nerfpp_workspace_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -33,6 +33,8 @@ int check_launch(const char* what) {
   do { if (!(cond)) return fail(NERFPP_ERR_ARG, "%s: requirement failed: %s", __func__, what); } while (0)
 
 constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// single-plane workspaces (forward precisions 1 and 3): H0 is not a saved tensor, its weight-gradient job recomputes it from X
+bool h0_recomputed(int WP) { return a_planes(WP) == 1; }
 
 // ---- level tables layout (int32 elements) -------------------------------------------------------
 struct TblLayout { int64_t fwd[2], bias[2], bwd[2], unpack[2], total; };
@@ -71,10 +73,12 @@ struct WsLayout {
   int ksplit;
 };
 int choose_ksplit(int64_t rows) {              // slabs to allocate: the most any job of the plan uses
-  const DwPlan pl = dw_plan(rows);
   int k = 1;
-  for (int net = 0; net < N_NET; ++net)
-    for (int j = 0; j < DW_JOBS; ++j) k = pl.k[net][j] > k ? pl.k[net][j] : k;
+  for (int rc = 0; rc < 2; ++rc) {
+    const DwPlan pl = dw_plan(rows, rc != 0);
+    for (int net = 0; net < N_NET; ++net)
+      for (int j = 0; j < DW_JOBS; ++j) k = pl.k[net][j] > k ? pl.k[net][j] : k;
+  }
   return k;
 }
 WsLayout ws_layout(int n_rays, int S, int P, bool training) {
@@ -91,6 +95,7 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
         L.tensor[net][t] = off;
         if (t == T_R || t == T_DR) continue;     // never materialised (remap_fixup_kernel derives their gradients)
         if (t == T_DG) continue;                 // columns 32..159 of the [dS | dG] tensor allocated as T_DS
+        if (t == T_H0 && h0_recomputed(P)) continue;   // recomputed from X inside its weight-gradient job (nerfpp_dw.hip: rc_job)
         off = align_up(off + (size_t)L.rows_padded * tensor_ld(net, t) * 2 * a_planes(P), 256);
       }
       L.slabs[net] = off; off = align_up(off + (size_t)L.ksplit * gslab_floats(net) * 4, 256);
@@ -243,9 +248,9 @@ int nerfpp_build_level_tables(int32_t* host_tables) {
   return NERFPP_OK;
 }
 
-int nerfpp_dw_plan(int64_t rows, int32_t* k_out, int32_t* is_full_out) {
-  if (!k_out || rows <= 0) return -1;
-  const DwPlan pl = dw_plan(rows);
+int nerfpp_dw_plan(int64_t rows, int workspace_precision, int32_t* k_out, int32_t* is_full_out) {
+  if (!k_out || rows <= 0 || !prec_ok_fwd(workspace_precision)) return -1;
+  const DwPlan pl = dw_plan(rows, h0_recomputed(workspace_precision));
   const JobTable jt = build_all_jobs();
   for (int net = 0; net < N_NET; ++net)
     for (int j = 0; j < DW_JOBS; ++j) {
@@ -287,6 +292,8 @@ int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, i
   REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= NERFPP_MAX_SAMPLES && prec_ok_fwd(precision), "sizes / precision");
   REQUIRE(net >= 0 && net < N_NET && tensor >= 0 && tensor < T_COUNT && tensor != T_R && tensor != T_DR, "net / tensor id");
   REQUIRE(byte_offset && ld && plane_bytes, "non-null outputs");
+  if (tensor == T_H0 && h0_recomputed(precision))
+    return fail(NERFPP_ERR_UNSUPPORTED, "nerfpp_workspace_tensor: H0 is not materialised at precision %d (its weight-gradient job recomputes it from X)", precision);
   const WsLayout L = ws_layout(n_rays, n_samples, precision, true);
   const int l = tensor_ld(net, tensor);
   *byte_offset = tensor == T_DG ? (int64_t)L.tensor[net][T_DS] + (DG_COL0 / 16) * FRAG_BYTES : (int64_t)L.tensor[net][tensor];
@@ -325,6 +332,7 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     m.depth_real = (float*)(ws + L.depth_real);
     if (train) { m.ws = make_netws(ws, L, net); m.masks = (uint4*)(ws + L.masks[net]); }
     m.save_lo = a->training == 2 ? 0 : 1;          // training == 2: the backward will be single-pass bf16 (hi planes only)
+    m.skip_h0 = (train && h0_recomputed(P)) ? 1 : 0;
     if (const char* e = PROBE_GETENV("NERFPP_SKIP_H_RT")) m.save_lo |= atoi(e) << 8;   // (probes: tools/probes/recompute_probe.py)
   }
   if (a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
@@ -368,7 +376,14 @@ static void weight_grads(hipStream_t st, const nerfpp_backward_args* a, const Ws
   }
   dw.rows = L.rows;
   dw.rows_padded = L.rows_padded;
-  dw.plan = dw_plan(L.rows);
+  const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
+  dw.h0_from_x = (a->precision == 1 && h0_recomputed(WP)) ? 1 : 0;
+  const PackLayout PL = pack_layout(a->precision);
+  for (int net = 0; net < N_NET; ++net) {
+    dw.fwd_w[net] = (const char*)a->packed + PL.fwd[net];
+    dw.fwd_bias[net] = (const float*)((const char*)a->packed + PL.bias[net]);
+  }
+  dw.plan = dw_plan(L.rows, dw.h0_from_x != 0);
   if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
   launch_dw(st, a->precision, dw);
   if (a->ev_dw_end) (void)hipEventRecord((hipEvent_t)a->ev_dw_end, st);
@@ -382,7 +397,8 @@ static bool defer_dw() {
 // split-K slabs -> flat gradient (fixed summation order, x grad_scale), then the derived remap / colour-head gradients
 static void reduce_grads(hipStream_t st, const nerfpp_backward_args* a, const WsLayout& L, const TblLayout& T) {
   char* ws = (char*)a->workspace;
-  const DwPlan plan = dw_plan(L.rows);
+  const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
+  const DwPlan plan = dw_plan(L.rows, a->precision == 1 && h0_recomputed(WP));
   const float* slabs[N_NET];
   int64_t slab_floats[N_NET];
   const int32_t* utbl[N_NET];

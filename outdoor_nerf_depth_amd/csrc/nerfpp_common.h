@@ -328,7 +328,13 @@ struct DwPlan { int k[N_NET][DW_JOBS]; };
 constexpr int dw_narrow_cost(const DwJob& j) {        // shader cycles per 32-row tile, bf16 (dw_kernel<1, false>, per-shape loops)
   return j.n_o == DSG_LD ? 2258 : j.n_o == 256 ? (j.n_i == 64 ? 1426 : j.n_i == 96 ? 1534 : j.n_i == 320 ? 2927 : 3133) : 775;
 }
-inline DwPlan dw_plan(int64_t rows) {
+// rc: the two L1 jobs (input H0) recompute their input from the encoded point (nerfpp_dw.hip: rc_job).  They read 20 / 22 instead
+// of 32 KiB per 32-row chunk but issue 20 / 22 instead of 16 MFMAs per wave for it, which makes them MATRIX-bound where the plain
+// jobs are HBM-bound (a chunk takes ~1.2x as long): they get DW_RC_SLICES slices each, the ten plain full jobs share the rest of
+// the 256 workgroups.  Measured on one box, step in ms: 16 slices 2.18, 23: 2.052, 26: 2.026, 30: 2.022, 34: 2.033; no recompute
+// (H0 saved): 2.047.
+constexpr int DW_RC_SLICES = 28;
+inline DwPlan dw_plan(int64_t rows, bool rc = false) {
   const JobTable jt = build_all_jobs();
   int64_t cap = rows / 512;
   cap = cap < 1 ? 1 : (cap > DW_KMAX ? DW_KMAX : cap);
@@ -350,6 +356,7 @@ inline DwPlan dw_plan(int64_t rows) {
       int64_t k;
       if (dw_job_is_full(job)) {
         k = 256 / n_full;
+        if (rc) k = job.b_tensor == T_H0 ? DW_RC_SLICES : (256 - 2 * DW_RC_SLICES) / (n_full - 2);
 #ifdef NERFPP_PROBES
         // (timing experiment: NERFPP_DW_RC_K = slices of the full jobs that would recompute their input, the others share the rest)
         if (const char* e = getenv("NERFPP_DW_RC_K")) {

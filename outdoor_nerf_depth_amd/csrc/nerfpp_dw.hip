@@ -139,8 +139,9 @@ __device__ __forceinline__ float bf16_sum8(const bf16x8& v) {
 }
 
 // one 32-row chunk: 2 k16-steps x (<=4 out-blocks x <=2 in-blocks) MFMAs for this wave
+// bufa / bufb: LDS offsets (incl. the lane's tr-read offset) of the A and B operand images (planes OPER_BYTES apart)
 template <int P, bool FULL>
-__device__ __forceinline__ void compute_chunk(lds_addr buf, int wo, int wi, int nbo, int nbi, bool do_bias,
+__device__ __forceinline__ void compute_chunk(lds_addr bufa, lds_addr bufb, int wo, int wi, int nbo, int nbi, bool do_bias,
                                               f32x16 (&acc)[4][2], float (&bsum)[4]) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
@@ -149,10 +150,10 @@ __device__ __forceinline__ void compute_chunk(lds_addr buf, int wo, int wi, int 
     for (int p = 0; p < P; ++p) {
 #pragma unroll
       for (int x = 0; x < 4; ++x)
-        if (FULL || x < nbo) fa[x][p] = tr_frag(buf + p * OPER_BYTES + kk * 512 + 2 * (4 * wo + x) * BLKP);
+        if (FULL || x < nbo) fa[x][p] = tr_frag(bufa + p * OPER_BYTES + kk * 512 + 2 * (4 * wo + x) * BLKP);
 #pragma unroll
       for (int x = 0; x < 2; ++x)
-        if (FULL || x < nbi) fb[x][p] = tr_frag(buf + (P + p) * OPER_BYTES + kk * 512 + 2 * (2 * wi + x) * BLKP);
+        if (FULL || x < nbi) fb[x][p] = tr_frag(bufb + p * OPER_BYTES + kk * 512 + 2 * (2 * wi + x) * BLKP);
     }
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo) {
@@ -393,6 +394,164 @@ __device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, in
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Job L1 of a net when H0 is not a saved tensor (round 5; single-plane workspaces): dW1 = dZ1^T H0 with
+//   H0 = relu(W0 X + b0)
+// recomputed per 32-row chunk from the saved encoded point X (KX = 4 / 6 chunk blocks instead of H0's 16: the job streams
+// 20 / 22 KiB per chunk instead of 32, and the training forward does not write H0 at all).  The bounding experiment of
+// profiles/r05_recompute_probe.md showed what NOT to do -- a second barrier per chunk and the recompute as a serial phase
+// in front of the chunk's MFMAs cost more than the bytes save.  Here the recompute runs ONE CHUNK AHEAD into a double-
+// buffered tile, so that its short dependent MFMA chain, the conversion and the tile write of chunk c + 1 sit between the 16
+// independent MFMAs of chunk c, with one barrier per chunk as before:
+//   iteration c:  wait chunk c + 1 | barrier | DMA chunk c + NB - 1 | H0(c + 1) -> tile[(c + 1) & 1] | dW += dZ1(c)^T tile[c & 1]
+// Wave w owns out-block w of H0: its W0 fragments (KX x 16 B per lane) and its bias slice stay in registers; the X blocks
+// are the forward's B-operand register images (16 B of lane (j, hi) at (2 j + hi) * 16), the MFMA orientation, k order and
+// bias-initialised accumulator are the forward's, so the recomputed tile is bit-identical to what the forward would have
+// saved; it is written in the saved tensors' block form, and the transposed reads of the weight-gradient MFMAs run on it
+// unchanged.  Rows past the end of the batch have X = 0, i.e. H0 = relu(b0) != 0 -- but dZ1 = 0 there, so they add nothing.
+template <int KX>
+struct RcShape {
+  static constexpr int NT = 16 + KX;                        // 1 KiB blocks (= DMA wave-instructions) per chunk: dZ1, then X
+  static constexpr int SLOT = NT * BLKP;
+  static constexpr int TILE0 = 160 * 1024 - 2 * OPER_BYTES; // the two recomputed tiles sit at the top of the CU's LDS
+  static constexpr int NB = TILE0 / SLOT;                   // ring depth: 5 for both nets
+  static constexpr int CW_HI = (NT + 7) / 8, N_HI = NT % 8; // waves < N_HI issue CW_HI instructions per chunk, the others one fewer
+  static_assert(NB >= 4 && NB <= 6 && N_HI != 0, "rc_job ring");
+};
+constexpr int RC_LDS_BYTES = 160 * 1024;
+
+template <int KX>
+__device__ __forceinline__ void rc_job(const DwArgs& a, const DwJob& job, int net, int split, int ksplit, int bid) {
+  using S = RcShape<KX>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const char* ga = (const char*)a.ws[net].t[job.a_tensor];
+  const char* gx = (const char*)a.ws[net].t[T_X];
+  const int64_t rows32 = (a.rows + 31) / 32 * 32;
+  int64_t rps = (rows32 + ksplit - 1) / ksplit;
+  rps = (rps + 31) / 32 * 32;
+  const int64_t r_begin = split * rps;
+  const int64_t r_end = r_begin + rps < rows32 ? r_begin + rps : rows32;
+  const int nchunk = r_end > r_begin ? (int)((r_end - r_begin) / 32) : 0;
+  DW_STAMP(true, 0, __builtin_readcyclecounter());
+  DW_STAMP(true, 4, nchunk);
+  DW_STAMP(true, 5, __builtin_amdgcn_s_getreg((3 << 11) | 20));
+
+  const int wo = wave >> 2, wi = wave & 3;
+  const bool do_bias = job.gb_off >= 0;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[x][0][r] = 0.f; acc[x][1][r] = 0.f; }
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  // resident operands of the recompute: W0 fragments (k-chunk kc, out-block wave) of the packed forward stream, bias slice in the
+  // accumulator (C / D) layout of the forward kernel's init_bias_lds
+  bf16x8 w0[KX];
+#pragma unroll
+  for (int kc = 0; kc < KX; ++kc) w0[kc] = *(const bf16x8*)((const char*)a.fwd_w[net] + (size_t)(kc * 8 + wave) * FRAG_BYTES + lane * 16);
+  f32x16 b0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *(const float4*)(a.fwd_bias[net] + wave * 32 + hi * 16 + 4 * q);
+    b0[4 * q] = v.x; b0[4 * q + 1] = v.y; b0[4 * q + 2] = v.z; b0[4 * q + 3] = v.w;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the counted waits below see DMA loads only
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
+  const int g = lane >> 4, a16 = lane & 15;
+  const int lane_off = (g & 1) * BLKP + ((((g >> 1) * 8 + (a16 >> 2)) * 2 + (a16 & 1)) * 16) + ((a16 >> 1) & 1) * 8;
+  if (nchunk == 0) goto write_out;
+  {
+    auto run = [&](auto cw_c) __attribute__((always_inline)) {
+      constexpr int CW = decltype(cw_c)::value;
+      int issued = 0;
+      auto issue = [&]() __attribute__((always_inline)) {       // next chunk of the slice -> its ring slot
+        const int c = issued++;
+        if (c >= nchunk) return;
+        const size_t tile = (size_t)(r_begin >> 5) + (size_t)c;
+        const uint32_t slot = lds_base + (uint32_t)(c % S::NB) * S::SLOT;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) {
+          const int id = wave + 8 * k;                            // < NT by the choice of CW
+          const char* src = id < 16 ? ga + (tile * 16 + id) * FRAG_BYTES : gx + (tile * KX + (id - 16)) * FRAG_BYTES;
+          glds16(src + lane * 16, slot + (uint32_t)id * BLKP);
+        }
+      };
+      auto wait_chunk = [&](int k) __attribute__((always_inline)) {     // chunk k has landed (wave-uniform; counts need immediates)
+        const int have = issued < nchunk ? issued : nchunk;
+        const int younger = have - 1 - k;
+        switch (younger <= 0 ? 0 : younger) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CW) : "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CW) : "memory"); break;
+        }
+      };
+      auto recompute = [&](int k) __attribute__((always_inline)) {      // H0 of chunk k -> tile[k & 1], out-block `wave`
+        const char* xs = dw_smem + (k % S::NB) * S::SLOT + 16 * BLKP + ((2 * li + hi) << 4);
+        f32x16 rc = b0;
+#pragma unroll
+        for (int kc = 0; kc < KX; ++kc)
+          rc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[kc], *(const bf16x8*)(xs + kc * BLKP), rc, 0, 0, 0);
+        char* dst = dw_smem + S::TILE0 + (k & 1) * OPER_BYTES + 2 * wave * BLKP + ((2 * li + hi) << 4);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          uint4 d;
+          uint32_t* dp = (uint32_t*)&d;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+            typedef short s16x2_ __attribute__((ext_vector_type(2)));
+            const f32x2_ v = {rc[8 * hh + 2 * w], rc[8 * hh + 2 * w + 1]};
+            const s16x2_ zero = {0, 0};
+            dp[w] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_, __builtin_convertvector(v, bf16x2_)), zero));
+          }
+          *(uint4*)(dst + hh * BLKP) = d;
+        }
+      };
+#pragma unroll
+      for (int c = 0; c < S::NB - 1; ++c) issue();
+      wait_chunk(0);
+      __builtin_amdgcn_s_barrier();
+      recompute(0);
+      for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) wait_chunk(c + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's tile writes of the previous iteration
+        __builtin_amdgcn_s_barrier();
+        issue();
+        if (c + 1 < nchunk) recompute(c + 1);
+        compute_chunk<1, true>((c % S::NB) * S::SLOT + lane_off, S::TILE0 + (c & 1) * OPER_BYTES + lane_off, wo, wi, 4, 2, do_bias, acc, bsum);
+      }
+    };
+    if (wave < S::N_HI) run(std::integral_constant<int, S::CW_HI>{});
+    else run(std::integral_constant<int, S::CW_HI - 1>{});
+  }
+write_out:
+  DW_STAMP(true, 1, __builtin_readcyclecounter());
+  float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
+#pragma unroll
+  for (int bo = 0; bo < 4; ++bo) {
+    const int ob = 32 * (4 * wo + bo);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      const int ib = 32 * (2 * wi + bi);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = ob + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        __builtin_nontemporal_store(acc[bo][bi][r], slab + job.gw_off + o * job.gw_ld + ib + li);
+      }
+    }
+    if (do_bias && bo == wi) {
+      const float tot = bsum[bo] + __shfl_xor(bsum[bo], 32, 64);
+      if (hi == 0) __builtin_nontemporal_store(tot, slab + gw_floats(net) + job.gb_off + ob + li);
+    }
+  }
+  DW_STAMP(true, 2, __builtin_readcyclecounter());
+}
+
 // workgroup -> (job of this launch, row slice): jobs in table order (net 0 then net 1), k slices each
 struct DwSched {
   int wg_end[2 * DW_JOBS];       // exclusive prefix of workgroups per job
@@ -420,6 +579,13 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
     else if (job.n_o == DSG_LD) narrow_job<P, DSG_LD, 288, 256>(a, job, net, split, ksplit, dbg, bid);
     else narrow_job<P, 32, 128, 128>(a, job, net, split, ksplit, dbg, bid);
     return;
+  }
+  if constexpr (P == 1) {
+    if (a.h0_from_x && job.b_tensor == T_H0) {               // (wave-uniform: the whole workgroup runs one job)
+      if (net == 0) rc_job<kpe(0)>(a, job, net, split, ksplit, bid);
+      else rc_job<kpe(1)>(a, job, net, split, ksplit, bid);
+      return;
+    }
   }
   const int rb_a = tensor_ld(net, job.a_tensor) * 2, rb_b = tensor_ld(net, job.b_tensor) * 2;   // row bytes
   const char* ga = (const char*)a.ws[net].t[job.a_tensor];
@@ -548,7 +714,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
       }
 #endif
       const lds_addr buf = (c % NBUF) * (2 * P * OPER_BYTES) + lane_off;
-      compute_chunk<P, true>(buf, wo, wi, nbo, nbi, do_bias, acc, bsum);
+      compute_chunk<P, true>(buf, buf + P * OPER_BYTES, wo, wi, nbo, nbi, do_bias, acc, bsum);
     }
   }
 
@@ -623,7 +789,7 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
 #endif
   const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only, 4..: recompute emulation
   if (P == 1) {
-    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, lds, st, a, sf, dbg);
+    hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, a.h0_from_x ? (size_t)RC_LDS_BYTES : lds, st, a, sf, dbg);
     hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg);
   } else {
     hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, sf, dbg);

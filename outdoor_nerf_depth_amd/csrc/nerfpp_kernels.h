@@ -27,6 +27,7 @@ struct MlpFwdArgs {
   NetWs ws;
   uint4* masks;                  // ReLU sign bits [9 stages][rows_padded/32][64 lanes] (training)
   int save_lo;                   // split-bf16 training: 0 = write the hi planes of the saved tensors only (bf16 backward)
+  int skip_h0;                   // training, precisions 1 / 3: H0 is not written -- its weight-gradient job recomputes it (nerfpp_dw.hip: rc_job)
 };
 
 struct MlpBwdArgs {
@@ -51,6 +52,11 @@ struct DwArgs {
   int64_t rows, rows_padded;
   float* slabs[N_NET];           // [DW_KMAX][gslab_floats(net)]; job j fills the first plan.k[net][j] slabs
   DwPlan plan;
+  // H0 = relu(W0 X + b0) is recomputed inside the L1 job from the saved encoded point (single-plane workspaces): the packed
+  // forward weight stream (its first kpe x 8 fragments are W0) and the forward bias stream of each net
+  int h0_from_x;
+  const void* fwd_w[N_NET];
+  const float* fwd_bias[N_NET];
 };
 
 }  // namespace nerfpp

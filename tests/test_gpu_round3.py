@@ -168,7 +168,7 @@ def test_sample_fine_pair_rng_and_det_at_bench_size(ops):
 # ------------------------------------------------------------------------------------------------ saved tensors (layout)
 @pytest.mark.parametrize('precision', [1, 2])
 def test_saved_activations_in_the_workspace_match_the_oracle(ops, precision):
-    """The fragment-major saved tensors, read back through nerfpp_workspace_tensor and un-permuted: H0..H7 and G of both nets
+    """The fragment-major saved tensors, read back through nerfpp_workspace_tensor and un-permuted: H0..H7 (H1..H7 at precision 1) and G of both nets
     against the oracle's activations of the same forward (48 rays x 64 samples: the last 256-row tile is ragged).  Checks
     the layout contract of include/nerfpp_hip.h directly, not only through the gradients."""
     n, S = 48, 64
@@ -187,6 +187,13 @@ def test_saved_activations_in_the_workspace_match_the_oracle(ops, precision):
         # samples in bg_z order and composite them back to front: the saved rows are the oracle's, reversed per ray)
         order = (lambda a: a.reshape(n, S, -1)[:, ::-1].reshape(n * S, -1)) if net == 1 else (lambda a: a)
         for l in range(8):
+            if l == 0 and precision == 1:
+                # single-plane workspaces do not materialise H0 (round 5): its weight-gradient job recomputes it from X per 32-row
+                # chunk (csrc/nerfpp_dw.hip: rc_job); the gradient tests (tests/test_gpu_parity.py) are what checks that path
+                from outdoor_nerf_depth_amd._lib import NerfppError
+                with pytest.raises(NerfppError):
+                    eng.saved_tensor(net, 1)
+                continue
             got = N(eng.saved_tensor(net, 1 + l))
             if precision == 2:
                 got = got + N(eng.saved_tensor(net, 1 + l, plane=1))          # hi + lo

@@ -209,7 +209,7 @@ def test_fp16_fwd_saves_feed_the_bf16_backward(levels):
     r2 = e2.forward(ray_o, ray_d, far, fg, bg, training=True)
     r3 = e3.forward(ray_o, ray_d, far, fg, bg, training=True)
     for net in (0, 1):
-        for t in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11):          # X, H0..H7, G, DIRX
+        for t in (0, 2, 3, 4, 5, 6, 7, 8, 10, 11):          # X, H1..H7, G, DIRX (the fp16x2w forward does not materialise H0)
             a2, a3 = e2.saved_tensor(net, t), e3.saved_tensor(net, t)
             if t in (0, 11):          # the encodings: the same float32 value rounded two ways
                 # one bf16 ulp is <= 2^-7 of the value; + the last-bit freedom of the point itself (the two kernel instantiations
