@@ -147,13 +147,12 @@ int nerfpp_build_tables(int net, int32_t* fwd_tbl, int32_t* bias_tbl, int32_t* b
 int64_t nerfpp_level_tables_elems(void);
 int nerfpp_build_level_tables(int32_t* host_tables);
 
-/* Host-side introspection of the weight-gradient launch plan for a level with `rows` = n_rays * n_samples whose forward ran at
- * `workspace_precision`: k_out[net * 10 + job] = row slices (= workgroups = gradient slabs) of job `job` of net `net`
+/* Host-side introspection of the weight-gradient launch plan for a level with `rows` = n_rays * n_samples and a backward at
+ * `backward_precision` (1 or 2): k_out[net * 10 + job] = row slices (= workgroups = gradient slabs) of job `job` of net `net`
  * (job order: L0, L1..L4, L5 (encoded-point and h4 columns), L6, L7, [sigma | rgb0] (M and view-dir columns),
- * rgb1), is_full_out[...] = 1 for the 256 x 256 jobs.  With a single-plane workspace (precisions 1, 3) job L1 recomputes its
- * input H0 from the encoded point and gets more slices than the other full jobs.  No GPU needed.  Returns the number of jobs
- * per net (10). */
-int nerfpp_dw_plan(int64_t rows, int workspace_precision, int32_t* k_out, int32_t* is_full_out);
+ * rgb1), is_full_out[...] = 1 for the 256 x 256 jobs.  In a bf16 backward job L1 recomputes its input H0 from the encoded point
+ * and gets more slices than the other full jobs.  No GPU needed.  Returns the number of jobs per net (10). */
+int nerfpp_dw_plan(int64_t rows, int backward_precision, int32_t* k_out, int32_t* is_full_out);
 
 /* packed weights of one level (both nets, forward + backward streams + biases) */
 int64_t nerfpp_packed_bytes(int precision);
@@ -174,7 +173,8 @@ int64_t nerfpp_workspace_bytes(int n_rays, int n_samples, int precision, int tra
  * (per 32-row tile and 16-column chunk one 1 KiB block = the register image of the wave that produced it); in split-bf16
  * precision the `lo` plane follows at + plane_bytes.  Rows = n_rays * n_samples in (ray, sample) order.
  * Precisions 1 and 3 do not materialise H0 (tensor 1): the weight-gradient job that needs it recomputes it from X per 32-row
- * chunk (ABI 7); the call returns NERFPP_ERR_UNSUPPORTED for it. */
+ * chunk (ABI 7); the call returns NERFPP_ERR_UNSUPPORTED for it.  (A precision-2 forward with training == 2 leaves its H0
+ * planes unwritten for the same reason: every bf16 backward recomputes H0.) */
 int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, int tensor,
                             int64_t* byte_offset, int32_t* ld, int64_t* plane_bytes);
 

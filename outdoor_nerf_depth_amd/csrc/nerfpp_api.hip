@@ -248,9 +248,9 @@ int nerfpp_build_level_tables(int32_t* host_tables) {
   return NERFPP_OK;
 }
 
-int nerfpp_dw_plan(int64_t rows, int workspace_precision, int32_t* k_out, int32_t* is_full_out) {
-  if (!k_out || rows <= 0 || !prec_ok_fwd(workspace_precision)) return -1;
-  const DwPlan pl = dw_plan(rows, h0_recomputed(workspace_precision));
+int nerfpp_dw_plan(int64_t rows, int backward_precision, int32_t* k_out, int32_t* is_full_out) {
+  if (!k_out || rows <= 0 || !prec_ok(backward_precision)) return -1;
+  const DwPlan pl = dw_plan(rows, backward_precision == 1);
   const JobTable jt = build_all_jobs();
   for (int net = 0; net < N_NET; ++net)
     for (int j = 0; j < DW_JOBS; ++j) {
@@ -332,7 +332,7 @@ int nerfpp_level_forward(void* stream, const nerfpp_forward_args* a) {
     m.depth_real = (float*)(ws + L.depth_real);
     if (train) { m.ws = make_netws(ws, L, net); m.masks = (uint4*)(ws + L.masks[net]); }
     m.save_lo = a->training == 2 ? 0 : 1;          // training == 2: the backward will be single-pass bf16 (hi planes only)
-    m.skip_h0 = (train && h0_recomputed(P)) ? 1 : 0;
+    m.skip_h0 = (train && (h0_recomputed(P) || a->training == 2)) ? 1 : 0;   // (training == 2: the bf16 backward recomputes it too)
     if (const char* e = PROBE_GETENV("NERFPP_SKIP_H_RT")) m.save_lo |= atoi(e) << 8;   // (probes: tools/probes/recompute_probe.py)
   }
   if (a->ev_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_mlp_begin, st);
@@ -377,7 +377,8 @@ static void weight_grads(hipStream_t st, const nerfpp_backward_args* a, const Ws
   dw.rows = L.rows;
   dw.rows_padded = L.rows_padded;
   const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
-  dw.h0_from_x = (a->precision == 1 && h0_recomputed(WP)) ? 1 : 0;
+  dw.h0_from_x = a->precision == 1 ? 1 : 0;      // every bf16 backward: X (hi plane) is in every workspace, W0 in its own pack
+  (void)WP;
   const PackLayout PL = pack_layout(a->precision);
   for (int net = 0; net < N_NET; ++net) {
     dw.fwd_w[net] = (const char*)a->packed + PL.fwd[net];
@@ -398,7 +399,8 @@ static bool defer_dw() {
 static void reduce_grads(hipStream_t st, const nerfpp_backward_args* a, const WsLayout& L, const TblLayout& T) {
   char* ws = (char*)a->workspace;
   const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
-  const DwPlan plan = dw_plan(L.rows, a->precision == 1 && h0_recomputed(WP));
+  const DwPlan plan = dw_plan(L.rows, a->precision == 1);
+  (void)WP;
   const float* slabs[N_NET];
   int64_t slab_floats[N_NET];
   const int32_t* utbl[N_NET];

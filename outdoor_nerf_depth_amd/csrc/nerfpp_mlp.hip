@@ -758,7 +758,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
     if constexpr (TRAIN && ROLES) {
       // (probes: H_l stays unsaved, its sign words go out; SKIP_H < 0: the mask comes with the launch, bits 8.. of save_lo)
       const bool skip = (P == 1 && (((probe::SKIP_H < 0 ? a.save_lo >> 8 : probe::SKIP_H) >> mask_stage) & 1)) ||
-                        (P != 2 && mask_stage == 0 && a.skip_h0);      // H0: recomputed by its weight-gradient job (rc_job)
+                        (mask_stage == 0 && a.skip_h0);      // H0: recomputed by its weight-gradient job (nerfpp_dw.hip: rc_job)
       if (skip) {
         if (partner && blk == 1) mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
       } else if (loader) {
