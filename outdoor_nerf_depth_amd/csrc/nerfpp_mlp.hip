@@ -601,7 +601,29 @@ __device__ __forceinline__ void pe_sincos(float arg, float* sn, float* cs) {
     *sn = __builtin_amdgcn_sinf(r);
     *cs = __builtin_amdgcn_cosf(r);
   } else {
-    sincosf(arg, sn, cs);
+    // split-bf16 (parity) precision: float32-accurate sin / cos for |arg| <= 1024 (points of the unit sphere x 2^9), branch-free:
+    // three-term Cody-Waite reduction by pi / 2 with FMAs (n <= 652 has 10 bits, n * HI is exact inside the FMA and the first
+    // difference is exactly representable), degree-9 / degree-8 minimax kernels on [-pi/4, pi/4], quadrant swap.  Measured
+    // against float64 over 2 M arguments up to 512 (tests/test_layout_emulation.py carries the numpy twin): max error 7.3e-8
+    // = 1.2 ulp, against 0.5 ulp for a correctly rounded result -- the reference's torch.sin is itself ~1 ulp.  libm's sincosf
+    // (~70 instructions with a Payne-Hanek branch, 20-26 calls per lane and tile) took 2-3 % of the split-bf16 forward.
+    const float n = __builtin_rintf(arg * 0.6366197723675814f);
+    float r = __builtin_fmaf(-n, 1.5707962512969971f, arg);
+    r = __builtin_fmaf(-n, 7.5497901264043321e-08f, r);
+    r = __builtin_fmaf(-n, -1.7763568394002505e-15f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, 2.7183114e-6f, -0.00019839335f);
+    ps = __builtin_fmaf(z, ps, 0.008333329f);
+    ps = __builtin_fmaf(z, ps, -0.16666667f);
+    const float s = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, 2.4390449e-5f, -0.0013886763f);
+    pc = __builtin_fmaf(z, pc, 0.04166662f);
+    pc = __builtin_fmaf(z, pc, -0.5f);
+    const float c = __builtin_fmaf(z, pc, 1.0f);
+    const int q = (int)n;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
   }
 }
 
