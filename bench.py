@@ -56,6 +56,8 @@ SURVEY_ALGO_BYTES_PER_RAY = 18.8e3   # inputs + outputs + amortised
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
 EXEC_OVER_ALGO = {'mlp_fwd': 1.0 - 2 * 65536.0 / (593408 + 604160), 'mlp_bwd': 1.0 - 2 * 65536.0 / (2 * 557696), 'dw': 1.0}
 DW_BYTES_PER_ROW = (4576 + 4640) * 2        # columns the jobs of nerfpp_common.h: build_all_jobs read per row (fg + bg), bf16
+# a bf16 backward: job L1 reads the encoded point (64 / 96 columns) instead of H0 (256) and recomputes it (nerfpp_dw.hip: rc_job)
+DW_BYTES_PER_ROW_BF16 = (4576 - 192 + 4640 - 160) * 2
 FLOP_PER_RAY_RENDER = 0.613e9    # forward only, both levels
 SETUP_STEPS = 12                 # untimed steps run when a trainer is set up, before the W warm-up steps (see run_mode)
 # HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16: PARSED at start-up from the rocprofv3 --pmc passes committed
@@ -291,7 +293,7 @@ def run_mode(args, precision, rank, world, device, batches):
     kernels = {
         'mlp_fwd_L1': dict(ms=fwd_ms, flop=2.0 * fwd_macs * rows),
         'mlp_bwd_L1': dict(ms=bwd_ms, flop=2.0 * (ALGO_MACS['dx'][0] + ALGO_MACS['dx'][1]) * rows),
-        'dw_L1': dict(ms=dw_ms, flop=2.0 * fwd_macs * rows, bytes=float(DW_BYTES_PER_ROW) * P * rows),
+        'dw_L1': dict(ms=dw_ms, flop=2.0 * fwd_macs * rows, bytes=float(DW_BYTES_PER_ROW * 2 if P == 2 else DW_BYTES_PER_ROW_BF16) * rows),
     }
     for k in kernels.values():
         k['tflops'] = k['flop'] / (k['ms'] * 1e-3) / 1e12
@@ -346,7 +348,7 @@ def roofline(r):
             # (no activation, nerf_network.py:131) is folded into the colour head (csrc/nerfpp_common.h, forward stages)
             'executed_over_algorithmic_macs': {k: round(v, 4) for k, v in EXEC_OVER_ALGO.items()},
             'hbm_view_of_dw': {'bound': 'hbm', 'achieved': dw['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                               'frac': dw['gbs'] / PEAK_HBM_GBS, 'operand_bytes_per_row': DW_BYTES_PER_ROW,
+                               'frac': dw['gbs'] / PEAK_HBM_GBS, 'operand_bytes_per_row': DW_BYTES_PER_ROW_BF16,
                                'traffic': PMC_TRAFFIC['dw_L1'] if r['pmc_ok'] else None}}
 
 
