@@ -383,6 +383,8 @@ static void weight_grads(hipStream_t st, const nerfpp_backward_args* a, const Ws
   for (int net = 0; net < N_NET; ++net) {
     dw.fwd_w[net] = (const char*)a->packed + PL.fwd[net];
     dw.fwd_bias[net] = (const float*)((const char*)a->packed + PL.bias[net]);
+    dw.bwd_w[net] = (const char*)a->packed + PL.bwd[net];
+    dw.masks[net] = (const uint4*)(ws + L.masks[net]);
   }
   dw.plan = dw_plan(L.rows, dw.h0_from_x != 0);
   if (a->ev_dw_begin) (void)hipEventRecord((hipEvent_t)a->ev_dw_begin, st);
@@ -472,6 +474,7 @@ int nerfpp_level_backward(void* stream, const nerfpp_backward_args* a) {
     m.d_out = (const float*)(ws + L.d_out[net]);
     m.ws = make_netws(ws, L, net);
     m.masks = (const uint4*)(ws + L.masks[net]);
+    m.skip_dz7 = P == 1 ? 1 : 0;
   }
   if (a->ev_bwd_begin) (void)hipEventRecord((hipEvent_t)a->ev_bwd_begin, st);
   if (split_nets()) {

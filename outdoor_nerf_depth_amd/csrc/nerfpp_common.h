@@ -334,6 +334,10 @@ constexpr int dw_narrow_cost(const DwJob& j) {        // shader cycles per 32-ro
 // the 256 workgroups.  Measured on one box, step in ms: 16 slices 2.18, 23: 2.052, 26: 2.026, 30: 2.022, 34: 2.033; no recompute
 // (H0 saved): 2.047.
 constexpr int DW_RC_SLICES = 28;
+// ... and the two L7 jobs recompute dZ7 from [dS | dG] (rc7_job: 27 instead of 32 KiB per chunk, 25 instead of 16 MFMAs per wave).
+// Measured on one box, step in ms: 24 slices 2.045, 30: 1.998, 36: 2.006, 42: 2.038; dZ7 saved: 2.006 -- the dX kernel gains what the
+// matrix-bound job costs, within 0.4 %; kept for the 512 B per row it takes out of the HBM traffic.
+constexpr int DW_RC7_SLICES = 30;
 inline DwPlan dw_plan(int64_t rows, bool rc = false) {
   const JobTable jt = build_all_jobs();
   int64_t cap = rows / 512;
@@ -356,7 +360,8 @@ inline DwPlan dw_plan(int64_t rows, bool rc = false) {
       int64_t k;
       if (dw_job_is_full(job)) {
         k = 256 / n_full;
-        if (rc) k = job.b_tensor == T_H0 ? DW_RC_SLICES : (256 - 2 * DW_RC_SLICES) / (n_full - 2);
+        if (rc) k = job.b_tensor == T_H0 ? DW_RC_SLICES : job.a_tensor == T_DZ0 + 7 ? DW_RC7_SLICES
+                                                        : (256 - 2 * DW_RC_SLICES - 2 * DW_RC7_SLICES) / (n_full - 4);
 #ifdef NERFPP_PROBES
         // (timing experiment: NERFPP_DW_RC_K = slices of the full jobs that would recompute their input, the others share the rest)
         if (const char* e = getenv("NERFPP_DW_RC_K")) {

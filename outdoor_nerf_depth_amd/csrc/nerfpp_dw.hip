@@ -552,6 +552,155 @@ write_out:
   DW_STAMP(true, 2, __builtin_readcyclecounter());
 }
 
+
+// Job L7 of a net in a bf16 backward (round 5): dW7 = dZ7^T H6 with
+//   dZ7 = mask7 * (Wc^T dG + wsigma dsigma)
+// recomputed per 32-row chunk from the saved [dS | dG] tensor (10 chunk blocks instead of dZ7's 16) and the ReLU sign words of
+// H7 (one 1 KiB block per tile), so that the dX kernel does not write dZ7 at all.  Same pipeline as rc_job (one chunk ahead,
+// double-buffered tile, one barrier per chunk); here the recomputed tile is the A operand.  Wave w owns out-block w of dZ7:
+// the 9 live fragments of stage BS_DH7 of the packed backward stream stay in registers; operand chunk kc < 8 is block 2 + kc of
+// [dS | dG] (the dG chunks), chunk 8 is block 0 (dsigma in slot 0) -- the dX kernel's own operand order, zero-initialised
+// accumulator and mask_to_frags, so the tile is bit-identical to the dZ7 that kernel would have written.
+struct Rc7Shape {
+  static constexpr int NT = 16 + DSG_LD / 16 + 1;            // H6 blocks, [dS | dG] blocks, the sign-word block
+  static constexpr int SLOT = NT * BLKP;
+  static constexpr int TILE0 = 160 * 1024 - 2 * OPER_BYTES;
+  static constexpr int NB = TILE0 / SLOT;                   // 4
+  static constexpr int CW_HI = (NT + 7) / 8, N_HI = NT % 8;
+  static constexpr int KL = 9;                               // live k-chunks of stage BS_DH7
+  static_assert(NB >= 4 && N_HI != 0 && NT == 27, "rc7_job ring");
+};
+
+__device__ __forceinline__ void rc7_job(const DwArgs& a, const DwJob& job, int net, int split, int ksplit, int bid) {
+  using S = Rc7Shape;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const char* gb = (const char*)a.ws[net].t[job.b_tensor];             // H6
+  const char* gd = (const char*)a.ws[net].t[T_DS];                     // [dS | dG], 10 blocks per tile
+  const char* gm = (const char*)(a.masks[net] + (size_t)7 * (a.rows_padded / 32) * 64);     // sign words of H7
+  const int64_t rows32 = (a.rows + 31) / 32 * 32;
+  int64_t rps = (rows32 + ksplit - 1) / ksplit;
+  rps = (rps + 31) / 32 * 32;
+  const int64_t r_begin = split * rps;
+  const int64_t r_end = r_begin + rps < rows32 ? r_begin + rps : rows32;
+  const int nchunk = r_end > r_begin ? (int)((r_end - r_begin) / 32) : 0;
+  DW_STAMP(true, 0, __builtin_readcyclecounter());
+  DW_STAMP(true, 4, nchunk);
+  DW_STAMP(true, 5, __builtin_amdgcn_s_getreg((3 << 11) | 20));
+  const int wo = wave >> 2, wi = wave & 3;
+  const bool do_bias = job.gb_off >= 0;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[x][0][r] = 0.f; acc[x][1][r] = 0.f; }
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  bf16x8 wt[S::KL];
+#pragma unroll
+  for (int kc = 0; kc < S::KL; ++kc)
+    wt[kc] = *(const bf16x8*)((const char*)a.bwd_w[net] + (size_t)(bs_frag_off(BS_DH7) + kc * 8 + wave) * FRAG_BYTES + lane * 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dw_smem;
+  const int g = lane >> 4, a16 = lane & 15;
+  const int lane_off = (g & 1) * BLKP + ((((g >> 1) * 8 + (a16 >> 2)) * 2 + (a16 & 1)) * 16) + ((a16 >> 1) & 1) * 8;
+  if (nchunk > 0) {
+    auto run = [&](auto cw_c) __attribute__((always_inline)) {
+      constexpr int CW = decltype(cw_c)::value;
+      int issued = 0;
+      auto issue = [&]() __attribute__((always_inline)) {
+        const int c = issued++;
+        if (c >= nchunk) return;
+        const size_t tile = (size_t)(r_begin >> 5) + (size_t)c;
+        const uint32_t slot = lds_base + (uint32_t)(c % S::NB) * S::SLOT;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) {
+          const int id = wave + 8 * k;
+          const char* src = id < 16 ? gb + (tile * 16 + id) * FRAG_BYTES
+                          : id < 26 ? gd + (tile * (DSG_LD / 16) + (id - 16)) * FRAG_BYTES : gm + tile * FRAG_BYTES;
+          glds16(src + lane * 16, slot + (uint32_t)id * BLKP);
+        }
+      };
+      auto wait_chunk = [&](int k) __attribute__((always_inline)) {
+        const int have = issued < nchunk ? issued : nchunk;
+        const int younger = have - 1 - k;
+        switch (younger <= 0 ? 0 : younger) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CW) : "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
+        }
+      };
+      auto recompute = [&](int k) __attribute__((always_inline)) {      // dZ7 of chunk k -> tile[k & 1], out-block `wave`
+        const char* sl = dw_smem + (k % S::NB) * S::SLOT;
+        const char* ds = sl + 16 * BLKP + ((2 * li + hi) << 4);
+        f32x16 rc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rc[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < S::KL; ++kc)
+          rc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[kc], *(const bf16x8*)(ds + (kc < 8 ? 2 + kc : 0) * BLKP), rc, 0, 0, 0);
+        const uint4 bits = *(const uint4*)(sl + 26 * BLKP + lane * 16);
+        const uint32_t wsel[4] = {bits.x, bits.y, bits.z, bits.w};
+        uint32_t act = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) act = (wave >> 1) == q ? ~wsel[q] : act;          // bit set = unit active
+        char* dst = dw_smem + S::TILE0 + (k & 1) * OPER_BYTES + 2 * wave * BLKP + ((2 * li + hi) << 4);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          uint4 d;
+          uint32_t* dp = (uint32_t*)&d;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+            typedef short s16x2_ __attribute__((ext_vector_type(2)));
+            const f32x2_ v = {rc[8 * hh + 2 * w], rc[8 * hh + 2 * w + 1]};
+            const int j = (wave & 1) * 8 + hh * 4 + w;
+            const uint32_t keep = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_, act << j) >> (s16x2_){15, 15});
+            dp[w] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_)) & keep;
+          }
+          *(uint4*)(dst + hh * BLKP) = d;
+        }
+      };
+#pragma unroll
+      for (int c = 0; c < S::NB - 1; ++c) issue();
+      wait_chunk(0);
+      __builtin_amdgcn_s_barrier();
+      recompute(0);
+      for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) wait_chunk(c + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue();
+        if (c + 1 < nchunk) recompute(c + 1);
+        compute_chunk<1, true>(S::TILE0 + (c & 1) * OPER_BYTES + lane_off, (c % S::NB) * S::SLOT + lane_off, wo, wi, 4, 2, do_bias, acc, bsum);
+      }
+    };
+    if (wave < S::N_HI) run(std::integral_constant<int, S::CW_HI>{});
+    else run(std::integral_constant<int, S::CW_HI - 1>{});
+  }
+  DW_STAMP(true, 1, __builtin_readcyclecounter());
+  float* slab = a.slabs[net] + (size_t)split * gslab_floats(net);
+#pragma unroll
+  for (int bo = 0; bo < 4; ++bo) {
+    const int ob = 32 * (4 * wo + bo);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      const int ib = 32 * (2 * wi + bi);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = ob + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        __builtin_nontemporal_store(acc[bo][bi][r], slab + job.gw_off + o * job.gw_ld + ib + li);
+      }
+    }
+    if (do_bias && bo == wi) {
+      const float tot = bsum[bo] + __shfl_xor(bsum[bo], 32, 64);
+      if (hi == 0) __builtin_nontemporal_store(tot, slab + gw_floats(net) + job.gb_off + ob + li);
+    }
+  }
+  DW_STAMP(true, 2, __builtin_readcyclecounter());
+}
+
 // workgroup -> (job of this launch, row slice): jobs in table order (net 0 then net 1), k slices each
 struct DwSched {
   int wg_end[2 * DW_JOBS];       // exclusive prefix of workgroups per job
@@ -584,6 +733,10 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const DwSched& sc, int 
     if (a.h0_from_x && job.b_tensor == T_H0) {               // (wave-uniform: the whole workgroup runs one job)
       if (net == 0) rc_job<kpe(0)>(a, job, net, split, ksplit, bid);
       else rc_job<kpe(1)>(a, job, net, split, ksplit, bid);
+      return;
+    }
+    if (a.h0_from_x && job.a_tensor == T_DZ0 + 7) {
+      rc7_job(a, job, net, split, ksplit, bid);
       return;
     }
   }

@@ -36,6 +36,7 @@ struct MlpBwdArgs {
   const float* d_out;            // [rows, 4] (d rgb_pre[3], d sigma_raw)
   NetWs ws;
   const uint4* masks;
+  int skip_dz7;                  // bf16 backward: dZ7 is not written -- its weight-gradient job recomputes it from [dS | dG] (rc7_job)
 };
 
 struct LossFuse {                // loss head folded into the compositing backward (nerfpp_backward_args::fused_loss)
@@ -57,6 +58,10 @@ struct DwArgs {
   int h0_from_x;
   const void* fwd_w[N_NET];
   const float* fwd_bias[N_NET];
+  // ... and dZ7 = mask7 * (Wc^T dG + wsigma dsigma) inside the L7 job from the saved [dS | dG] tensor and the sign words of H7:
+  // the packed backward (transposed) weight stream (stage BS_DH7) and the ReLU sign words of each net
+  const void* bwd_w[N_NET];
+  const uint4* masks[N_NET];
 };
 
 }  // namespace nerfpp

@@ -998,6 +998,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a, const int bid)
     constexpr int NCH = decltype(nch_c)::value, HMAX = NW >= 5 ? 4 : NW - 1, HN = NCH / 4 < HMAX ? NCH / 4 : HMAX;
     constexpr int Q = (NCH + HN - 1) / HN, CPB = LD::BF / 8;
     if constexpr (ROLES) {
+      if (P == 1 && a.skip_dz7 && base == a.ws.t[T_DZ0 + 7]) return;      // recomputed by its weight-gradient job (nerfpp_dw.hip: rc7_job)
       if (loader) {
         if (blk == 0) handoff_write<NCH, P>(region, lane, frags);
       } else {

@@ -253,7 +253,7 @@ def test_level_tables_concatenate_both_nets():
 
 def test_weight_gradient_launch_plan():
     """Host code of the dW launch plan (nerfpp_dw_plan): every job gets >= 1 row slice, the 12 full 256x256
-    jobs get equal shares (split-bf16 backward; in a bf16 backward the two recomputing L1 jobs get 28, the others 20), the narrow jobs' workgroups add up to exactly one round of the 256 CUs and follow
+    jobs get equal shares (split-bf16 backward; in a bf16 backward the recomputing L1 / L7 jobs get 28 / 30, the others 17), the narrow jobs' workgroups add up to exactly one round of the 256 CUs and follow
     their measured cost per row; small batches are capped at rows / 512 slices."""
     import ctypes as C
     lib = L.lib()
@@ -268,7 +268,9 @@ def test_weight_gradient_launch_plan():
             assert (k[full == 1] == 21).all()
         if cap == 64 and wp != 2:
             # bf16 backward: job L1 (input H0) recomputes its input and is matrix-bound: more slices, one round in total
-            assert k[1] == k[11] == 28 and (np.delete(k[full == 1], [0, 6]) == 20).all() and k[full == 1].sum() == 256
+            # (and job L7 recomputes dZ7 from [dS | dG]: 30)
+            assert k[1] == k[11] == 28 and k[7] == k[17] == 30 and (np.delete(k[full == 1], [0, 5, 6, 11]) == 17).all()
+            assert 250 <= k[full == 1].sum() <= 256
         if cap == 64:
             nk = k[full == 0]
             # L5 = dZ5^T [X | H4] (256 + 320 / 352 columns) is the widest narrow job, rgb1 (32 + 128) the narrowest
