@@ -97,7 +97,8 @@ __device__ __forceinline__ bf16x8 tr_frag(lds_addr off, uint32_t row2 = 128) {
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + off + row2));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-constexpr int DW_LDS_BYTES = 8 * OPER_BYTES;   // 144 KiB of dynamic LDS for every instantiation
+constexpr int DW_LDS_BYTES = 8 * OPER_BYTES;   // 144 KiB: the full jobs' ring (4 x 2 operand images)
+constexpr int NARROW_LDS_BYTES = 160 * 1024;    // the narrow launch takes the whole LDS of the CU: its jobs are bound by bytes in flight
 // Narrow jobs, per shape.  An operand image is its n / 16 chunk blocks per plane per 32-row tile; a ring slot holds T tiles
 // (two for the 160-column jobs, whose 10 KiB tiles are too little work per barrier: the serial chain wait -> barrier -> DMA
 // issue -> LDS read -> MFMA took 870-980 cycles per tile against ~700 of HBM time).  The wave index runs along the LONGER
@@ -125,7 +126,7 @@ struct NarrowShape {
   static constexpr int CHUNK = T * SUB;
   static constexpr int NT = P * (NBLK_A + NBLK_B), NTOT = T * NT;       // DMA wave-instructions per tile / per slot
   static constexpr int CW_HI = (NTOT + 7) / 8;                 // waves < NTOT % 8 issue CW_HI of them, the others one fewer
-  static constexpr int NB = DW_LDS_BYTES / CHUNK > 8 ? 8 : DW_LDS_BYTES / CHUNK;
+  static constexpr int NB = NARROW_LDS_BYTES / CHUNK > 8 ? 8 : NARROW_LDS_BYTES / CHUNK;
   static constexpr int KG = P == 1 ? 6 : 3;                    // short-axis fragments read ahead of their MFMAs (registers)
   static_assert(NW <= 8 && NTOT >= 8 && NB >= 2 && (NB - 2) * CW_HI < 63, "narrow dW shape");
 };
@@ -381,7 +382,7 @@ __device__ __forceinline__ void narrow_pass(const DwArgs& a, const DwJob& job, i
 template <int P, int N_O, int N_I, int N_I1>
 __device__ __forceinline__ void narrow_job(const DwArgs& a, const DwJob& job, int net, int split, int ksplit, int dbg, int bid) {
   constexpr int N_IB = N_I / 32, T = (N_O + N_I) / 16 <= 10 ? 2 : 1;
-  if constexpr (DW_LDS_BYTES / (T * P * ((N_O + N_I) / 16) * BLKP) >= 2) {
+  if constexpr (NARROW_LDS_BYTES / (T * P * ((N_O + N_I) / 16) * BLKP) >= 2) {
     narrow_pass<P, N_O, N_I1, 0, N_IB>(a, job, net, split, ksplit, dbg, bid);
   } else {
     constexpr int H = (N_IB + 1) / 2;
@@ -943,9 +944,9 @@ void launch_dw(hipStream_t st, int P, const DwArgs& a) {
   const int dbg = PROBE_GETENV("NERFPP_DW_DEBUG") ? atoi(PROBE_GETENV("NERFPP_DW_DEBUG")) : 0;   // 1: DMA only, 2: MFMA only, 4..: recompute emulation
   if (P == 1) {
     hipLaunchKernelGGL((dw_kernel<1, true>), gfull, block, a.h0_from_x ? (size_t)RC_LDS_BYTES : lds, st, a, sf, dbg);
-    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, lds, st, a, sn, dbg);
+    hipLaunchKernelGGL((dw_kernel<1, false>), gnarrow, block, (size_t)NARROW_LDS_BYTES, st, a, sn, dbg);
   } else {
     hipLaunchKernelGGL((dw_kernel<2, true>), gfull, block, lds, st, a, sf, dbg);
-    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, lds, st, a, sn, dbg);
+    hipLaunchKernelGGL((dw_kernel<2, false>), gnarrow, block, (size_t)NARROW_LDS_BYTES, st, a, sn, dbg);
   }
 }
