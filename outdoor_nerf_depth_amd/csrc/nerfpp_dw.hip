@@ -27,6 +27,11 @@
 //   * the number of row slices is per job (dw_plan, nerfpp_common.h): every launch fills the 256 CUs
 //     once with workgroups that finish at about the same time.
 //   * bias gradients: VALU column sums of the A fragments, split over the waves that share them.
+//   * a bf16 backward (round 5): two operands are NOT saved tensors but recomputed inside their job, one 32-row chunk ahead
+//     into a double-buffered tile -- H0 = relu(W0 X + b0) from the encoded point in job L1 (rc_job), dZ7 = mask7 *
+//     (Wc^T dG + wsigma dsigma) from [dS | dG] and the sign words of H7 in job L7 (rc7_job); the MLP kernels then write 512 B
+//     per row less each.  Those jobs are matrix-bound and get more slices (dw_plan).  The narrow launch takes the CU's whole
+//     160 KiB of LDS (deeper rings), the full launch 144 KiB (160 with the recomputing jobs).
 // Rows beyond `rows` up to rows_padded (a multiple of 256) are zero in every saved tensor (the MLP kernels
 // zero-fill their tile tails), so no masking is needed.
 #include "probe_env.h"

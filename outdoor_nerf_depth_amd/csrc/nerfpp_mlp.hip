@@ -6,12 +6,15 @@
 //                    -> v_mfma_f32_32x32x16_bf16.
 //                    Reference: nerf_network.py:42-60,120-142; ddp_model.py:16-45,86-94,107-120.
 //   mlp_bwd_kernel : the dX chain of the same network (closed-form backward of the above; the
-//                    reference relies on autograd), again chained in registers; writes every dZ
-//                    for the weight-gradient GEMMs (nerfpp_dw.hip).
+//                    reference relies on autograd), again chained in registers; writes the dZ tensors
+//                    for the weight-gradient GEMMs (nerfpp_dw.hip; in bf16 all but dZ7, which its job recomputes,
+//                    as the forward leaves H0 to the job that needs it).
 //
 // Precision P: 1 = single-pass bf16 operands / f32 accumulate ("speed" mode);
 //              2 = split-bf16 (x = hi + lo, 3 MFMA passes hi*hi + hi*lo + lo*hi), which holds
-//                  ~1e-5 relative error against the float32 reference ("parity" mode).
+//                  ~1e-5 relative error against the float32 reference ("parity" mode);
+//              3 = (forward kernels only) fp16x2w: weights hi + lo in fp16, activations rounded to fp16 once, 2 passes of
+//                  v_mfma_f32_32x32x16_f16 -- an intermediate precision (nerfpp_common.h: precision ids).
 //
 // Weight-pipe modes (WeightPipe<P, NW, MODE, NBUF, BF>): blocks of BF fragments x P planes (16 KiB in every training kernel)
 // through an LDS ring, four fragments per DMA set-up (glds16xN_saddr), COUNTED vmcnt waits, one raw s_barrier per block.
