@@ -610,7 +610,12 @@ def gen_trajectory_seeds(mode, seeds, part_dir):
     """the float32 reference trained SEED_STEPS steps on the config-1 scene for several seeds of the batch /
     uniform streams -- the reference's own seed spread at convergence, and paired reference runs for the HIP trainer's replay
     (tests/test_gpu_round5.py).  One part file per (mode, seed) so that several processes can share the ~2 h of CPU;
-    `trajectory_seeds merge` collects them into tests/golden/trajectory_seeds.npz."""
+    `trajectory_seeds merge` collects them into tests/golden/trajectory_seeds.npz.
+    The committed fixture: seeds 0-3 (kl) and 0, 2, 3, 4 (mse: seed 1 ran 6x slower than the others -- the torch CPU kernels in
+    denormals -- and was replaced), TRAJ_THREADS = 3 (kl 0, 1; mse 0) and 2 (the rest).  torch's CPU reductions depend on the
+    thread count in their last bits and a 1000-step run amplifies that to ~0.1 dB, so a regeneration with other thread counts
+    yields other -- equally valid -- runs of the reference, not these bits (the 200-step trajectory.npz regenerates bit-identically
+    with the 8 threads its branch sets)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.makedirs(part_dir, exist_ok=True)
     for seed in seeds:
