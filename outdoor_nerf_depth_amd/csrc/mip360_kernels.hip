@@ -225,18 +225,6 @@ __device__ __forceinline__ float safe_sin(float x) {      // math.py:26-38 with 
   return sinf(x);
 }
 
-// bf16 features only need bf16-grade sines: the same safe_sin argument handling, then a two-constant Cody-Waite
-// reduction to [-pi, pi] and the hardware v_sin_f32 (argument in revolutions) instead of libm's sinf (~50 VALU ops;
-// the kernel is VALU-bound on them: 24 sines + 12 exponentials per lane).  Absolute error ~2e-6.
-__device__ __forceinline__ float safe_sin_fast(float x) {
-  const float t = 314.15927f;
-  if (fabsf(x) >= t) x = x - floorf(x / t) * t;
-  const float n = rintf(x * 0.15915494309189535f);
-  float r = fmaf(-n, 6.2831854820251465f, x);
-  r = fmaf(-n, -1.7484556000744883e-7f, r);
-  return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
-}
-
 // MODE 0: float32 rows, 1: bf16 rows (row-major), 2: bf16 in the fragment-major layout of mip360_fm.hip -- a workgroup of
 // 704 threads owns one 32-row block (thread t: row t / 21, basis t % 21), assembles its 32 blocks of 1 KiB in LDS and writes
 // them out whole (enc = the tensor's base + the block offset of its first column, ld = the tensor's columns)
@@ -349,28 +337,69 @@ __global__ __launch_bounds__(MODE == 2 ? 704 : 256) void cast_encode_kernel(
   const int wave_l = threadIdx.x >> 6;
   constexpr int FM_ROW = MIP360_IPE_LD + 4;                       // staged row stride (elements)
   auto fm_at = [&](int r, int col) -> __bf16* { return &rows_lds[0][0][0] + r * FM_ROW + col; };
-#pragma unroll
-  for (int k = 0; k < ND; ++k) {
-    const float sc = (float)(1 << k);
-    const float sm = lm * sc, sv = lv * sc * sc;
-    const float damp = BF16 ? __expf(-0.5f * sv) : expf(-0.5f * sv);
-    const float es = !live ? 0.f : damp * (BF16 ? safe_sin_fast(sm) : safe_sin(sm));
-    const float ec = !live ? 0.f : damp * (BF16 ? safe_sin_fast(sm + 1.5707963267948966f) : safe_sin(sm + 1.5707963267948966f));
-    if (!live) continue;
-    if (FM) {
-      *fm_at(sub, k * MIP360_N_BASIS + j) = (__bf16)es;
-      *fm_at(sub, HALF + k * MIP360_N_BASIS + j) = (__bf16)ec;
-    } else if (staged) {
-      rows_lds[wave_l][sub][k * MIP360_N_BASIS + j] = (__bf16)es;
-      rows_lds[wave_l][sub][HALF + k * MIP360_N_BASIS + j] = (__bf16)ec;
-    } else if (BF16) {
-      __bf16* e = (__bf16*)enc + (size_t)row * ld;
-      e[k * MIP360_N_BASIS + j] = (__bf16)es;
-      e[HALF + k * MIP360_N_BASIS + j] = (__bf16)ec;
+  // one (sin, cos) pair of degree k to its two columns
+  auto emit = [&](int k, float es, float ec) {
+    if (FM || staged || BF16) {
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const bf16x2_t p = __builtin_convertvector((f32x2_t){es, ec}, bf16x2_t);      // one v_cvt_pk_bf16_f32 for the pair
+      if (FM) {
+        *fm_at(sub, k * MIP360_N_BASIS + j) = p[0];
+        *fm_at(sub, HALF + k * MIP360_N_BASIS + j) = p[1];
+      } else if (staged) {
+        rows_lds[wave_l][sub][k * MIP360_N_BASIS + j] = p[0];
+        rows_lds[wave_l][sub][HALF + k * MIP360_N_BASIS + j] = p[1];
+      } else {
+        __bf16* e = (__bf16*)enc + (size_t)row * ld;
+        e[k * MIP360_N_BASIS + j] = p[0];
+        e[HALF + k * MIP360_N_BASIS + j] = p[1];
+      }
     } else {
       float* e = (float*)enc + (size_t)row * ld;
       e[k * MIP360_N_BASIS + j] = es;
       e[HALF + k * MIP360_N_BASIS + j] = ec;
+    }
+  };
+  if (live) {
+    if (BF16) {
+      // bf16 features: direct evaluation at the degrees 0, 2, 5, 8 only (safe_sin's argument handling, Cody-Waite reduction,
+      // hardware sine AND cosine of the one reduced argument, one exponential); the one to three degrees after each follow by
+      // angle doubling -- sin 2x = 2 sin x cos x, cos 2x = 1 - 2 sin^2 x, exp(-v/2)^4 = exp(-4v/2) -- 7 VALU operations instead
+      // of two range reductions + three transcendentals.  A doubling multiplies the absolute error by <= 2.8: 4e-6 at degree 1,
+      // 1e-5 at 4 and 7, 1e-4 at 11 (tools: the numpy twin in tests/test_layout_emulation.py), inside the frequency-scaled
+      // tolerance 2e-6 + 3e-6 . 2^k the float32 path is tested to and far below the bf16 grid.
+      float sn = 0.f, cs = 0.f, damp = 0.f;
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        if (k == 0 || k == 2 || k == 5 || k == 8) {
+          const float sc = (float)(1 << k);
+          float x = lm * sc;
+          const float t = 314.15927f;
+          if (fabsf(x) >= t) x = x - floorf(x / t) * t;
+          const float n = rintf(x * 0.15915494309189535f);
+          float r = fmaf(-n, 6.2831854820251465f, x);
+          r = fmaf(-n, -1.7484556000744883e-7f, r) * 0.15915494309189535f;
+          sn = __builtin_amdgcn_sinf(r);
+          cs = __builtin_amdgcn_cosf(r);
+          damp = __expf(-0.5f * (lv * sc * sc));
+        } else {
+          const float u = sn + sn;
+          const float s2 = u * cs;
+          cs = fmaf(-u, sn, 1.f);
+          sn = s2;
+          const float d2 = damp * damp;
+          damp = d2 * d2;
+        }
+        emit(k, damp * sn, damp * cs);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        const float sc = (float)(1 << k);
+        const float sm = lm * sc, sv = lv * sc * sc;
+        const float damp = expf(-0.5f * sv);
+        emit(k, damp * safe_sin(sm), damp * safe_sin(sm + 1.5707963267948966f));
+      }
     }
   }
   if (FM) {

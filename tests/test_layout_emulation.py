@@ -397,3 +397,37 @@ def test_split_precision_sincos_kernel_accuracy():
     sn, cs = np.where(q & 2, -ss, ss), np.where((q + 1) & 2, -cc, cc)
     assert np.abs(sn - np.sin(x.astype(np.float64))).max() <= 8e-8
     assert np.abs(cs - np.cos(x.astype(np.float64))).max() <= 8e-8
+
+
+def test_mip360_ipe_angle_doubling_error_budget():
+    """numpy twin of the bf16 path of cast_encode_kernel (csrc/mip360_kernels.hip): sin / cos / damping evaluated directly at the
+    degrees 0, 2, 5, 8 and by angle doubling in between.  In float32 with exact transcendentals (the hardware's add ~1e-6) the
+    features stay inside the frequency-scaled tolerance the float32 path is tested to (tests/test_gpu_mip360.py): 2e-6 + 3e-6 2^k."""
+    f = np.float32
+    rs = np.random.RandomState(0)
+    lm = (rs.rand(100000) * 4 - 2).astype(f)                       # |contracted mean . basis| <= 2
+    lv = (10.0 ** (rs.rand(100000) * 8 - 8)).astype(f)
+    sn = cs = dp = None
+    for k in range(12):
+        sc = f(2 ** k)
+        if k in (0, 2, 5, 8):
+            x = lm * sc
+            t = f(314.15927)
+            x = np.where(np.abs(x) >= t, x - np.floor(x / t) * t, x).astype(f)
+            n = np.rint(x * f(0.15915494309189535)).astype(f)
+            r = (x.astype(np.float64) - n.astype(np.float64) * 6.2831854820251465).astype(f)
+            r = ((r.astype(np.float64) + n.astype(np.float64) * 1.7484556000744883e-7).astype(f) * f(0.15915494309189535)).astype(f)
+            sn = np.sin(2 * np.pi * r.astype(np.float64)).astype(f)
+            cs = np.cos(2 * np.pi * r.astype(np.float64)).astype(f)
+            dp = np.exp(-0.5 * (lv * sc * sc).astype(np.float64)).astype(f)
+        else:
+            u = (sn + sn).astype(f)
+            s2 = (u * cs).astype(f)
+            cs = (1.0 - u.astype(np.float64) * sn.astype(np.float64)).astype(f)
+            sn = s2
+            d2 = (dp * dp).astype(f)
+            dp = (d2 * d2).astype(f)
+        damp = np.exp(-0.5 * lv.astype(np.float64) * 4.0 ** k)
+        arg = lm.astype(np.float64) * 2.0 ** k
+        err = max(np.abs(dp * sn - damp * np.sin(arg)).max(), np.abs(dp * cs - damp * np.cos(arg)).max())
+        assert err < 0.5 * (2e-6 + 3e-6 * 2 ** k), (k, err)
