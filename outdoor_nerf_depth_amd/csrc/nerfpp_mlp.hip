@@ -50,6 +50,7 @@ constexpr int WAVES_P1 = 8;            // waves per workgroup of the bf16 kernel
 constexpr int LOADER_SLEEP = 0;        // (probes: idle cycles / 64 added to the loader wave per weight block)
 constexpr int LDS_REUSE = 1;           // (probes: MFMAs per weight-fragment read)
 constexpr int SKIP_H = 0;              // (probes: bit l = the training forward does not write H_l out)
+constexpr int SKEW_INFER = 0;          // weight blocks by which waves NW/2.. lag waves 0..NW/2-1 (inference forward, bf16)
 __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   const u32x4_ vv = {v.x, v.y, v.z, v.w};
@@ -114,24 +115,30 @@ __device__ __forceinline__ void glds16xN_saddr(const char* sbase, uint32_t voff,
 template <int P, bool TRAIN>
 constexpr int blk_frags_of() { return (P >= 2 && TRAIN) ? 8 : BLK_FRAGS; }
 
-template <int P, int NW, int MODE, int NBUF, int BF = BLK_FRAGS>
+// SKEW > 0: the waves NW/2.. ("lagging") consume block t - SKEW in the step in which the waves 0..NW/2-1 consume block t (one wave
+// of each half per SIMD): a stage's epilogue -- conversion VALU with nothing for the matrix pipe -- of one half then coincides
+// with MFMA blocks of the other half instead of with its epilogue.  Every wave takes part in every step (barrier, DMA issue):
+// the lagging waves run SKEW empty steps first (lead_in), the others SKEW empty steps last (lead_out); a slot is re-filled
+// SKEW steps later than without skew, i.e. the ring runs NBUF - 1 - SKEW blocks ahead.
+template <int P, int NW, int MODE, int NBUF, int BF = BLK_FRAGS, int SKEW = 0>
 struct WeightPipe {
   static constexpr int BLKF = BF;
   static constexpr int BLK_BYTES = BF * P * FRAG_BYTES;
   // DMA wave-instructions per block of the waves that wait for it (roles: the loader issues them all)
   static constexpr int PER_BLK = MODE == PIPE_ROLES ? BF * P : BF * P / NW;
-  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_BLK < 63, "ring depth");
+  static constexpr int AHEAD = NBUF - 1 - SKEW;                // blocks in flight ahead of the step's block
+  static_assert(AHEAD >= 1 && AHEAD <= 3 && (AHEAD - 1) * PER_BLK < 63 && SKEW >= 0, "ring depth");
   const char* g;
   uint32_t stamp_off = 0;                                      // (probes: LDS offset of the cycle stamps)
-  int nblk, cur, wave, lane;
+  int nblk, cur, step, wave, lane;                             // cur: blocks this wave has consumed, step: barriers passed
   int slot_cur, slot_issue, next_issue;                        // ring positions (NBUF need not be a power of 2)
   uint32_t lds_base;
   __device__ __forceinline__ void init(const void* stream, int nblk_, int wave_, int lane_) {
-    g = (const char*)stream; nblk = nblk_; cur = 0; wave = wave_; lane = lane_;
+    g = (const char*)stream; nblk = nblk_; cur = 0; step = 0; wave = wave_; lane = lane_;
     slot_cur = 0; slot_issue = 0; next_issue = 0;
     lds_base = lds_base_addr();
 #pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b) issue();
+    for (int b = 0; b < AHEAD; ++b) issue();
   }
   __device__ __forceinline__ void issue() {                    // next block of the stream -> next ring slot
     const int blk = next_issue, slot = slot_issue;
@@ -159,17 +166,17 @@ struct WeightPipe {
       }
     }
   }
-  // wait until block `cur` has landed, leaving up to NBUF-2 younger blocks in flight.  Valid because
+  // wait until block `step` has landed, leaving up to AHEAD-1 younger blocks in flight.  Valid because
   // every VMEM op the waiting wave has outstanding is a load (they retire in order); extra loads in
   // between (sign words, rays) only make the count conservative.
   __device__ __forceinline__ void wait_counted() {
-    const int younger = nblk - 1 - cur < NBUF - 2 ? nblk - 1 - cur : NBUF - 2;
-    if (NBUF >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_BLK) : "memory");
-    else if (NBUF >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_BLK) : "memory");
+    const int younger = nblk - 1 - step < AHEAD - 1 ? nblk - 1 - step : AHEAD - 1;
+    if (AHEAD >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_BLK) : "memory");
+    else if (AHEAD >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_BLK) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  // make block `cur` readable, start fetching into the slot freed by the barrier, return LDS address
-  __device__ __forceinline__ const char* acquire() {
+  // one step: block `step` readable by everybody, start fetching into the slot the barrier freed
+  __device__ __forceinline__ void sync_step() {
     probe::stamp(0, cur, wave, lane, stamp_off);                 // arrival at the block boundary
     if constexpr (MODE == PIPE_RING) {
       wait_counted();
@@ -182,6 +189,18 @@ struct WeightPipe {
     }
     probe::stamp(1, cur, wave, lane, stamp_off);                 // released by the barrier
     issue();
+    ++step;
+  }
+  __device__ __forceinline__ bool lagging() const { return SKEW > 0 && wave >= NW / 2; }
+  __device__ __forceinline__ void lead_in() {
+    if constexpr (SKEW > 0) if (lagging()) for (int s_ = 0; s_ < SKEW; ++s_) sync_step();
+  }
+  __device__ __forceinline__ void lead_out() {
+    if constexpr (SKEW > 0) if (!lagging()) for (int s_ = 0; s_ < SKEW; ++s_) sync_step();
+  }
+  // make this wave's next block readable, return its LDS address
+  __device__ __forceinline__ const char* acquire() {
+    sync_step();
     const char* l = smem + slot_cur * BLK_BYTES + lane * 16;
     slot_cur = slot_cur + 1 == NBUF ? 0 : slot_cur + 1;
     ++cur;
@@ -686,7 +705,8 @@ struct FwdLds {
   static constexpr bool ROLES = MODE == PIPE_ROLES;
   static constexpr int BF = blk_frags_of<P, TRAIN>();
   // ring depth: as deep as the 160 KiB of LDS allow
-  static constexpr int NBUF = MODE == PIPE_RING ? (P == 1 ? 4 : 3) : 4;
+  static constexpr int SKEW = (MODE == PIPE_RING && P == 1 && NW >= 2) ? probe::SKEW_INFER : 0;
+  static constexpr int NBUF = MODE == PIPE_RING ? (P == 1 ? 4 + SKEW : 3) : 4;
   static constexpr int W = NBUF * BF * w_planes(P) * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STASH = REGION + (ROLES ? region_bytes(P) : 0);
@@ -730,7 +750,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
   const size_t nblk32 = a.rows_padded / 32;
   uint4* mask_out = a.masks + (wrow0 / 32) * 64 + lane;                     // + stage * nblk32 * 64
 
-  WeightPipe<w_planes(P), NW, LD::MODE, LD::NBUF, LD::BF> pipe;
+  WeightPipe<w_planes(P), NW, LD::MODE, LD::NBUF, LD::BF, LD::SKEW> pipe;
   pipe.stamp_off = LD::TOTAL;
   pipe.init(a.w_stream, fwd_frags(NET) / LD::BF, wave, lane);
   // The loader's tile is written out by the helper waves 1..H.  CPB chunks of a storer's own tile go out per weight block
@@ -742,6 +762,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
     *(float4*)(smem + LD::BIAS + i * 16) = ((const float4*)a.bias)[i];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  pipe.lead_in();
   auto bias_init8 = [&](f32x16 (&acc_)[8], int off) { init_bias_lds<8>(acc_, LD::BIAS + off * 4, hi); };
   auto bias_init4 = [&](f32x16 (&acc_)[4], int off) { init_bias_lds<4>(acc_, LD::BIAS + off * 4, hi); };
   auto bias_init1 = [&](f32x16 (&acc_)[1], int off) { init_bias_lds<1>(acc_, LD::BIAS + off * 4, hi); };
@@ -944,6 +965,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
     bias_init1(acc1, fs_bias_off(FS_RGB1));
     stage_gemm<1, 16, P, 8>(pipe, acc1, in, HOOK(flush(blk, IC(8), a.ws.t[T_G], 128, 8)));
   }
+  pipe.lead_out();
   if (valid && hi == 0) {
     float4 o;
     o.x = 1.f / (1.f + expf(-acc1[0][0]));

@@ -66,6 +66,10 @@ constexpr int LDS_PREFETCH = NERFPP_LDS_PREFETCH;
 constexpr int HOOK_ORDER = NERFPP_HOOK_ORDER;
 constexpr int WAVES_P1 = NERFPP_WAVES_P1;
 constexpr int LOADER_SLEEP = NERFPP_LOADER_SLEEP;
+#ifndef NERFPP_SKEW_INFER
+#define NERFPP_SKEW_INFER 0
+#endif
+constexpr int SKEW_INFER = NERFPP_SKEW_INFER;
 constexpr int SKIP_H = NERFPP_SKIP_H;             // bit l: the bf16 training forward leaves H_l unsaved (what would one-layer recompute in dw_kernel buy?)
 constexpr int LDS_REUSE = NERFPP_LDS_REUSE;       // 2: one weight-fragment read per two MFMAs (what 64-row waves would need); with NERFPP_LDS_PREFETCH=0
 
