@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MIP360_ABI_VERSION 5
+#define MIP360_ABI_VERSION 6
 #define MIP360_OK 0
 #define MIP360_ERR_ARG 1
 #define MIP360_ERR_HIP 2
@@ -174,6 +174,18 @@ int mip360_rowdot_fm(void* stream, int m, int k, const void* a_fm, int lda, cons
                      float act_param, float* out, int ldo);
 int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,
                               int ksplit, float* slabs, float* grad_kernel, float scale, float* grad_bias);
+/* The PropMLP forward (models.py:436-606 with configs/360.gin:12-13: four 256-wide ReLU layers on the 512 padded IPE columns,
+ * density head) as ONE launch: = four mip360_linear_fm (act 1) + mip360_rowdot_fm (act 2) with the activations in registers
+ * between the layers (csrc/mip360_prop.hip).  x_fm [rows, ldx] fm, columns [x_col0, x_col0 + 512); w_fm[l] fm [256, ldw[l]]
+ * (the fwd_fm copies of mip360_pack_weight_fm), bias[l] [256]; rows a multiple of 256.  h_fm / masks (4 pointers each, both
+ * or neither): H_l [rows, 256] fm and the ReLU mask of layer l in mip360_linear_fm's format (mip360_fm_mask_bytes(rows, 256)
+ * each) -- what the backward pass reads; NULL: inference, nothing but the density leaves the chip.  density (may be NULL
+ * when training outputs are requested) [rows] = softplus(H_3 . wd + bd[0] + act_param), bit-identical to mip360_rowdot_fm
+ * on the H_3 this call writes.  Layer outputs agree with mip360_linear_fm up to the summation order (float bias first here,
+ * bf16 hi + lo bias last there). */
+int mip360_prop_mlp_fm(void* stream, int rows, const void* x_fm, int ldx, int x_col0, const void* const* w_fm, const int* ldw,
+                       const float* const* bias, void* const* h_fm, void* const* masks, const void* wd_bf16, const float* bd,
+                       float act_param, float* density);
 /* c_fm[m][n] = bf16(z[m] * w[n]) where bit (m, n) of `mask` is set (z bf16 [m], w bf16 [n]): mip360_linear_fm act 2 for a
  * one-column operand -- the PropMLP's dZ of the last trunk layer (its only head is the density column).
  * mip360_grad_weight_col_fm with lddz == 1 reads z from such a plain vector. */

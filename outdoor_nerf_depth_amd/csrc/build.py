@@ -31,6 +31,7 @@ SOURCES_MIP360 = {
     'mip360_kernels.hip': ['-ffp-contract=off'],    # arithmetic order of the oracle
     'mip360_gemm.hip': [],
     'mip360_fm.hip': [],
+    'mip360_prop.hip': [],                          # the PropMLP forward as one launch
     'mip360_train.hip': [],
     'mip360_api.hip': [],
 }

@@ -55,6 +55,9 @@ void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, flo
 void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd,
                                void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0);
 int mip360_launch_outer_masked_fm(hipStream_t st, int M, int N, const void* z, const void* w, const void* mask, void* out, int ldc);
+int mip360_launch_prop_mlp_fm(hipStream_t st, int rows, const void* x_fm, int ldx, int x_col0, const void* const* w_fm, const int* ldw,
+                              const float* const* bias, void* const* h_fm, void* const* masks, const void* wd, const float* bd,
+                              float act_param, float* density);
 void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width);
 
 namespace {
@@ -265,6 +268,17 @@ int mip360_rowdot_fm(void* stream, int m, int k, const void* a_fm, int lda, cons
   REQUIRE(mip360_launch_rowdot_fm((hipStream_t)stream, m, k, a_fm, lda, w_bf16, bias, act, act_param, out, ldo) == 0,
           "m a multiple of 32, k / lda multiples of 16, act in 0..2");
   return check_launch("rowdot_fm");
+}
+
+int mip360_prop_mlp_fm(void* stream, int rows, const void* x_fm, int ldx, int x_col0, const void* const* w_fm, const int* ldw,
+                       const float* const* bias, void* const* h_fm, void* const* masks, const void* wd_bf16, const float* bd,
+                       float act_param, float* density) {
+  const int rc = mip360_launch_prop_mlp_fm((hipStream_t)stream, rows, x_fm, ldx, x_col0, w_fm, ldw, bias, h_fm, masks, wd_bf16, bd,
+                                           act_param, density);
+  REQUIRE(rc != 1, "rows a multiple of 256, ldx / x_col0 / ldw multiples of 16, 512 operand columns, h_fm and masks together, "
+                   "density or training outputs");
+  REQUIRE(rc == 0, "hipFuncSetAttribute");
+  return check_launch("prop_mlp_fm");
 }
 
 int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,

@@ -19,7 +19,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MIP360_HIP_LIB') or os.path.join(_HERE, 'libmip360_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
 _fp = C.c_void_p
 _fpp = C.POINTER(C.c_void_p)
@@ -53,6 +53,8 @@ SYMBOLS = {
     'mip360_rowdot_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_float, _fp, C.c_int]),
     'mip360_grad_weight_col_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp]),
     'mip360_outer_masked_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int]),
+    'mip360_prop_mlp_fm': (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fpp, C.POINTER(C.c_int), _fpp, _fpp, _fpp, _fp, _fp,
+                                     C.c_float, _fp]),
     'mip360_pack_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
@@ -253,6 +255,27 @@ def linear_fm(a, w, bias, act, m, n, k, out, mask, lda=None, ldw=None, ldc=None,
                                   _fm_ptr(out, out_col0), ldc or n, _p(mask)), 'mip360_linear_fm')
 
 
+# MIP360_NO_FUSED_PROP=1 keeps the PropMLP forward on four mip360_linear_fm + mip360_rowdot_fm launches (A/B runs)
+USE_FUSED_PROP = os.environ.get('MIP360_NO_FUSED_PROP') is None
+
+
+def fused_prop_ok(cfg, rows):
+    """the shapes csrc/mip360_prop.hip takes: the 4 x 256 density-only MLP of configs/360.gin on whole 256-row tiles"""
+    return (USE_FM and USE_FUSED_PROP and cfg['disable_rgb'] and cfg['net_width'] == 256 and cfg['net_depth'] == 4
+            and rows % 256 == 0)
+
+
+def prop_mlp_fm(enc_buf, x_col0, ldx, rows, w_fm, ldw, bias, wd, bd, density, h=None, masks=None):
+    """The PropMLP forward as one launch (include/mip360_hip.h: mip360_prop_mlp_fm).  h / masks: 4 fm buffers / mask buffers
+    (training) or None."""
+    arr = lambda ts: (C.c_void_p * 4)(*[_p(t) for t in ts])
+    keep = [arr(w_fm), (C.c_int * 4)(*[int(v) for v in ldw]), arr(bias)]
+    hp = arr([h_[0] if isinstance(h_, tuple) else h_ for h_ in h]) if h is not None else None
+    mp = arr(masks) if masks is not None else None
+    _check(lib().mip360_prop_mlp_fm(_stream(), int(rows), _fm_ptr(enc_buf, 0), int(ldx), int(x_col0), keep[0], keep[1], keep[2], hp, mp,
+                                    _p(wd), _p(bd), DENSITY_BIAS, _p(density)), 'mip360_prop_mlp_fm')
+
+
 def render_level(density, rgb_samples, tdist, directions, opaque_background=True, bg_rgb=1.0):
     density, tdist = _f32(density), _f32(tdist)
     n, S = density.shape
@@ -425,6 +448,11 @@ def mlp_forward_fm(pk, enc_buf, rows, viewdirs=None, n_rays=None, n_samples=None
     W, depth = cfg['net_width'], cfg['net_depth']
     dev = enc_buf.device
     ld_enc = W + IPE_LD
+    if fused_prop_ok(cfg, rows):
+        density = torch.empty(rows, 1, device=dev)
+        prop_mlp_fm(enc_buf, W, ld_enc, rows, [pk.w_fm[i] for i in range(depth)], [pk.w[i].shape[1] for i in range(depth)],
+                    [pk.b[i] for i in range(depth)], pk.w[depth], pk.b[depth], density)
+        return density[:, 0], None
     nbytes = lib().mip360_fm_mask_bytes(int(rows), int(W))
     if pk.mask_scratch is None or pk.mask_scratch.numel() < nbytes:
         pk.mask_scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -730,6 +758,19 @@ def mlp_forward_train_fm(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
     dev = enc_buf.device
     ld_enc = W + IPE_LD
     saved = dict(fm=True, enc_buf=enc_buf, H=[], inputs=[], masks=[])
+    if fused_prop_ok(tm.cfg, rows):
+        # one launch for the four layers and the head; it leaves exactly what the loop below would (H_l, masks, density)
+        hs = [fm_buffer(rows, W, dev) for _ in range(D)]
+        masks = [fm_mask_buffer(rows, W, dev) for _ in range(D)]
+        density = torch.empty(rows, 1, device=dev)
+        prop_mlp_fm(enc_buf, W, ld_enc, rows, [tm.w_fm[i] for i in range(D)], [tm.in_pad[i] for i in range(D)],
+                    [tm.b[i] for i in range(D)], tm.w[D], tm.b[D], density, h=hs, masks=masks)
+        saved['inputs'] = [(enc_buf, W, ld_enc, IPE_LD)] + [(hs[i], 0, W, W) for i in range(D - 1)]
+        saved['H'] = [(hs[i], W) for i in range(D)]
+        saved['masks'] = masks
+        saved['trunk'] = (hs[D - 1], 0, W, W)
+        saved['density'] = density
+        return density[:, 0], None, saved
     x, x_col0, x_ld, x_k = enc_buf, W, ld_enc, IPE_LD
     for i in range(D):
         skip_out = (i % SKIP_LAYER == 0 and i > 0)

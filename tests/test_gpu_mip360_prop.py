@@ -1,0 +1,119 @@
+"""mip360_prop_mlp_fm (csrc/mip360_prop.hip): the PropMLP forward as one launch, through the C ABI.
+
+* every layer output against a float64 evaluation of the same bf16 operands chained through the kernel's own (bf16) outputs, and
+  against the launches it replaces (mip360_linear_fm act 1 x 4): equal up to the summation order, i.e. a bf16 ulp on a small
+  fraction of the elements;
+* the ReLU masks in mip360_linear_fm's format: the masked dX layer (act 2) driven by the fused kernel's mask zeroes exactly the
+  elements whose saved activation is zero;
+* density == mip360_rowdot_fm of the saved last layer, bit for bit; inference mode (nothing saved) == training mode;
+* the training step of Mip360Trainer with and without the fused launch: same losses / parameters to summation-order grade.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_mip360_fm import M, N, T, bf, dev, round_bf16   # noqa: F401  (fixtures / helpers)
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(M, rows, seed, ld=768, col0=256):
+    rs = np.random.RandomState(seed)
+    x = round_bf16((rs.randn(rows, 512) * 0.7).astype(np.float32))
+    x[:, 504:] = 0
+    ws = [round_bf16((rs.randn(256, 512 if l == 0 else 256) * np.sqrt(2.0 / (512 if l == 0 else 256))).astype(np.float32)) for l in range(4)]
+    bs = [(rs.randn(256) * 0.1).astype(np.float32) for _ in range(4)]
+    wd = round_bf16((rs.randn(1, 256) / 16).astype(np.float32))
+    bd = np.array([0.3], np.float32)
+    enc = torch.full((rows * ld,), 5.0, dtype=torch.bfloat16, device=dev())
+    M.to_fm(bf(x), out=enc, ld=ld, col0=col0)
+    return dict(x=x, ws=ws, bs=bs, wd=wd, bd=bd, enc=enc, ld=ld, col0=col0,
+                w_fm=[M.to_fm(bf(w)) for w in ws], b_t=[T(b) for b in bs], wd_t=bf(wd), bd_t=T(bd))
+
+
+def _fused(M, P, rows, train=True):
+    hs = [M.fm_buffer(rows, 256, dev()) for _ in range(4)] if train else None
+    masks = [M.fm_mask_buffer(rows, 256, dev()) for _ in range(4)] if train else None
+    density = torch.empty(rows, 1, device=dev())
+    M.prop_mlp_fm(P['enc'], P['col0'], P['ld'], rows, P['w_fm'], [512, 256, 256, 256], P['b_t'], P['wd_t'], P['bd_t'], density,
+                  h=hs, masks=masks)
+    return hs, masks, density
+
+
+@pytest.mark.parametrize('rows', [256, 66 * 256])
+def test_prop_mlp_fm_layers_masks_and_density(M, rows):
+    P = _problem(M, rows, rows)
+    hs, masks, density = _fused(M, P, rows)
+    assert (N(M.from_fm(P['enc'], rows, 256, ld=P['ld'], col0=0)) == 5.0).all()      # nothing outside the operand window is touched
+    a = P['x'].astype(np.float64)
+    a_t, a_col0, a_ld, a_k = P['enc'], P['col0'], P['ld'], 512
+    for l in range(4):
+        got = N(M.from_fm(hs[l], rows, 256))
+        ref = np.maximum(a @ P['ws'][l].astype(np.float64).T + P['bs'][l], 0)
+        np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=2e-3)
+        assert (got >= 0).all() and not np.signbit(got).any()
+        # the launch it replaces, on the same operand
+        want_fm, want_mask = M.fm_buffer(rows, 256, dev()), M.fm_mask_buffer(rows, 256, dev())
+        M.linear_fm(a_t, P['w_fm'][l], P['b_t'][l], 1, rows, 256, a_k, want_fm, want_mask, lda=a_ld, a_col0=a_col0)
+        want = N(M.from_fm(want_fm, rows, 256))
+        diff = got != want
+        assert diff.mean() < 2e-3, diff.mean()                              # summation order: a bf16 ulp here and there
+        np.testing.assert_allclose(got, want, rtol=2 ** -7, atol=1e-6)
+        # the mask drives linear_fm's masked dX exactly like the saved activation
+        eye = round_bf16(np.eye(256, dtype=np.float32))
+        ones_fm = M.to_fm(bf(np.ones((rows, 256), np.float32)))
+        out = M.fm_buffer(rows, 256, dev())
+        M.linear_fm(ones_fm, M.to_fm(bf(eye)), None, 2, rows, 256, 256, out, masks[l])
+        np.testing.assert_array_equal(N(M.from_fm(out, rows, 256)) != 0, got != 0)
+        a = got.astype(np.float64)
+        a_t, a_col0, a_ld, a_k = hs[l], 0, 256, 256
+    # density: the row-dot launch on the saved last layer, bit for bit; and the float64 value
+    want_d = torch.empty(rows, 1, device=dev())
+    M._check(M.lib().mip360_rowdot_fm(M._stream(), rows, 256, M._fm_ptr(hs[3], 0), 256, M._p(P['wd_t']), M._p(P['bd_t']), 2, M.DENSITY_BIAS,
+                                      M._p(want_d), 1), 'rowdot_fm')
+    np.testing.assert_array_equal(N(density), N(want_d))
+    raw = a @ P['wd'].astype(np.float64).T + P['bd'] + M.DENSITY_BIAS
+    np.testing.assert_allclose(N(density), np.logaddexp(raw, 0), rtol=1e-5, atol=1e-6)
+    # inference mode: nothing saved, the same density
+    _, _, d_inf = _fused(M, P, rows, train=False)
+    np.testing.assert_array_equal(N(d_inf), N(density))
+
+
+def test_prop_mlp_fm_rejects_shapes_it_does_not_take(M):
+    P = _problem(M, 256, 3)
+    density = torch.empty(256, 1, device=dev())
+    with pytest.raises(M.Mip360Error):                                   # rows not a multiple of 256
+        M.prop_mlp_fm(P['enc'], P['col0'], P['ld'], 224, P['w_fm'], [512, 256, 256, 256], P['b_t'], P['wd_t'], P['bd_t'], density)
+    with pytest.raises(M.Mip360Error):                                   # operand window beyond the tensor
+        M.prop_mlp_fm(P['enc'], 512, P['ld'], 256, P['w_fm'], [512, 256, 256, 256], P['b_t'], P['wd_t'], P['bd_t'], density)
+    with pytest.raises(M.Mip360Error):                                   # first layer narrower than the 512 operand columns
+        M.prop_mlp_fm(P['enc'], P['col0'], P['ld'], 256, P['w_fm'], [256, 256, 256, 256], P['b_t'], P['wd_t'], P['bd_t'], density)
+
+
+def test_trainer_step_with_and_without_the_fused_prop_mlp(M, monkeypatch):
+    """Three optimisation steps of Mip360Trainer on 64 rays (4096 / 2048 rows per level): the fused PropMLP forward against the
+    five launches it replaces.  Same sample positions would need bit-equal densities; the layers differ in summation order, so
+    the comparison is loss-level (1e-3) and update-level (Adam steps of size lr: a fraction of the components may flip sign)."""
+    from oracle import mip360_oracle as O
+    from tests.test_gpu_mip360 import _rays
+    rs = np.random.RandomState(5)
+    n = 64
+    rays = {k: T(v) for k, v in _rays(rs, n).items()}
+    gt = T(rs.rand(n, 3).astype(np.float32))
+    sup = T((0.5 + rs.rand(n)).astype(np.float32))
+    jit = [[T(np.random.RandomState(10 * s_ + l).rand(n).astype(np.float32)) for l in range(3)] for s_ in range(3)]
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(M, 'USE_FUSED_PROP', fused)
+        prs = np.random.RandomState(7)
+        tr = M.Mip360Trainer(O.init_mlp_params(O.PROP_CFG, prs), O.init_mlp_params(O.NERF_CFG, prs), dev(), max_steps=1000)
+        hist = [N(tr.train_step(rays, gt, sup, jitter01=jit[s_])) for s_ in range(3)]
+        tr.flush()
+        out[fused] = (np.stack(hist), N(tr.prop.flat), N(tr.nerf.flat))
+    assert np.isfinite(out[True][0]).all()
+    np.testing.assert_allclose(out[True][0][0], out[False][0][0], rtol=2e-3, atol=1e-6)       # first step: same weights
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-2, atol=1e-5)
+    lr = float(M.learning_rate(3))
+    for a_, b_ in ((out[True][1], out[False][1]), (out[True][2], out[False][2])):
+        assert np.abs(a_ - b_).max() <= 3 * 2.5 * lr                     # three Adam steps, each bounded by ~lr
+        assert np.mean(np.abs(a_ - b_) > 0.5 * lr) < 0.1
