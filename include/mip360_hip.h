@@ -186,6 +186,13 @@ int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, i
 int mip360_prop_mlp_fm(void* stream, int rows, const void* x_fm, int ldx, int x_col0, const void* const* w_fm, const int* ldw,
                        const float* const* bias, void* const* h_fm, void* const* masks, const void* wd_bf16, const float* bd,
                        float act_param, float* density);
+/* The dX chain of the same MLP as ONE launch: dZ_3 = mask_3 . bf16(z (x) wd) (= mip360_outer_masked_fm), dZ_{l-1} = mask_{l-1} .
+ * bf16(dZ_l W_l) (= mip360_linear_fm act 2) for l = 3, 2, 1, dZ_l in registers between the layers; all four dZ_l [rows, 256] fm
+ * are written for mip360_grad_weight_fm.  z bf16 [rows] (d loss / d raw density), wd bf16 [256], masks[l] as written by
+ * mip360_prop_mlp_fm / mip360_linear_fm act 1, wb_fm[l] (l = 1..3; entry 0 ignored) the bwd_fm copies of
+ * mip360_pack_weight_fm [256, ldwb[l]].  Bit-identical to the four launches it replaces. */
+int mip360_prop_mlp_bwd_fm(void* stream, int rows, const void* z_bf16, const void* wd_bf16, const void* const* masks,
+                           const void* const* wb_fm, const int* ldwb, void* const* dz_fm);
 /* c_fm[m][n] = bf16(z[m] * w[n]) where bit (m, n) of `mask` is set (z bf16 [m], w bf16 [n]): mip360_linear_fm act 2 for a
  * one-column operand -- the PropMLP's dZ of the last trunk layer (its only head is the density column).
  * mip360_grad_weight_col_fm with lddz == 1 reads z from such a plain vector. */

@@ -58,6 +58,8 @@ int mip360_launch_outer_masked_fm(hipStream_t st, int M, int N, const void* z, c
 int mip360_launch_prop_mlp_fm(hipStream_t st, int rows, const void* x_fm, int ldx, int x_col0, const void* const* w_fm, const int* ldw,
                               const float* const* bias, void* const* h_fm, void* const* masks, const void* wd, const float* bd,
                               float act_param, float* density);
+int mip360_launch_prop_mlp_bwd_fm(hipStream_t st, int rows, const void* z, const void* wd, const void* const* masks,
+                                  const void* const* wb_fm, const int* ldwb, void* const* dz_fm);
 void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width);
 
 namespace {
@@ -279,6 +281,14 @@ int mip360_prop_mlp_fm(void* stream, int rows, const void* x_fm, int ldx, int x_
                    "density or training outputs");
   REQUIRE(rc == 0, "hipFuncSetAttribute");
   return check_launch("prop_mlp_fm");
+}
+
+int mip360_prop_mlp_bwd_fm(void* stream, int rows, const void* z_bf16, const void* wd_bf16, const void* const* masks,
+                           const void* const* wb_fm, const int* ldwb, void* const* dz_fm) {
+  const int rc = mip360_launch_prop_mlp_bwd_fm((hipStream_t)stream, rows, z_bf16, wd_bf16, masks, wb_fm, ldwb, dz_fm);
+  REQUIRE(rc != 1, "rows a multiple of 256, four masks / outputs, wb_fm[1..3] with ldwb multiples of 16 >= 256");
+  REQUIRE(rc == 0, "hipFuncSetAttribute");
+  return check_launch("prop_mlp_bwd_fm");
 }
 
 int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,

@@ -262,6 +262,142 @@ __global__ __launch_bounds__(NW * 64, 1) void prop_mlp_fwd_kernel(const Args a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The dX chain of the same MLP (jax.grad through the four ReLU layers) as one launch:
+//   dZ_3 = mask_3 . bf16(z (x) w_density)          (mip360_outer_masked_fm)
+//   dZ_{l-1} = mask_{l-1} . bf16(dZ_l W_l)          (mip360_linear_fm act 2), l = 3, 2, 1
+// with dZ_l in registers between the layers; every dZ_l is written (fm) for the weight-gradient GEMMs, two fragments per weight
+// block of the layer that consumes it.  Same MFMA sequence per output element as linear_fm (k ascending, no bias): bit-identical.
+struct BwdArgs {
+  int rows;                                             // multiple of 256
+  const uint16_t* z;                                    // d loss / d raw density, bf16 [rows]
+  const uint16_t* wd;                                   // density kernel, bf16 [256]
+  const uint32_t* mask[DEPTH];                          // mask words of H_l (written by the forward)
+  const char* wb[DEPTH]; int wb_bpr[DEPTH];             // l = 1 .. 3: fm [256 inputs, ld] backward operand of layer l
+  char* dz[DEPTH];                                      // fm [rows, 256]
+};
+
+__global__ __launch_bounds__(NW * 64, 1) void prop_mlp_bwd_kernel(const BwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = lane & 31, hi = lane >> 5;
+  const uint32_t u16 = unit_of(row, hi) * 16u;
+  const size_t tile = blockIdx.x, rb = tile * NW + wave;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  constexpr int LBLK = WIDTH / 16 / KPB, NBLK = (DEPTH - 1) * LBLK;
+
+  // side data first (older than every counted operation): this wave's mask words of the four layers, its rows' z
+  uint32_t mw[DEPTH][4];
+#pragma unroll
+  for (int l = 0; l < DEPTH; ++l) {
+    const uint32_t* m = a.mask[l] + (((size_t)tile * 8 + (wave >> 2) * 4) * 64 + lane) * 4 + (wave & 3);
+#pragma unroll
+    for (int wn = 0; wn < 4; ++wn) mw[l][wn] = m[(size_t)wn * 64 * 4];
+  }
+  const float zv = __builtin_bit_cast(float, (uint32_t)a.z[rb * 32 + row] << 16);
+  if (threadIdx.x < WIDTH / 8) *(uint4*)(smem + LDS_HEAD + threadIdx.x * 16) = ((const uint4*)a.wd)[threadIdx.x];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int vm_issued = 0, vm_mark[NBLK];
+  int issue_t = 0, slot_issue = 0;
+  auto issue = [&]() {
+    const int t = issue_t++, slot = slot_issue;
+    slot_issue = slot_issue + 1 == NBUF ? 0 : slot_issue + 1;
+    if (t >= NBLK) return;
+    const int l = DEPTH - 1 - t / LBLK, lb = t % LBLK;                          // layers 3, 2, 1
+    const int kc = lb * KPB + (wave >> 2), ob = 2 * (wave & 3);
+    const char* src = a.wb[l] + ((size_t)ob * a.wb_bpr[l] + kc) * 1024;
+    const uint32_t dst = lds0 + slot * BLK_BYTES + ((wave >> 2) * NOB + ob) * 1024;
+    glds_frag(src, (uint32_t)lane * 16u, dst);
+    glds_frag(src + (size_t)a.wb_bpr[l] * 1024, (uint32_t)lane * 16u, dst + 1024u);
+    vm_issued += 2;
+    vm_mark[t] = vm_issued;
+  };
+  int step = 0, slot_cur = 0;
+  auto acquire = [&]() -> int {
+    wait_vmcnt(vm_issued - vm_mark[step]);
+    __builtin_amdgcn_s_barrier();
+    issue();
+    const int s_ = slot_cur;
+    slot_cur = slot_cur + 1 == NBUF ? 0 : slot_cur + 1;
+    ++step;
+    return s_;
+  };
+#pragma unroll
+  for (int b = 0; b < AHEAD; ++b) issue();
+
+  // dZ_3: the masked outer product, fragment by fragment
+  u32x4 dzf[WIDTH / 16];
+  auto mask_of = [&](int l, int ob, int p) { return (mw[l][ob >> 1] >> (8 * (ob & 1) + p)) & 0x00010001u; };
+  {
+    const char* wl = smem + LDS_HEAD + 8 * hi;
+#pragma unroll
+    for (int c = 0; c < WIDTH / 16; ++c) {
+      const uint2 w0 = *(const uint2*)(wl + c * 32), w1 = *(const uint2*)(wl + c * 32 + 16);
+      const uint32_t ws[4] = {w0.x, w0.y, w1.x, w1.y};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 f = {zv * __builtin_bit_cast(float, ws[q] << 16), zv * __builtin_bit_cast(float, ws[q] & 0xFFFF0000u)};
+        uint32_t v = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+        v &= mask_of(DEPTH - 1, c >> 1, 4 * (c & 1) + q) * 0xFFFFu;
+        dzf[c][q] = v;
+      }
+    }
+  }
+  auto save_frag = [&](int l, int c) {
+    __builtin_nontemporal_store(dzf[c], (u32x4*)(a.dz[l] + (rb * (WIDTH / 16) + c) * 1024 + u16));
+    vm_issued += 1;
+  };
+  f32x16 acc[NOB];
+#pragma unroll
+  for (int l = DEPTH - 1; l >= 1; --l) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < LBLK; ++b) {
+      const int slot = acquire();
+      const char* lw = smem + slot * BLK_BYTES + u16;
+#pragma unroll
+      for (int kl = 0; kl < KPB; ++kl)
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+          acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lw + (kl * NOB + ob) * 1024),
+                                                            __builtin_bit_cast(bf16x8, dzf[KPB * b + kl]), acc[ob], 0, 0, 0);
+      if constexpr (PROP_LDS_PREFETCH > 0) {
+        constexpr int D = PROP_LDS_PREFETCH, NF = KPB * NOB;
+#pragma unroll
+        for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < NF - D; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+#pragma unroll
+      for (int kl = 0; kl < KPB; ++kl) save_frag(l, KPB * b + kl);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // bf16, then the ReLU mask of the layer below: halves times their bit (v_pk_mul_lo_u16), as linear_fm act 2
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const f32x2 f = {acc[ob][2 * p], acc[ob][2 * p + 1]};
+        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, w) * __builtin_bit_cast(u16x2, mask_of(l - 1, ob, p)));
+        dzf[2 * ob + (p >> 2)][p & 3] = w;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int c = 0; c < WIDTH / 16; ++c) save_frag(0, c);
+}
+
 }  // namespace mip360prop
 
 // hipFuncSetAttribute is per device: remember which devices of this process have had it applied (one bit per device id)
@@ -304,5 +440,27 @@ int mip360_launch_prop_mlp_fm(hipStream_t st, int rows, const void* x_fm, int ld
       if (hipFuncSetAttribute((const void*)prop_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) return 3;
     hipLaunchKernelGGL(prop_mlp_fwd_kernel<false>, dim3(rows / 256), dim3(NW * 64), LDS_TOTAL, st, a);
   }
+  return 0;
+}
+
+// z bf16 [rows], wd bf16 [256], masks[l] of the forward, wb_fm[l] (l = 1 .. 3) fm [256, ldwb[l]], dz_fm[l] fm [rows, 256] out
+int mip360_launch_prop_mlp_bwd_fm(hipStream_t st, int rows, const void* z, const void* wd, const void* const* masks,
+                                  const void* const* wb_fm, const int* ldwb, void* const* dz_fm) {
+  using namespace mip360prop;
+  if (rows <= 0 || rows % 256 || !z || !wd || !masks || !wb_fm || !ldwb || !dz_fm) return 1;
+  BwdArgs a{};
+  a.rows = rows; a.z = (const uint16_t*)z; a.wd = (const uint16_t*)wd;
+  for (int l = 0; l < DEPTH; ++l) {
+    if (!masks[l] || !dz_fm[l]) return 1;
+    a.mask[l] = (const uint32_t*)masks[l]; a.dz[l] = (char*)dz_fm[l];
+    if (l >= 1) {
+      if (!wb_fm[l] || ldwb[l] % 16 || ldwb[l] < WIDTH) return 1;
+      a.wb[l] = (const char*)wb_fm[l]; a.wb_bpr[l] = ldwb[l] / 16;
+    }
+  }
+  static std::atomic<uint64_t> done{0};
+  if (prop_first_launch_on_this_device(done))
+    if (hipFuncSetAttribute((const void*)prop_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) return 3;
+  hipLaunchKernelGGL(prop_mlp_bwd_kernel, dim3(rows / 256), dim3(NW * 64), LDS_TOTAL, st, a);
   return 0;
 }

@@ -55,6 +55,7 @@ SYMBOLS = {
     'mip360_outer_masked_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int]),
     'mip360_prop_mlp_fm': (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fpp, C.POINTER(C.c_int), _fpp, _fpp, _fpp, _fp, _fp,
                                      C.c_float, _fp]),
+    'mip360_prop_mlp_bwd_fm': (C.c_int, [_fp, C.c_int, _fp, _fp, _fpp, _fpp, C.POINTER(C.c_int), _fpp]),
     'mip360_pack_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
@@ -274,6 +275,14 @@ def prop_mlp_fm(enc_buf, x_col0, ldx, rows, w_fm, ldw, bias, wd, bd, density, h=
     mp = arr(masks) if masks is not None else None
     _check(lib().mip360_prop_mlp_fm(_stream(), int(rows), _fm_ptr(enc_buf, 0), int(ldx), int(x_col0), keep[0], keep[1], keep[2], hp, mp,
                                     _p(wd), _p(bd), DENSITY_BIAS, _p(density)), 'mip360_prop_mlp_fm')
+
+
+def prop_mlp_bwd_fm(rows, z, wd, masks, wb_fm, ldwb, dz):
+    """The PropMLP dX chain as one launch (include/mip360_hip.h: mip360_prop_mlp_bwd_fm): z bf16 [rows], masks / dz: 4 buffers,
+    wb_fm / ldwb: entries 1..3 (entry 0 ignored)."""
+    arr = lambda ts: (C.c_void_p * 4)(*[_p(t) for t in ts])
+    _check(lib().mip360_prop_mlp_bwd_fm(_stream(), int(rows), _p(z), _p(wd), arr(masks), arr(wb_fm), (C.c_int * 4)(*[int(v) for v in ldwb]),
+                                        arr(dz)), 'mip360_prop_mlp_bwd_fm')
 
 
 def render_level(density, rgb_samples, tdist, directions, opaque_background=True, bg_rgb=1.0):
@@ -838,6 +847,14 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
                                           RGB_PADDING, _p(d_raw), 1, 0, 1, None), 'mip360_head_backward')
         _check(lib().mip360_grad_weight_col_fm(_stream(), rows, trunk_k, _fm_ptr(trunk, t_col0), t_ld, _p(d_raw), 1, 0, ks, _p(scratch[0]),
                                                _p(tm.kernel(D, G)), 1.0, _p(tm.bias(D, G))), 'mip360_grad_weight_col_fm')
+        if fused_prop_ok(tm.cfg, rows):
+            # the whole dX chain in one launch, then the four weight-gradient GEMMs on what it wrote
+            dzs = [fm_buffer(rows, W, dev) for _ in range(D - 1)] + [dz]
+            prop_mlp_bwd_fm(rows, d_raw, tm.w[D], saved['masks'], [None] + [tm.wb_fm[i] for i in range(1, D)], [0] + [W] * (D - 1), dzs)
+            for i in reversed(range(D)):
+                x, x_col0, x_ld, x_k = saved['inputs'][i]
+                _grad_weight_fm(x, x_col0, x_ld, dzs[i], W, rows, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G), rows_out=tm.shapes[i][0])
+            return
         _check(lib().mip360_outer_masked_fm(_stream(), rows, W, _p(d_raw), _p(tm.w[D]), _p(saved['masks'][D - 1]), _p(dz), W),
                'mip360_outer_masked_fm')
     else:

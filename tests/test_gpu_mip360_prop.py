@@ -6,6 +6,7 @@
 * the ReLU masks in mip360_linear_fm's format: the masked dX layer (act 2) driven by the fused kernel's mask zeroes exactly the
   elements whose saved activation is zero;
 * density == mip360_rowdot_fm of the saved last layer, bit for bit; inference mode (nothing saved) == training mode;
+* mip360_prop_mlp_bwd_fm (the dX chain as one launch) == mip360_outer_masked_fm + 3 x mip360_linear_fm act 2, bit for bit;
 * the training step of Mip360Trainer with and without the fused launch: same losses / parameters to summation-order grade.
 """
 import numpy as np
@@ -77,6 +78,35 @@ def test_prop_mlp_fm_layers_masks_and_density(M, rows):
     # inference mode: nothing saved, the same density
     _, _, d_inf = _fused(M, P, rows, train=False)
     np.testing.assert_array_equal(N(d_inf), N(density))
+
+
+@pytest.mark.parametrize('rows', [256, 66 * 256])
+def test_prop_mlp_bwd_fm_equals_the_launches_it_replaces(M, rows):
+    """dZ_3 .. dZ_0 of mip360_prop_mlp_bwd_fm against mip360_outer_masked_fm + three mip360_linear_fm (act 2) on the masks the fused
+    forward wrote: bit for bit (same products, same MFMA sequence per element); and dZ_2 against float64."""
+    P = _problem(M, rows, rows + 1)
+    hs, masks, _ = _fused(M, P, rows)
+    rs = np.random.RandomState(rows)
+    z = round_bf16((rs.randn(rows) * 0.05).astype(np.float32))
+    wbs = [None] + [round_bf16(np.ascontiguousarray(P['ws'][l].T)) for l in range(1, 4)]        # [in, out] = W_l^T: dX = dZ W_l
+    wb_fm = [None] + [M.to_fm(bf(w)) for w in wbs[1:]]
+    dz = [M.fm_buffer(rows, 256, dev()) for _ in range(4)]
+    M.prop_mlp_bwd_fm(rows, bf(z), P['wd_t'], masks, wb_fm, [0, 256, 256, 256], dz)
+    want = [None] * 4
+    want[3] = M.fm_buffer(rows, 256, dev())
+    M._check(M.lib().mip360_outer_masked_fm(M._stream(), rows, 256, M._p(bf(z)), M._p(P['wd_t']), M._p(masks[3]), M._p(want[3]), 256),
+             'outer_masked_fm')
+    for l in (3, 2, 1):
+        want[l - 1] = M.fm_buffer(rows, 256, dev())
+        M.linear_fm(want[l], wb_fm[l], None, 2, rows, 256, 256, want[l - 1], masks[l - 1])
+    for l in range(4):
+        np.testing.assert_array_equal(N(dz[l]).view(np.uint16) if N(dz[l]).dtype != np.float32 else N(dz[l]), N(want[l]).view(np.uint16) if N(want[l]).dtype != np.float32 else N(want[l]))
+    d3 = N(M.from_fm(dz[3], rows, 256)).astype(np.float64)
+    h2 = N(M.from_fm(hs[2], rows, 256))
+    ref = (d3 @ P['ws'][3].astype(np.float64)) * (h2 != 0)
+    np.testing.assert_allclose(N(M.from_fm(dz[2], rows, 256)), ref, rtol=2 ** -7, atol=1e-5)
+    h3 = N(M.from_fm(hs[3], rows, 256))
+    np.testing.assert_allclose(d3, round_bf16((z[:, None] * P['wd']).astype(np.float32)) * (h3 != 0), rtol=0, atol=0)
 
 
 def test_prop_mlp_fm_rejects_shapes_it_does_not_take(M):
