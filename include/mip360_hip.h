@@ -201,6 +201,15 @@ int mip360_outer_masked_fm(void* stream, int m, int n, const void* z_bf16, const
  * (i, bwd_col0 + o) for i < bwd_rows; either may be NULL; padding is never written (zero the buffers once). */
 int mip360_pack_weight_fm(void* stream, int n_in, int n_out, const float* kernel, void* fwd_bf16, int ld_fwd, void* bwd_bf16, int ld_bwd,
                           void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0);
+/* n calls of mip360_pack_weight_fm as ONE launch (all parameter tensors of an MLP after an Adam step: twelve 5-10 us launches on
+ * the update stream otherwise run next to the following step's first kernels).  descs: host array, 1 <= n <= 16. */
+typedef struct mip360_pack_desc {
+  const float* kernel; int32_t n_in, n_out;
+  void* fwd_bf16; void* bwd_bf16; void* fwd_fm; void* bwd_fm;
+  int32_t ld_fwd, ld_bwd, ld_fwd_fm, ld_bwd_fm, bwd_rows, bwd_col0;
+} mip360_pack_desc;
+#define MIP360_PACK_BATCH_MAX 16
+int mip360_pack_weights_fm_batch(void* stream, int n, const mip360_pack_desc* descs);
 /* mip360_grad_weight_bf16 (below) with both operands in fm layout; n_in, n_out multiples of 256, m of 32.  Same slab
  * contract: grad_kernel == NULL leaves the sums to mip360_grad_weight_reduce. */
 int mip360_grad_weight_fm(void* stream, int m, int n_in, int n_out, const void* h_fm, int ldh, const void* dz_fm, int lddz,

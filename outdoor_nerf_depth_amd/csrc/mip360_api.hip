@@ -52,6 +52,7 @@ void mip360_launch_sumsq(hipStream_t st, int64_t n, const float* g, float* parti
 void mip360_launch_clip_mult(hipStream_t st, int n_partial, const float* partial, float max_norm, float* out);
 void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, float* m, float* v, const float* gmult, float lr,
                         float b1, float b2, float eps, float bc1, float bc2);
+void mip360_launch_pack_weight_batch(hipStream_t st, int n, const mip360_pack_desc* descs);
 void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd,
                                void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0);
 int mip360_launch_outer_masked_fm(hipStream_t st, int M, int N, const void* z, const void* w, const void* mask, void* out, int ldc);
@@ -367,6 +368,20 @@ int mip360_pack_weight_fm(void* stream, int n_in, int n_out, const float* kernel
   mip360_launch_pack_weight((hipStream_t)stream, n_in, n_out, kernel, fwd_bf16, ld_fwd, bwd_bf16, ld_bwd, fwd_fm, ld_fwd_fm, bwd_fm, ld_bwd_fm,
                             bwd_rows, bwd_col0);
   return check_launch("pack_weight_fm");
+}
+
+int mip360_pack_weights_fm_batch(void* stream, int n, const mip360_pack_desc* descs) {
+  REQUIRE(n >= 1 && n <= MIP360_PACK_BATCH_MAX && descs, "1 <= n <= 16 descriptors");
+  for (int t = 0; t < n; ++t) {
+    const mip360_pack_desc& d = descs[t];
+    REQUIRE(d.n_in > 0 && d.n_out > 0 && d.kernel, "arguments");
+    REQUIRE((!d.fwd_bf16 || d.ld_fwd >= d.n_in) && (!d.bwd_bf16 || d.ld_bwd >= d.n_out), "leading dimensions");
+    REQUIRE((!d.fwd_fm || (d.ld_fwd_fm >= d.n_in && d.ld_fwd_fm % 16 == 0)) &&
+            (!d.bwd_fm || (d.ld_bwd_fm >= d.bwd_col0 + d.n_out && d.ld_bwd_fm % 16 == 0 && d.bwd_col0 >= 0)),
+            "fm leading dimensions (multiples of 16)");
+  }
+  mip360_launch_pack_weight_batch((hipStream_t)stream, n, descs);
+  return check_launch("pack_weights_fm_batch");
 }
 
 int mip360_outer_masked_fm(void* stream, int m, int n, const void* z_bf16, const void* w_bf16, const void* mask, void* c_fm, int ldc) {

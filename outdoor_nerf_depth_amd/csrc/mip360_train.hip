@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "../../include/mip360_hip.h"
 
 namespace mip360 {
 
@@ -586,6 +587,29 @@ void mip360_launch_clip_mult(hipStream_t st, int n_partial, const float* partial
 void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, float* m, float* v, const float* gmult, float lr,
                         float b1, float b2, float eps, float bc1, float bc2) {
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, gmult, lr, b1, b2, eps, bc1, bc2);
+}
+// the same for up to 16 tensors in one launch: blockIdx.y = tensor, blocks beyond a tensor's elements leave at once
+struct PackBatch { mip360_pack_desc d[MIP360_PACK_BATCH_MAX]; };
+__global__ void pack_weight_batch_kernel(const PackBatch b) {
+  const mip360_pack_desc& d = b.d[blockIdx.y];
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)d.n_in * d.n_out) return;
+  const int i = (int)(e / d.n_out), o = (int)(e - (int64_t)i * d.n_out);
+  const __bf16 v = (__bf16)d.kernel[e];
+  if (d.fwd_bf16) ((__bf16*)d.fwd_bf16)[(size_t)o * d.ld_fwd + i] = v;
+  if (d.bwd_bf16) ((__bf16*)d.bwd_bf16)[(size_t)i * d.ld_bwd + o] = v;
+  if (d.fwd_fm) ((__bf16*)d.fwd_fm)[fm_elem(o, i, d.ld_fwd_fm)] = v;
+  if (d.bwd_fm && i < d.bwd_rows) ((__bf16*)d.bwd_fm)[fm_elem(i, d.bwd_col0 + o, d.ld_bwd_fm)] = v;
+}
+void mip360_launch_pack_weight_batch(hipStream_t st, int n, const mip360_pack_desc* descs) {
+  PackBatch b{};
+  int64_t most = 0;
+  for (int t = 0; t < n; ++t) {
+    b.d[t] = descs[t];
+    const int64_t e = (int64_t)descs[t].n_in * descs[t].n_out;
+    most = e > most ? e : most;
+  }
+  hipLaunchKernelGGL(pack_weight_batch_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n), dim3(256), 0, st, b);
 }
 void mip360_launch_pack_weight(hipStream_t st, int n_in, int n_out, const float* k, void* fwd, int ld_fwd, void* bwd, int ld_bwd,
                                void* fwd_fm, int ld_fwd_fm, void* bwd_fm, int ld_bwd_fm, int bwd_rows, int bwd_col0) {

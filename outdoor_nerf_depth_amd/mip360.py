@@ -24,6 +24,13 @@ N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
 _fp = C.c_void_p
 _fpp = C.POINTER(C.c_void_p)
 
+class PackDesc(C.Structure):
+    """include/mip360_hip.h: mip360_pack_desc"""
+    _fields_ = [('kernel', C.c_void_p), ('n_in', C.c_int32), ('n_out', C.c_int32), ('fwd_bf16', C.c_void_p), ('bwd_bf16', C.c_void_p),
+                ('fwd_fm', C.c_void_p), ('bwd_fm', C.c_void_p), ('ld_fwd', C.c_int32), ('ld_bwd', C.c_int32), ('ld_fwd_fm', C.c_int32),
+                ('ld_bwd_fm', C.c_int32), ('bwd_rows', C.c_int32), ('bwd_col0', C.c_int32)]
+
+
 SYMBOLS = {
     'mip360_last_error': (C.c_char_p, []),
     'mip360_abi_version': (C.c_int, []),
@@ -57,6 +64,7 @@ SYMBOLS = {
                                      C.c_float, _fp]),
     'mip360_prop_mlp_bwd_fm': (C.c_int, [_fp, C.c_int, _fp, _fp, _fpp, _fpp, C.POINTER(C.c_int), _fpp]),
     'mip360_pack_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int]),
+    'mip360_pack_weights_fm_batch': (C.c_int, [_fp, C.c_int, _fp]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
     'mip360_grad_weight_bf16': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                           C.c_float, _fp]),
@@ -256,6 +264,8 @@ def linear_fm(a, w, bias, act, m, n, k, out, mask, lda=None, ldw=None, ldc=None,
                                   _fm_ptr(out, out_col0), ldc or n, _p(mask)), 'mip360_linear_fm')
 
 
+# MIP360_NO_BATCH_PACK=1: one mip360_pack_weight_fm launch per parameter tensor instead of one per MLP (A/B runs)
+USE_BATCH_PACK = os.environ.get('MIP360_NO_BATCH_PACK') is None
 # MIP360_NO_FUSED_PROP=1 keeps the PropMLP forward on four mip360_linear_fm + mip360_rowdot_fm launches (A/B runs)
 USE_FUSED_PROP = os.environ.get('MIP360_NO_FUSED_PROP') is None
 
@@ -637,6 +647,7 @@ class TrainableMLP(object):
         L = lib()
         skip_rm = bool(lazy and self.w_fm)
         self.rm_stale = skip_rm
+        descs = []
         for t, (i, o) in enumerate(self.shapes):
             k = self.kernel(t)
             bwd, ldb = None, 0
@@ -663,9 +674,19 @@ class TrainableMLP(object):
                 fwd, bwd = None, None
             elif skip_rm and t == D:
                 bwd = None
-            _check(L.mip360_pack_weight_fm(_stream(), i, o, _p(k), _p(fwd), self.in_pad[t], _p(bwd), ldb, _p(fwd_fm),
-                                           self.in_pad[t] if fwd_fm is not None else 0, _p(bwd_fm), ld_bwd_fm, bwd_rows, bwd_col0),
-                   'mip360_pack_weight_fm')
+            ptr = lambda x: None if x is None else x.data_ptr()
+            descs.append(PackDesc(ptr(k), i, o, ptr(fwd), ptr(bwd), ptr(fwd_fm), ptr(bwd_fm), self.in_pad[t], ldb,
+                                  self.in_pad[t] if fwd_fm is not None else 0, ld_bwd_fm, bwd_rows, bwd_col0))
+        # one launch for all tensors (twelve small launches on the update stream otherwise run next to the next step's first kernels)
+        if not USE_BATCH_PACK:                              # (A/B runs: one launch per tensor)
+            for d in descs:
+                _check(L.mip360_pack_weight_fm(_stream(), d.n_in, d.n_out, d.kernel, d.fwd_bf16, d.ld_fwd, d.bwd_bf16, d.ld_bwd, d.fwd_fm,
+                                               d.ld_fwd_fm, d.bwd_fm, d.ld_bwd_fm, d.bwd_rows, d.bwd_col0), 'mip360_pack_weight_fm')
+            return
+        for a0 in range(0, len(descs), 16):
+            chunk = descs[a0:a0 + 16]
+            arr = (PackDesc * len(chunk))(*chunk)
+            _check(L.mip360_pack_weights_fm_batch(_stream(), len(chunk), C.cast(arr, C.c_void_p)), 'mip360_pack_weights_fm_batch')
 
     def state(self):
         return [(self.kernel(t).clone(), self.bias(t).clone()) for t in range(len(self.shapes))]
