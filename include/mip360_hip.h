@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MIP360_ABI_VERSION 6
+#define MIP360_ABI_VERSION 7
 #define MIP360_OK 0
 #define MIP360_ERR_ARG 1
 #define MIP360_ERR_HIP 2
@@ -193,6 +193,16 @@ int mip360_prop_mlp_fm(void* stream, int rows, const void* x_fm, int ldx, int x_
  * mip360_pack_weight_fm [256, ldwb[l]].  Bit-identical to the four launches it replaces. */
 int mip360_prop_mlp_bwd_fm(void* stream, int rows, const void* z_bf16, const void* wd_bf16, const void* const* masks,
                            const void* const* wb_fm, const int* ldwb, void* const* dz_fm);
+/* The view branch of the NerfMLP, forward, as ONE launch (models.py:560-606): [bottleneck (256) | pos_enc(viewdirs, 0, 4) (27 -> 32)]
+ * -> Dense(128) + ReLU -> Dense(3) -> sigmoid * (1 + 2 rgb_padding) - rgb_padding; = mip360_from_fm + mip360_dir_encode + two
+ * mip360_linear_bf16 (act 1 / 3).  bott_fm [rows, 256] fm (mip360_linear_fm act 0); dir_table_bf16 [rows / n_samples, 32]: the rays'
+ * direction features, written by mip360_dir_encode(n_rays, S = 1, viewdirs, table, ld 32, col0 0, width 32); w1_fm fm
+ * [128, ldw1 >= 288], w2_fm fm [32, ldw2 >= 128] with rows 3..31 zero (fwd_fm copies of mip360_pack_weight_fm), b1 [128], b2 [3].
+ * view_in_bf16 [rows, ld_view >= 288] / h_bf16 [rows, ld_h >= 128]: the row-major operands the backward entry points read
+ * (either may be NULL: not written); rgb [rows, 3].  rows a multiple of 256. */
+int mip360_view_branch_fm(void* stream, int rows, int n_samples, const void* bott_fm, const void* dir_table_bf16, const void* w1_fm, int ldw1,
+                          const float* b1, const void* w2_fm, int ldw2, const float* b2, float rgb_padding, void* view_in_bf16,
+                          int ld_view, void* h_bf16, int ld_h, float* rgb);
 /* c_fm[m][n] = bf16(z[m] * w[n]) where bit (m, n) of `mask` is set (z bf16 [m], w bf16 [n]): mip360_linear_fm act 2 for a
  * one-column operand -- the PropMLP's dZ of the last trunk layer (its only head is the density column).
  * mip360_grad_weight_col_fm with lddz == 1 reads z from such a plain vector. */

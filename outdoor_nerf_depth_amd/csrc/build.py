@@ -31,7 +31,8 @@ SOURCES_MIP360 = {
     'mip360_kernels.hip': ['-ffp-contract=off'],    # arithmetic order of the oracle
     'mip360_gemm.hip': [],
     'mip360_fm.hip': [],
-    'mip360_prop.hip': [],                          # the PropMLP forward as one launch
+    'mip360_prop.hip': [],                          # the PropMLP forward / dX chain as one launch each
+    'mip360_view.hip': [],                          # the NerfMLP's view branch forward as one launch
     'mip360_train.hip': [],
     'mip360_api.hip': [],
 }

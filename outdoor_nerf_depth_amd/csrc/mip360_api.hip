@@ -61,6 +61,9 @@ int mip360_launch_prop_mlp_fm(hipStream_t st, int rows, const void* x_fm, int ld
                               float act_param, float* density);
 int mip360_launch_prop_mlp_bwd_fm(hipStream_t st, int rows, const void* z, const void* wd, const void* const* masks,
                                   const void* const* wb_fm, const int* ldwb, void* const* dz_fm);
+int mip360_launch_view_branch_fm(hipStream_t st, int rows, int n_samples, const void* bott_fm, const void* dir_table, const void* w1_fm,
+                                 int ldw1, const float* b1, const void* w2_fm, int ldw2, const float* b2, float rgb_padding,
+                                 void* view_in, int ld_view, void* h, int ld_h, float* rgb);
 void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width);
 
 namespace {
@@ -290,6 +293,17 @@ int mip360_prop_mlp_bwd_fm(void* stream, int rows, const void* z_bf16, const voi
   REQUIRE(rc != 1, "rows a multiple of 256, four masks / outputs, wb_fm[1..3] with ldwb multiples of 16 >= 256");
   REQUIRE(rc == 0, "hipFuncSetAttribute");
   return check_launch("prop_mlp_bwd_fm");
+}
+
+int mip360_view_branch_fm(void* stream, int rows, int n_samples, const void* bott_fm, const void* dir_table_bf16, const void* w1_fm, int ldw1,
+                          const float* b1, const void* w2_fm, int ldw2, const float* b2, float rgb_padding, void* view_in_bf16,
+                          int ld_view, void* h_bf16, int ld_h, float* rgb) {
+  const int rc = mip360_launch_view_branch_fm((hipStream_t)stream, rows, n_samples, bott_fm, dir_table_bf16, w1_fm, ldw1, b1, w2_fm, ldw2, b2,
+                                              rgb_padding, view_in_bf16, ld_view, h_bf16, ld_h, rgb);
+  REQUIRE(rc != 1, "rows a multiple of 256 and of n_samples, ldw1 >= 288 / ldw2 >= 128 multiples of 16, ld_view >= 288 / ld_h >= 128 "
+                   "multiples of 4, non-null operands");
+  REQUIRE(rc == 0, "hipFuncSetAttribute");
+  return check_launch("view_branch_fm");
 }
 
 int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,

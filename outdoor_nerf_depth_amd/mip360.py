@@ -19,7 +19,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MIP360_HIP_LIB') or os.path.join(_HERE, 'libmip360_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
 _fp = C.c_void_p
 _fpp = C.POINTER(C.c_void_p)
@@ -63,6 +63,8 @@ SYMBOLS = {
     'mip360_prop_mlp_fm': (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fpp, C.POINTER(C.c_int), _fpp, _fpp, _fpp, _fp, _fp,
                                      C.c_float, _fp]),
     'mip360_prop_mlp_bwd_fm': (C.c_int, [_fp, C.c_int, _fp, _fp, _fpp, _fpp, C.POINTER(C.c_int), _fpp]),
+    'mip360_view_branch_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_float, _fp, C.c_int,
+                                        _fp, C.c_int, _fp]),
     'mip360_pack_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int]),
     'mip360_pack_weights_fm_batch': (C.c_int, [_fp, C.c_int, _fp]),
     'mip360_grad_weight_tile': (C.c_int, [C.c_int] * 5),
@@ -287,6 +289,25 @@ def prop_mlp_fm(enc_buf, x_col0, ldx, rows, w_fm, ldw, bias, wd, bd, density, h=
                                     _p(wd), _p(bd), DENSITY_BIAS, _p(density)), 'mip360_prop_mlp_fm')
 
 
+# MIP360_NO_FUSED_VIEW=1 keeps the view branch forward on from_fm + dir_encode + two row-major GEMMs (A/B runs)
+USE_FUSED_VIEW = os.environ.get('MIP360_NO_FUSED_VIEW') is None
+
+
+def view_branch_fm(pk, depth, bott, rows, n_samples, viewdirs, view_in, h, rgb):
+    """include/mip360_hip.h: mip360_view_branch_fm on the fm copies pk.w_fm[depth + 2] / [depth + 3]; view_in / h may be None"""
+    n_rays = rows // n_samples
+    table = torch.empty(n_rays, DIR_LD, dtype=torch.bfloat16, device=bott.device)      # the rays' direction features, once per ray
+    _check(lib().mip360_dir_encode(_stream(), n_rays, 1, _p(_f32(viewdirs)), _p(table), DIR_LD, 0, DIR_LD), 'mip360_dir_encode')
+    _check(lib().mip360_view_branch_fm(_stream(), int(rows), int(n_samples), _p(bott), _p(table), _p(pk.w_fm[depth + 2]),
+                                       BOTTLENECK + DIR_LD, _p(pk.b[depth + 2]), _p(pk.w_fm[depth + 3]), VIEW_WIDTH, _p(pk.b[depth + 3]),
+                                       RGB_PADDING, _p(view_in), view_in.stride(0) if view_in is not None else 0, _p(h),
+                                       h.stride(0) if h is not None else 0, _p(rgb)), 'mip360_view_branch_fm')
+
+
+def fused_view_ok(pk, depth, rows):
+    return USE_FUSED_VIEW and rows % 256 == 0 and (depth + 3) in pk.w_fm
+
+
 def prop_mlp_bwd_fm(rows, z, wd, masks, wb_fm, ldwb, dz):
     """The PropMLP dX chain as one launch (include/mip360_hip.h: mip360_prop_mlp_bwd_fm): z bf16 [rows], masks / dz: 4 buffers,
     wb_fm / ldwb: entries 1..3 (entry 0 ignored)."""
@@ -424,6 +445,11 @@ class PackedMLP(object):
         if USE_FM and W % 256 == 0:
             for i in list(range(depth)) + ([] if cfg['disable_rgb'] else [depth + 1]):
                 self.w_fm[i] = to_fm(self.w[i])
+            if not cfg['disable_rgb']:                     # the view branch as one launch (mip360_view_branch_fm)
+                self.w_fm[depth + 2] = to_fm(self.w[depth + 2])
+                w3 = torch.zeros(32, VIEW_WIDTH, dtype=torch.bfloat16, device=self.device)
+                w3[:3] = self.w[depth + 3]
+                self.w_fm[depth + 3] = to_fm(w3)
         self.mask_scratch = None
 
 
@@ -492,6 +518,10 @@ def mlp_forward_fm(pk, enc_buf, rows, viewdirs=None, n_rays=None, n_samples=None
         return density[:, 0], None
     bott = fm_buffer(rows, BOTTLENECK, dev)
     linear_fm(x, pk.w_fm[depth + 1], pk.b[depth + 1], 0, rows, BOTTLENECK, x_k, bott, None, lda=x_ld, ldw=x_k, a_col0=x_col0)
+    if fused_view_ok(pk, depth, rows):
+        rgb = torch.empty(rows, 3, device=dev)
+        view_branch_fm(pk, depth, bott, rows, n_samples, viewdirs, None, None, rgb)
+        return density[:, 0], rgb
     view_in = torch.empty(rows, BOTTLENECK + DIR_LD, dtype=torch.bfloat16, device=dev)
     from_fm(bott, rows, BOTTLENECK, out=view_in)
     _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0), BOTTLENECK,
@@ -624,6 +654,8 @@ class TrainableMLP(object):
             self.wb_fm['heads'] = fmz(W, self.head_k)
             if not cfg['disable_rgb']:
                 self.w_fm[D + 1] = fmz(BOTTLENECK, W)
+                self.w_fm[D + 2] = fmz(VIEW_WIDTH, BOTTLENECK + DIR_LD)       # the view branch as one launch (mip360_view_branch_fm)
+                self.w_fm[D + 3] = fmz(32, VIEW_WIDTH)                        # (3 live rows)
         self.repack()
 
     def kernel(self, t, buf=None):
@@ -821,13 +853,16 @@ def mlp_forward_train_fm(tm, enc_buf, rows, viewdirs, n_rays, n_samples):
         bott = fm_buffer(rows, BOTTLENECK, dev)
         linear_fm(x, tm.w_fm[D + 1], tm.b[D + 1], 0, rows, BOTTLENECK, x_k, bott, None, lda=x_ld, ldw=x_k, a_col0=x_col0)
         view_in = torch.empty(rows, BOTTLENECK + DIR_LD, dtype=torch.bfloat16, device=dev)
-        from_fm(bott, rows, BOTTLENECK, out=view_in)
-        _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0),
-                                       BOTTLENECK, DIR_LD), 'mip360_dir_encode')
         h = torch.empty(rows, VIEW_WIDTH, dtype=torch.bfloat16, device=dev)
-        linear(view_in, tm.w[D + 2], tm.b[D + 2], act=1, out_bf16=h, m=rows, n=VIEW_WIDTH, k=BOTTLENECK + DIR_LD)
         rgb = torch.empty(rows, 3, device=dev)
-        linear(h, tm.w[D + 3], tm.b[D + 3], act=3, act_param=RGB_PADDING, out_f32=rgb, m=rows, n=3, k=VIEW_WIDTH)
+        if fused_view_ok(tm, D, rows):
+            view_branch_fm(tm, D, bott, rows, n_samples, viewdirs, view_in, h, rgb)
+        else:
+            from_fm(bott, rows, BOTTLENECK, out=view_in)
+            _check(lib().mip360_dir_encode(_stream(), n_rays, n_samples, _p(_f32(viewdirs)), _p(view_in), view_in.stride(0),
+                                           BOTTLENECK, DIR_LD), 'mip360_dir_encode')
+            linear(view_in, tm.w[D + 2], tm.b[D + 2], act=1, out_bf16=h, m=rows, n=VIEW_WIDTH, k=BOTTLENECK + DIR_LD)
+            linear(h, tm.w[D + 3], tm.b[D + 3], act=3, act_param=RGB_PADDING, out_f32=rgb, m=rows, n=3, k=VIEW_WIDTH)
         saved.update(view_in=view_in, h=h, rgb=rgb)
     return density[:, 0], rgb, saved
 

@@ -7,6 +7,7 @@
   elements whose saved activation is zero;
 * density == mip360_rowdot_fm of the saved last layer, bit for bit; inference mode (nothing saved) == training mode;
 * mip360_prop_mlp_bwd_fm (the dX chain as one launch) == mip360_outer_masked_fm + 3 x mip360_linear_fm act 2, bit for bit;
+* mip360_view_branch_fm (the NerfMLP's view branch, forward) against from_fm + dir_encode + two row-major GEMMs;
 * the training step of Mip360Trainer with and without the fused launch: same losses / parameters to summation-order grade.
 """
 import numpy as np
@@ -135,6 +136,7 @@ def test_trainer_step_with_and_without_the_fused_prop_mlp(M, monkeypatch):
     out = {}
     for fused in (True, False):
         monkeypatch.setattr(M, 'USE_FUSED_PROP', fused)
+        monkeypatch.setattr(M, 'USE_FUSED_VIEW', fused)
         prs = np.random.RandomState(7)
         tr = M.Mip360Trainer(O.init_mlp_params(O.PROP_CFG, prs), O.init_mlp_params(O.NERF_CFG, prs), dev(), max_steps=1000)
         hist = [N(tr.train_step(rays, gt, sup, jitter01=jit[s_])) for s_ in range(3)]
@@ -147,3 +149,56 @@ def test_trainer_step_with_and_without_the_fused_prop_mlp(M, monkeypatch):
     for a_, b_ in ((out[True][1], out[False][1]), (out[True][2], out[False][2])):
         assert np.abs(a_ - b_).max() <= 3 * 2.5 * lr                     # three Adam steps, each bounded by ~lr
         assert np.mean(np.abs(a_ - b_) > 0.5 * lr) < 0.1
+
+
+def test_view_branch_fm_equals_the_launches_it_replaces(M):
+    """mip360_view_branch_fm against mip360_from_fm + mip360_dir_encode + two mip360_linear_bf16 (act 1 / act 3) on the same operands:
+    view_in bit for bit (a copy of the bottleneck + dir_encode's arithmetic), h up to the summation order, rgb to 1e-5; and against
+    float64.  Inference form (nothing but rgb written) gives the same rgb."""
+    rs = np.random.RandomState(21)
+    n_rays, S = 64, 32
+    rows = n_rays * S
+    bott = round_bf16(rs.randn(rows, 256).astype(np.float32))
+    vd = rs.randn(n_rays, 3).astype(np.float32)
+    vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    w1 = round_bf16((rs.randn(128, 288) * np.sqrt(2.0 / 283)).astype(np.float32))
+    w1[:, 283:] = 0
+    w2 = round_bf16((rs.randn(3, 128) / np.sqrt(128)).astype(np.float32))
+    b1, b2 = (rs.randn(128) * 0.1).astype(np.float32), (rs.randn(3) * 0.1).astype(np.float32)
+    bott_fm = M.to_fm(bf(bott))
+    w1_fm = M.to_fm(bf(w1))
+    w2p = np.zeros((32, 128), np.float32)
+    w2p[:3] = w2
+    w2_fm = M.to_fm(bf(w2p))
+
+    class PK(object):
+        w_fm = {2: w1_fm, 3: w2_fm}
+        b = {2: T(b1), 3: T(b2)}
+    view_in = torch.full((rows, 288), 9.0, dtype=torch.bfloat16, device=dev())
+    h = torch.full((rows, 128), 9.0, dtype=torch.bfloat16, device=dev())
+    rgb = torch.empty(rows, 3, device=dev())
+    M.view_branch_fm(PK, 0, bott_fm, rows, S, T(vd), view_in, h, rgb)
+    # the launches it replaces
+    want_in = torch.empty(rows, 288, dtype=torch.bfloat16, device=dev())
+    M.from_fm(bott_fm, rows, 256, out=want_in)
+    M._check(M.lib().mip360_dir_encode(M._stream(), n_rays, S, M._p(T(vd)), M._p(want_in), 288, 256, 32), 'dir_encode')
+    want_h = torch.empty(rows, 128, dtype=torch.bfloat16, device=dev())
+    M.linear(want_in, bf(w1), T(b1), act=1, out_bf16=want_h, m=rows, n=128, k=288)
+    want_rgb = torch.empty(rows, 3, device=dev())
+    M.linear(want_h, bf(w2), T(b2), act=3, act_param=M.RGB_PADDING, out_f32=want_rgb, m=rows, n=3, k=128)
+    np.testing.assert_array_equal(N(view_in), N(want_in))
+    gh, wh = N(h), N(want_h)
+    assert (gh != wh).mean() < 2e-3
+    np.testing.assert_allclose(gh, wh, rtol=2 ** -7, atol=1e-6)
+    np.testing.assert_allclose(N(rgb), N(want_rgb), rtol=0, atol=2e-4)
+    # float64 on the kernel's own bf16 intermediate
+    x = N(view_in).astype(np.float64)
+    ref_h = np.maximum(x @ w1.astype(np.float64).T + b1, 0)
+    np.testing.assert_allclose(gh, ref_h, rtol=2 ** -7, atol=2e-3)
+    raw = gh.astype(np.float64) @ w2.astype(np.float64).T + b2
+    np.testing.assert_allclose(N(rgb), 1 / (1 + np.exp(-raw)) * (1 + 2 * M.RGB_PADDING) - M.RGB_PADDING, rtol=0, atol=2e-6)
+    rgb2 = torch.empty(rows, 3, device=dev())
+    M.view_branch_fm(PK, 0, bott_fm, rows, S, T(vd), None, None, rgb2)
+    np.testing.assert_array_equal(N(rgb2), N(rgb))
+    with pytest.raises(M.Mip360Error):
+        M.view_branch_fm(PK, 0, bott_fm, rows - 32, S, T(vd), None, None, rgb2)
