@@ -29,6 +29,8 @@ int mip360_launch_linear_fm(hipStream_t st, int M, int N, int K, const void* A, 
                             int act, void* C, int ldc, void* mask);
 int mip360_launch_grad_weight_fm(hipStream_t st, int M, int I, int O, const void* H, int ldh, const void* dZ, int lddz, int ksplit,
                                  float* slabs, int ldc, float* bias_slabs);
+int mip360_launch_grad_weight_fm_multi(hipStream_t st, int n, int M, int ksplit, const int* I, const int* O, const void* const* H, const int* ldh,
+                                       const void* const* dZ, const int* lddz, float* const* slabs);
 int mip360_launch_rowdot_fm(hipStream_t st, int M, int K, const void* A, int lda, const void* w, const float* bias, int act, float act_param,
                             float* out, int ldo);
 int mip360_launch_grad_weight_col_fm(hipStream_t st, int M, int I, const void* H, int ldh, const void* dZ, int lddz, int zcol, int ksplit,
@@ -266,6 +268,15 @@ int mip360_grad_weight_fm(void* stream, int m, int n_in, int n_out, const void* 
           "m a multiple of 32, n_in / n_out multiples of 256, leading dimensions multiples of 16");
   if (grad_kernel) mip360_launch_grad_weight_reduce((hipStream_t)stream, n_in, n_in, n_out, ksplit, slabs, grad_kernel, ldg, scale, grad_bias);
   return check_launch("grad_weight_fm");
+}
+
+int mip360_grad_weight_fm_multi(void* stream, int n, int m, int ksplit, const int* n_in, const int* n_out, const void* const* h_fm,
+                                const int* ldh, const void* const* dz_fm, const int* lddz, float* const* slabs) {
+  REQUIRE(n_in && n_out && h_fm && ldh && dz_fm && lddz && slabs, "pointers");
+  REQUIRE(mip360_launch_grad_weight_fm_multi((hipStream_t)stream, n, m, ksplit, n_in, n_out, h_fm, ldh, dz_fm, lddz, slabs) == 0,
+          "1 <= n <= 8 problems, m a multiple of 32, ksplit a multiple of 8 (<= 256), n_in / n_out multiples of 256, leading dimensions "
+          "multiples of 16");
+  return check_launch("grad_weight_fm_multi");
 }
 
 int mip360_rowdot_fm(void* stream, int m, int k, const void* a_fm, int lda, const void* w_bf16, const float* bias, int act,

@@ -57,6 +57,8 @@ SYMBOLS = {
     'mip360_linear_fm': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
     'mip360_grad_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int,
                                         C.c_float, _fp]),
+    'mip360_grad_weight_fm_multi': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _fpp, C.POINTER(C.c_int),
+                                              _fpp, C.POINTER(C.c_int), _fpp]),
     'mip360_rowdot_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_float, _fp, C.c_int]),
     'mip360_grad_weight_col_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp]),
     'mip360_outer_masked_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int]),
@@ -289,6 +291,8 @@ def prop_mlp_fm(enc_buf, x_col0, ldx, rows, w_fm, ldw, bias, wd, bd, density, h=
                                     _p(wd), _p(bd), DENSITY_BIAS, _p(density)), 'mip360_prop_mlp_fm')
 
 
+# MIP360_NO_MULTI_DW=1: the PropMLP's four weight-gradient GEMMs stay four launches (A/B runs)
+USE_MULTI_DW = os.environ.get('MIP360_NO_MULTI_DW') is None
 # MIP360_NO_FUSED_VIEW=1 keeps the view branch forward on from_fm + dir_encode + two row-major GEMMs (A/B runs)
 USE_FUSED_VIEW = os.environ.get('MIP360_NO_FUSED_VIEW') is None
 
@@ -907,6 +911,26 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
             # the whole dX chain in one launch, then the four weight-gradient GEMMs on what it wrote
             dzs = [fm_buffer(rows, W, dev) for _ in range(D - 1)] + [dz]
             prop_mlp_bwd_fm(rows, d_raw, tm.w[D], saved['masks'], [None] + [tm.wb_fm[i] for i in range(1, D)], [0] + [W] * (D - 1), dzs)
+            if USE_MULTI_DW:
+                # the four weight-gradient GEMMs as one launch (5 tiles x 48 row slices instead of 4 launches of 256 / 512 slices: a
+                # fifth of the slab traffic), then the four slab sums
+                ks = 48
+                n_ins = [saved['inputs'][i][3] for i in range(D)]
+                sizes = [ks * (n_ins[i] * W + W) for i in range(D)]
+                if scratch[1] is None or scratch[1].numel() < sum(sizes):
+                    scratch[1] = torch.empty(sum(sizes), device=dev)
+                offs = np.concatenate([[0], np.cumsum(sizes)])
+                slabs = [scratch[1][int(offs[i]):int(offs[i + 1])] for i in range(D)]
+                ci = lambda v: (C.c_int * D)(*[int(x) for x in v])
+                cp = lambda ps: (C.c_void_p * D)(*ps)
+                _check(lib().mip360_grad_weight_fm_multi(
+                    _stream(), D, rows, ks, ci(n_ins), ci([W] * D), cp([_fm_ptr(saved['inputs'][i][0], saved['inputs'][i][1]) for i in range(D)]),
+                    ci([saved['inputs'][i][2] for i in range(D)]), cp([_p(dzs[i]) for i in range(D)]), ci([W] * D),
+                    cp([_p(t) for t in slabs])), 'mip360_grad_weight_fm_multi')
+                for i in range(D):
+                    _check(lib().mip360_grad_weight_reduce(_stream(), tm.shapes[i][0], n_ins[i], W, ks, _p(slabs[i]), _p(tm.kernel(i, G)), W,
+                                                           1.0, _p(tm.bias(i, G))), 'mip360_grad_weight_reduce')
+                return
             for i in reversed(range(D)):
                 x, x_col0, x_ld, x_k = saved['inputs'][i]
                 _grad_weight_fm(x, x_col0, x_ld, dzs[i], W, rows, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G), rows_out=tm.shapes[i][0])

@@ -202,3 +202,37 @@ def test_view_branch_fm_equals_the_launches_it_replaces(M):
     np.testing.assert_array_equal(N(rgb2), N(rgb))
     with pytest.raises(M.Mip360Error):
         M.view_branch_fm(PK, 0, bott_fm, rows - 32, S, T(vd), None, None, rgb2)
+
+
+def test_grad_weight_fm_multi_equals_the_single_problem_launches(M):
+    """mip360_grad_weight_fm_multi (the PropMLP's four weight-gradient problems in one launch, 48 row slices each) against
+    mip360_grad_weight_fm per problem (its own slice count) and float64: kernel and bias gradients."""
+    import ctypes as C
+    rs = np.random.RandomState(31)
+    m, W = 6144, 256                                       # 192 chunks of 32 rows: 48 slices of 4
+    n_ins = [512, 256, 256, 256]
+    hs = [round_bf16(rs.randn(m, k).astype(np.float32)) for k in n_ins]
+    dzs = [round_bf16((rs.randn(m, W) * 0.1).astype(np.float32)) for _ in n_ins]
+    h_fm = [M.to_fm(bf(h)) for h in hs]
+    dz_fm = [M.to_fm(bf(d)) for d in dzs]
+    ks = 48
+    sizes = [ks * (k * W + W) for k in n_ins]
+    slabs = [torch.empty(sz, device=dev()) for sz in sizes]
+    ci = lambda v: (C.c_int * 4)(*[int(x) for x in v])
+    cp = lambda ps: (C.c_void_p * 4)(*ps)
+    M._check(M.lib().mip360_grad_weight_fm_multi(M._stream(), 4, m, ks, ci(n_ins), ci([W] * 4), cp([M._p(t) for t in h_fm]), ci(n_ins),
+                                                 cp([M._p(t) for t in dz_fm]), ci([W] * 4), cp([M._p(t) for t in slabs])), 'multi')
+    scratch = [None, None]
+    for i, k in enumerate(n_ins):
+        out, bias = torch.empty(k, W, device=dev()), torch.empty(W, device=dev())
+        M._check(M.lib().mip360_grad_weight_reduce(M._stream(), k, k, W, ks, M._p(slabs[i]), M._p(out), W, 1.0, M._p(bias)), 'reduce')
+        want, want_b = torch.empty(k, W, device=dev()), torch.empty(W, device=dev())
+        M._grad_weight_fm(h_fm[i], 0, k, dz_fm[i], W, m, k, W, want, scratch, want_b)
+        ref = hs[i].astype(np.float64).T @ dzs[i].astype(np.float64)
+        np.testing.assert_allclose(N(out), ref, rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(N(out), N(want), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(N(bias), dzs[i].astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(N(bias), N(want_b), rtol=1e-4, atol=1e-3)
+    with pytest.raises(M.Mip360Error):
+        M._check(M.lib().mip360_grad_weight_fm_multi(M._stream(), 4, m, 50, ci(n_ins), ci([W] * 4), cp([M._p(t) for t in h_fm]), ci(n_ins),
+                                                     cp([M._p(t) for t in dz_fm]), ci([W] * 4), cp([M._p(t) for t in slabs])), 'multi')
