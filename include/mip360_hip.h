@@ -169,7 +169,7 @@ int mip360_linear_fm(void* stream, int m, int n, int k, const void* a_fm, int ld
                      const float* bias, int act, void* c_fm, int ldc, void* mask);
 /* n <= 8 weight-gradient problems over the same m rows in ONE launch (the PropMLP's four layers): slabs[p] receives what
  * mip360_grad_weight_fm(grad_kernel = NULL) writes for problem p with this ksplit (ksplit x n_in[p] x n_out[p] floats, then
- * ksplit x n_out[p] bias slabs; ksplit a multiple of 8); sum them with mip360_grad_weight_reduce.  With the workgroups of all
+ * ksplit x n_out[p] bias slabs); sum them with mip360_grad_weight_reduce.  With the workgroups of all
  * problems on the chip together, ksplit ~ 256 / (total 256 x 256 tiles) fills it: a fraction of the split-K slab traffic. */
 int mip360_grad_weight_fm_multi(void* stream, int n, int m, int ksplit, const int* n_in, const int* n_out, const void* const* h_fm,
                                 const int* ldh, const void* const* dz_fm, const int* lddz, float* const* slabs);

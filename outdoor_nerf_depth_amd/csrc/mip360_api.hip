@@ -274,8 +274,7 @@ int mip360_grad_weight_fm_multi(void* stream, int n, int m, int ksplit, const in
                                 const int* ldh, const void* const* dz_fm, const int* lddz, float* const* slabs) {
   REQUIRE(n_in && n_out && h_fm && ldh && dz_fm && lddz && slabs, "pointers");
   REQUIRE(mip360_launch_grad_weight_fm_multi((hipStream_t)stream, n, m, ksplit, n_in, n_out, h_fm, ldh, dz_fm, lddz, slabs) == 0,
-          "1 <= n <= 8 problems, m a multiple of 32, ksplit a multiple of 8 (<= 256), n_in / n_out multiples of 256, leading dimensions "
-          "multiples of 16");
+          "1 <= n <= 8 problems, m a multiple of 32, 1 <= ksplit <= 256, n_in / n_out multiples of 256, leading dimensions multiples of 16");
   return check_launch("grad_weight_fm_multi");
 }
 

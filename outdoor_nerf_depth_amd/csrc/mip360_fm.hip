@@ -377,23 +377,14 @@ __device__ __forceinline__ bf16x8 tr_frag_fm(uint32_t off) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// (vblock: the workgroup's index among the problem's tiles x slices -- blockIdx.x for the single-problem launch)
+// (slice, b: the workgroup's row slice and its tile among the problem's (I / 256) x (O / 256))
 template <bool PP>
-__device__ __forceinline__ void grad_weight_fm_body(const int vblock, int M, int I, int O, const char* __restrict__ H, int ldh,
+__device__ __forceinline__ void grad_weight_fm_body(const int slice, const int b, int M, int I, int O, const char* __restrict__ H, int ldh,
                                                     const char* __restrict__ dZ, int lddz, int ksplit,
                                                     float* __restrict__ slabs, int ldc, float* __restrict__ bias_slabs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 2, wo = wave & 3;
-  const int tiles_o = O / 256, tiles = (I / 256) * tiles_o;
-  int slice, b;                                         // all tiles of a row slice on one XCD (they share its rows through that L2)
-  if ((ksplit & 7) == 0) {
-    const int xcd = vblock & 7, id = vblock >> 3, per_xcd = ksplit >> 3;
-    slice = xcd * per_xcd + id / tiles;
-    b = id % tiles;
-  } else {
-    slice = vblock / tiles;
-    b = vblock - slice * tiles;
-  }
+  const int tiles_o = O / 256;
   const int ti = b / tiles_o, to = b - ti * tiles_o;
   const int i0 = ti * 256, o0 = to * 256;
   const int64_t chunks_total = M / 32;
@@ -540,7 +531,17 @@ template <bool PP>
 __global__ __launch_bounds__(512) void grad_weight_fm_kernel(int M, int I, int O, const char* __restrict__ H, int ldh,
                                                              const char* __restrict__ dZ, int lddz, int ksplit,
                                                              float* __restrict__ slabs, int ldc, float* __restrict__ bias_slabs) {
-  grad_weight_fm_body<PP>((int)blockIdx.x, M, I, O, H, ldh, dZ, lddz, ksplit, slabs, ldc, bias_slabs);
+  const int tiles = (I / 256) * (O / 256);
+  int slice, b;                                         // all tiles of a row slice on one XCD (they share its rows through that L2)
+  if ((ksplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, id = blockIdx.x >> 3, per_xcd = ksplit >> 3;
+    slice = xcd * per_xcd + id / tiles;
+    b = id % tiles;
+  } else {
+    slice = blockIdx.x / tiles;
+    b = blockIdx.x - slice * tiles;
+  }
+  grad_weight_fm_body<PP>(slice, b, M, I, O, H, ldh, dZ, lddz, ksplit, slabs, ldc, bias_slabs);
 }
 // Several weight-gradient problems over the same M rows in ONE launch (the four layers of the PropMLP: one tile each, two for the
 // first): with the workgroups of all of them on the chip together a problem gets along with ksplit ~ 256 / (total tiles) row slices
@@ -548,15 +549,20 @@ __global__ __launch_bounds__(512) void grad_weight_fm_kernel(int M, int I, int O
 struct GwMulti {
   static constexpr int MAXP = 8;
   int n, M, ksplit;
-  int I[MAXP], O[MAXP], ldh[MAXP], lddz[MAXP], first_block[MAXP + 1];
+  int I[MAXP], O[MAXP], ldh[MAXP], lddz[MAXP], first_tile[MAXP + 1];       // first_tile[n] = tiles of all problems
   const char* H[MAXP]; const char* dZ[MAXP];
   float* slabs[MAXP]; float* bias_slabs[MAXP];
 };
+// Workgroup order: XCD-major (the hardware deals workgroup g to XCD g % 8), inside it (slice, problem, tile) with the tile running
+// fastest -- the tiles of a problem's row slice sit on one XCD and share its rows through that L2.
 template <bool PP>
 __global__ __launch_bounds__(512) void grad_weight_fm_multi_kernel(const GwMulti a) {
+  const int T = a.first_tile[a.n];
+  const int v = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int slice = v / T, r = v - slice * T;
   int p = 0;
-  while (p + 1 < a.n && (int)blockIdx.x >= a.first_block[p + 1]) ++p;
-  grad_weight_fm_body<PP>((int)blockIdx.x - a.first_block[p], a.M, a.I[p], a.O[p], a.H[p], a.ldh[p], a.dZ[p], a.lddz[p], a.ksplit,
+  while (p + 1 < a.n && r >= a.first_tile[p + 1]) ++p;
+  grad_weight_fm_body<PP>(slice, r - a.first_tile[p], a.M, a.I[p], a.O[p], a.H[p], a.ldh[p], a.dZ[p], a.lddz[p], a.ksplit,
                           a.slabs[p], a.O[p], a.bias_slabs[p]);
 }
 
@@ -805,22 +811,23 @@ int mip360_launch_grad_weight_fm(hipStream_t st, int M, int I, int O, const void
 }
 
 // n problems (I[p], O[p] multiples of 256) over the same M rows; slabs[p]: ksplit x I[p] x O[p] floats followed by ksplit x O[p]
-// bias slabs (as mip360_grad_weight_fm lays them out); ksplit a multiple of 8 (tile blocks of a problem start on XCD 0)
+// bias slabs (as mip360_grad_weight_fm lays them out)
 int mip360_launch_grad_weight_fm_multi(hipStream_t st, int n, int M, int ksplit, const int* I, const int* O, const void* const* H, const int* ldh,
                                        const void* const* dZ, const int* lddz, float* const* slabs) {
   using namespace mip360fm;
-  if (n < 1 || n > GwMulti::MAXP || M <= 0 || M % 32 || ksplit < 8 || ksplit % 8 || ksplit > 256) return 1;
+  if (n < 1 || n > GwMulti::MAXP || M <= 0 || M % 32 || ksplit < 1 || ksplit > 256) return 1;
   GwMulti a{};
   a.n = n; a.M = M; a.ksplit = ksplit;
-  int blocks = 0;
+  int tiles = 0;
   for (int p = 0; p < n; ++p) {
     if (I[p] <= 0 || O[p] <= 0 || I[p] % 256 || O[p] % 256 || ldh[p] % 16 || lddz[p] % 16 || ldh[p] < I[p] || lddz[p] < O[p] || !H[p] || !dZ[p] || !slabs[p]) return 1;
     a.I[p] = I[p]; a.O[p] = O[p]; a.ldh[p] = ldh[p]; a.lddz[p] = lddz[p]; a.H[p] = (const char*)H[p]; a.dZ[p] = (const char*)dZ[p];
     a.slabs[p] = slabs[p]; a.bias_slabs[p] = slabs[p] + (size_t)ksplit * I[p] * O[p];
-    a.first_block[p] = blocks;
-    blocks += (I[p] / 256) * (O[p] / 256) * ksplit;
+    a.first_tile[p] = tiles;
+    tiles += (I[p] / 256) * (O[p] / 256);
   }
-  a.first_block[n] = blocks;
+  a.first_tile[n] = tiles;
+  const int blocks = tiles * ksplit;
   static std::atomic<uint64_t> attr_done{0};
   if (first_launch_on_this_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)grad_weight_fm_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GNBUF * GCHUNK);

@@ -291,6 +291,8 @@ def prop_mlp_fm(enc_buf, x_col0, ldx, rows, w_fm, ldw, bias, wd, bd, density, h=
                                     _p(wd), _p(bd), DENSITY_BIAS, _p(density)), 'mip360_prop_mlp_fm')
 
 
+# MIP360_NO_DEFER_DW=1: the NerfMLP's trunk weight gradients stay one launch per layer between the dX layers (A/B runs)
+USE_DEFER_DW = os.environ.get('MIP360_NO_DEFER_DW') is None
 # MIP360_NO_MULTI_DW=1: the PropMLP's four weight-gradient GEMMs stay four launches (A/B runs)
 USE_MULTI_DW = os.environ.get('MIP360_NO_MULTI_DW') is None
 # MIP360_NO_FUSED_VIEW=1 keeps the view branch forward on from_fm + dir_encode + two row-major GEMMs (A/B runs)
@@ -888,6 +890,32 @@ def _grad_weight_fm(h, h_col0, ldh, dz, lddz, m, n_in, n_out, out, scratch, bias
            'mip360_grad_weight_reduce')
 
 
+def _grad_weight_fm_multi(tm, items, rows, scratch):
+    """The weight-gradient GEMMs of several trunk layers as ONE launch + one slab sum per layer (include/mip360_hip.h:
+    mip360_grad_weight_fm_multi).  items: (layer t, x, x_col0, x_ld, x_k, dz) with dz [rows, W] fm.  With all their 256 x 256 tiles
+    on the chip together the layers need ksplit ~ 256 / tiles row slices: 48 for the PropMLP's 5 tiles, 2 for the NerfMLP's 128."""
+    W, G, n = tm.W, tm.grads, len(items)
+    tiles = sum((it[4] // 256) * (W // 256) for it in items)
+    ks = max(1, min(256 // tiles, rows // 32))
+    while ks > 1 and (tiles * ks) % 8:                       # whole XCD rounds (the launch deals workgroups XCD-major)
+        ks -= 1
+    sizes = [ks * (it[4] * W + W) for it in items]
+    if scratch[1] is None or scratch[1].numel() < sum(sizes):
+        scratch[1] = torch.empty(sum(sizes), device=tm.device)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    slabs = [scratch[1][int(offs[j]):int(offs[j + 1])] for j in range(n)]
+    ci = lambda v: (C.c_int * n)(*[int(x) for x in v])
+    cp = lambda ps: (C.c_void_p * n)(*ps)
+    _check(lib().mip360_grad_weight_fm_multi(
+        _stream(), n, rows, ks, ci([it[4] for it in items]), ci([W] * n), cp([_fm_ptr(it[1], it[2]) for it in items]),
+        ci([it[3] for it in items]), cp([_p(it[5]) for it in items]), ci([W] * n), cp([_p(t) for t in slabs])),
+        'mip360_grad_weight_fm_multi')
+    for j, it in enumerate(items):
+        t = it[0]
+        _check(lib().mip360_grad_weight_reduce(_stream(), tm.shapes[t][0], it[4], W, ks, _p(slabs[j]), _p(tm.kernel(t, G)), W, 1.0,
+                                               _p(tm.bias(t, G))), 'mip360_grad_weight_reduce')
+
+
 def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
     """mlp_backward on the fm tensors mlp_forward_train_fm saved."""
     W, D = tm.W, tm.depth
@@ -912,24 +940,7 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
             dzs = [fm_buffer(rows, W, dev) for _ in range(D - 1)] + [dz]
             prop_mlp_bwd_fm(rows, d_raw, tm.w[D], saved['masks'], [None] + [tm.wb_fm[i] for i in range(1, D)], [0] + [W] * (D - 1), dzs)
             if USE_MULTI_DW:
-                # the four weight-gradient GEMMs as one launch (5 tiles x 48 row slices instead of 4 launches of 256 / 512 slices: a
-                # fifth of the slab traffic), then the four slab sums
-                ks = 48
-                n_ins = [saved['inputs'][i][3] for i in range(D)]
-                sizes = [ks * (n_ins[i] * W + W) for i in range(D)]
-                if scratch[1] is None or scratch[1].numel() < sum(sizes):
-                    scratch[1] = torch.empty(sum(sizes), device=dev)
-                offs = np.concatenate([[0], np.cumsum(sizes)])
-                slabs = [scratch[1][int(offs[i]):int(offs[i + 1])] for i in range(D)]
-                ci = lambda v: (C.c_int * D)(*[int(x) for x in v])
-                cp = lambda ps: (C.c_void_p * D)(*ps)
-                _check(lib().mip360_grad_weight_fm_multi(
-                    _stream(), D, rows, ks, ci(n_ins), ci([W] * D), cp([_fm_ptr(saved['inputs'][i][0], saved['inputs'][i][1]) for i in range(D)]),
-                    ci([saved['inputs'][i][2] for i in range(D)]), cp([_p(dzs[i]) for i in range(D)]), ci([W] * D),
-                    cp([_p(t) for t in slabs])), 'mip360_grad_weight_fm_multi')
-                for i in range(D):
-                    _check(lib().mip360_grad_weight_reduce(_stream(), tm.shapes[i][0], n_ins[i], W, ks, _p(slabs[i]), _p(tm.kernel(i, G)), W,
-                                                           1.0, _p(tm.bias(i, G))), 'mip360_grad_weight_reduce')
+                _grad_weight_fm_multi(tm, [(i,) + tuple(saved['inputs'][i]) + (dzs[i],) for i in range(D)], rows, scratch)
                 return
             for i in reversed(range(D)):
                 x, x_col0, x_ld, x_k = saved['inputs'][i]
@@ -961,13 +972,22 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
                                                _p(scratch[0]), _p(tm.kernel(D, G)), 1.0, _p(tm.bias(D, G))), 'mip360_grad_weight_col_fm')
         # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
         linear_fm(heads_fm, tm.wb_fm['heads'], None, 2, rows, W, tm.head_k, dz, saved['masks'][D - 1])
+    defer = USE_DEFER_DW and D <= 8 and all(saved['inputs'][i][3] % 256 == 0 for i in range(D))
+    pending = []
     for i in reversed(range(D)):
         x, x_col0, x_ld, x_k = saved['inputs'][i]
-        _grad_weight_fm(x, x_col0, x_ld, dz, W, rows, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G), rows_out=tm.shapes[i][0])
+        if defer:
+            pending.append((i, x, x_col0, x_ld, x_k, dz))
+        else:
+            _grad_weight_fm(x, x_col0, x_ld, dz, W, rows, x_k, W, tm.kernel(i, G), scratch, tm.bias(i, G), rows_out=tm.shapes[i][0])
         if i > 0:
             nxt = fm_buffer(rows, W, dev)
             linear_fm(dz, tm.wb_fm[i], None, 2, rows, W, W, nxt, saved['masks'][i - 1])
             dz = nxt
+    if defer:
+        # every trunk layer's weight gradient in ONE launch behind the dX chain (all dZ_l kept: 8 x 268 MB): 128 tiles x 2 row
+        # slices fill the chip, where a layer alone needs 16 slices -- an eighth of the split-K slab traffic, no launch boundaries
+        _grad_weight_fm_multi(tm, pending, rows, scratch)
 
 
 def mlp_backward(tm, saved, rows, g_density, g_rgb, scratch, side_stream=None):

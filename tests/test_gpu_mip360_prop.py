@@ -234,5 +234,5 @@ def test_grad_weight_fm_multi_equals_the_single_problem_launches(M):
         np.testing.assert_allclose(N(bias), dzs[i].astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(N(bias), N(want_b), rtol=1e-4, atol=1e-3)
     with pytest.raises(M.Mip360Error):
-        M._check(M.lib().mip360_grad_weight_fm_multi(M._stream(), 4, m, 50, ci(n_ins), ci([W] * 4), cp([M._p(t) for t in h_fm]), ci(n_ins),
+        M._check(M.lib().mip360_grad_weight_fm_multi(M._stream(), 4, m, 300, ci(n_ins), ci([W] * 4), cp([M._p(t) for t in h_fm]), ci(n_ins),
                                                      cp([M._p(t) for t in dz_fm]), ci([W] * 4), cp([M._p(t) for t in slabs])), 'multi')
