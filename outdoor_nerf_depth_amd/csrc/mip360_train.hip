@@ -464,13 +464,20 @@ __global__ void head_backward_kernel(int64_t rows, const float* __restrict__ den
 }
 
 // deterministic sum of squares: partial[b] per block, then block 0 style reduce by a second launch
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ partial) {
-  __shared__ double sh[256];
+// (1024 threads per block and 16-byte loads: with 256 threads the 256 blocks were 4 waves per CU of dependent 4-byte loads -- 52 us
+// for the NerfMLP's 50 MB.  Fixed order: thread-strided double sums, then a tree over the block.)
+__global__ __launch_bounds__(1024) void sumsq_partial_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ partial) {
+  __shared__ double sh[1024];
   double acc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)g[i] * g[i];
+  const int64_t n4 = ((uintptr_t)g & 15) == 0 ? n >> 2 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 1024) {
+    const float4 v = ((const float4*)g)[i];
+    acc += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) acc += (double)g[i] * g[i];
   sh[threadIdx.x] = acc;
   __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
+  for (int d = 512; d > 0; d >>= 1) {
     if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
     __syncthreads();
   }
@@ -478,11 +485,18 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(int64_t n, const flo
 }
 // clip_gradients (train_utils.py:215-236): mult = min(1, max_norm / (eps + ||g||)) over all tensors of ONE MLP;
 // `partials` holds the per-tensor partial sums of that MLP back to back
-__global__ void clip_mult_kernel(int n_partial, const float* __restrict__ partial, float max_norm, float* __restrict__ out) {
-  if (threadIdx.x || blockIdx.x) return;
+__global__ __launch_bounds__(256) void clip_mult_kernel(int n_partial, const float* __restrict__ partial, float max_norm, float* __restrict__ out) {
+  __shared__ double sh[256];
   double acc = 0;
-  for (int i = 0; i < n_partial; ++i) acc += (double)partial[i];
-  const float norm = (float)sqrt(acc);
+  for (int i = threadIdx.x; i < n_partial; i += 256) acc += (double)partial[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  const float norm = (float)sqrt(sh[0]);
   // jnp.minimum(1, max_norm / (eps + norm)) (train_utils.py:228-229) PROPAGATES a NaN norm (fminf would return 1)
   const float ratio = max_norm / (1.1920928955078125e-07f + norm);
   out[0] = max_norm > 0.f ? (ratio != ratio ? ratio : fminf(1.f, ratio)) : 1.f;
@@ -579,10 +593,10 @@ void mip360_launch_head_backward(hipStream_t st, int64_t rows, const float* dens
                      g_rgb, pad, (__bf16*)d_raw, ld_raw, raw_col, raw_zero_to, (__bf16*)d_pre);
 }
 void mip360_launch_sumsq(hipStream_t st, int64_t n, const float* g, float* partial, int nblocks) {
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, g, partial);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblocks), dim3(1024), 0, st, n, g, partial);
 }
 void mip360_launch_clip_mult(hipStream_t st, int n_partial, const float* partial, float max_norm, float* out) {
-  hipLaunchKernelGGL(clip_mult_kernel, dim3(1), dim3(64), 0, st, n_partial, partial, max_norm, out);
+  hipLaunchKernelGGL(clip_mult_kernel, dim3(1), dim3(256), 0, st, n_partial, partial, max_norm, out);
 }
 void mip360_launch_adam(hipStream_t st, int64_t n, float* p, const float* g, float* m, float* v, const float* gmult, float lr,
                         float b1, float b2, float eps, float bc1, float bc2) {
