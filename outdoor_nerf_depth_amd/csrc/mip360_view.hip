@@ -5,10 +5,12 @@
 // Same scheme as mip360_prop.hip: a wave owns 32 rows, lane (row, hi) of v_mfma_f32_32x32x16_bf16 carries the sample as the B
 // operand.  The 16 bottleneck fragments of the wave's rows are 1-KiB blocks of the fm tensor mip360_linear_fm (act 0) wrote,
 // loaded 16 bytes per lane; the two direction fragments come from a per-RAY table [rays, 32] that mip360_dir_encode (S = 1)
-// writes once per step (computing them in the kernel -- 16 libm sines per lane -- cost 256 VGPRs + 1.2 KB of scratch and 180 us).  Both weight matrices (72 + 8 KiB as fm blocks) stay in LDS for the whole launch; workgroups are
-// persistent over 256-row tiles.  For the backward pass the kernel writes what the row-major launches wrote -- view_in
-// [rows, 288] and h [rows, 128] in bf16, 8 bytes per lane and half fragment (the two lanes of a row complete 16-byte pieces;
-// L2 assembles the rows) -- or nothing but rgb (inference).
+// writes once per step (computing them in the kernel -- 16 libm sines per lane -- cost registers and time for values that are
+// the same for all samples of a ray).  Both weight matrices (72 + 8 KiB as fm blocks) stay in LDS for the whole launch;
+// workgroups are persistent over 256-row tiles and issue the next tile's operand loads before the current tile's MFMAs.  For the
+// backward pass the kernel writes what the row-major launches wrote -- view_in [rows, 288] and h [rows, 128] in bf16, 8 bytes
+// per lane and half fragment (the two lanes of a row complete 16-byte pieces; L2 assembles the rows) -- or nothing but rgb
+// (inference).
 #include "probe_env.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
