@@ -738,7 +738,10 @@ def _grad_weight(h, dz, n_in, n_out, out, scratch, bias_out=None, rows_out=None,
     ld = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
     tile = lib().mip360_grad_weight_tile(m, n_in, n_out, ld(h), ld(dz))
     tiles = ((n_in + tile - 1) // tile) * ((n_out + tile - 1) // tile)
-    ksplit = int(max(1, min(256 if tile == 256 else 64, (256 + tiles - 1) // tiles, (m + 31) // 32)))
+    # (small outputs -- the view branch's [128, 3] and [288, 128] -- have small slabs: as many row slices as fill the chip;
+    #  tools/probes/mip360_view_dw_ksplit.py: 48 -> 30 us and 50 -> 33 us at 131 072 rows from 64 to 256 / 85 slices)
+    cap = 256 if (tile == 256 or n_in * n_out <= 288 * 128) else 64
+    ksplit = int(max(1, min(cap, (256 + tiles - 1) // tiles, (m + 31) // 32)))
     if ksplit >= 8 or m >= 8 * 256:
         ksplit = max(8, (ksplit // 8) * 8)            # multiples of 8: one or more whole row slices per XCD
     if n_out == 1 and n_in % 8 == 0 and m >= 256 * 64:
