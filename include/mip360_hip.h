@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MIP360_ABI_VERSION 7
+#define MIP360_ABI_VERSION 8
 #define MIP360_OK 0
 #define MIP360_ERR_ARG 1
 #define MIP360_ERR_HIP 2
@@ -209,6 +209,15 @@ int mip360_prop_mlp_bwd_fm(void* stream, int rows, const void* z_bf16, const voi
 int mip360_view_branch_fm(void* stream, int rows, int n_samples, const void* bott_fm, const void* dir_table_bf16, const void* w1_fm, int ldw1,
                           const float* b1, const void* w2_fm, int ldw2, const float* b2, float rgb_padding, void* view_in_bf16,
                           int ld_view, void* h_bf16, int ld_h, float* rgb);
+/* The heads' backward up to the bottleneck as ONE launch: = mip360_head_backward + mip360_linear_bf16 act 4 (d_hz = relu'(h) .
+ * (d_pre W_rgb)) + mip360_linear_bf16 (d_bott = d_hz W_view[:, :256]) + mip360_to_fm.  density / g_density [rows], rgb / g_rgb
+ * [rows, 3]; h_bf16 [rows, ld_h] the saved ReLU output; wb_rgb_fm fm [128, ld_wb_rgb >= 32] and wb_view_fm fm [>= 256, ld_wb_view >=
+ * 128]: the bwd_fm copies of mip360_pack_weight_fm of the two view-branch kernels.  Written: d_pre_bf16 [rows, 32] and d_hz_bf16
+ * [rows, ld_dhz] row-major (operands of the two mip360_grad_weight_bf16 launches of the branch), heads_fm [rows, 320] fm =
+ * [d_bott (256) | d raw density | 0 ...] (operand of the heads' weight gradients and of the trunk's first masked dX). */
+int mip360_view_branch_bwd_fm(void* stream, int rows, const float* density, const float* g_density, const float* rgb, const float* g_rgb,
+                              float rgb_padding, const void* h_bf16, int ld_h, const void* wb_rgb_fm, int ld_wb_rgb, const void* wb_view_fm,
+                              int ld_wb_view, void* d_pre_bf16, void* d_hz_bf16, int ld_dhz, void* heads_fm);
 /* c_fm[m][n] = bf16(z[m] * w[n]) where bit (m, n) of `mask` is set (z bf16 [m], w bf16 [n]): mip360_linear_fm act 2 for a
  * one-column operand -- the PropMLP's dZ of the last trunk layer (its only head is the density column).
  * mip360_grad_weight_col_fm with lddz == 1 reads z from such a plain vector. */

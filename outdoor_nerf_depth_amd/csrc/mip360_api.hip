@@ -66,6 +66,9 @@ int mip360_launch_prop_mlp_bwd_fm(hipStream_t st, int rows, const void* z, const
 int mip360_launch_view_branch_fm(hipStream_t st, int rows, int n_samples, const void* bott_fm, const void* dir_table, const void* w1_fm,
                                  int ldw1, const float* b1, const void* w2_fm, int ldw2, const float* b2, float rgb_padding,
                                  void* view_in, int ld_view, void* h, int ld_h, float* rgb);
+int mip360_launch_view_branch_bwd_fm(hipStream_t st, int rows, const float* density, const float* g_density, const float* rgb,
+                                     const float* g_rgb, float rgb_padding, const void* h, int ld_h, const void* wb3_fm, int ldwb3,
+                                     const void* wb2_fm, int ldwb2, void* d_pre, void* d_hz, int ld_dhz, void* heads_fm);
 void mip360_launch_dir_encode(hipStream_t st, int n, int S, const float* viewdirs, void* out, int ld, int col0, int width);
 
 namespace {
@@ -314,6 +317,17 @@ int mip360_view_branch_fm(void* stream, int rows, int n_samples, const void* bot
                    "multiples of 4, non-null operands");
   REQUIRE(rc == 0, "hipFuncSetAttribute");
   return check_launch("view_branch_fm");
+}
+
+int mip360_view_branch_bwd_fm(void* stream, int rows, const float* density, const float* g_density, const float* rgb, const float* g_rgb,
+                              float rgb_padding, const void* h_bf16, int ld_h, const void* wb_rgb_fm, int ld_wb_rgb, const void* wb_view_fm,
+                              int ld_wb_view, void* d_pre_bf16, void* d_hz_bf16, int ld_dhz, void* heads_fm) {
+  const int rc = mip360_launch_view_branch_bwd_fm((hipStream_t)stream, rows, density, g_density, rgb, g_rgb, rgb_padding, h_bf16, ld_h,
+                                                  wb_rgb_fm, ld_wb_rgb, wb_view_fm, ld_wb_view, d_pre_bf16, d_hz_bf16, ld_dhz, heads_fm);
+  REQUIRE(rc != 1, "rows a multiple of 256, non-null operands, ld_h / ld_dhz >= 128 multiples of 4, ld_wb_rgb >= 32 / ld_wb_view >= 128 "
+                   "multiples of 16");
+  REQUIRE(rc == 0, "hipFuncSetAttribute");
+  return check_launch("view_branch_bwd_fm");
 }
 
 int mip360_grad_weight_col_fm(void* stream, int m, int n_in, const void* h_fm, int ldh, const void* dz_fm, int lddz, int zcol,

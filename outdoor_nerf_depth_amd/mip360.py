@@ -19,7 +19,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MIP360_HIP_LIB') or os.path.join(_HERE, 'libmip360_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 N_BASIS, IPE_DIM, IPE_LD = 21, 504, 512
 _fp = C.c_void_p
 _fpp = C.POINTER(C.c_void_p)
@@ -65,6 +65,8 @@ SYMBOLS = {
     'mip360_prop_mlp_fm': (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fpp, C.POINTER(C.c_int), _fpp, _fpp, _fpp, _fp, _fp,
                                      C.c_float, _fp]),
     'mip360_prop_mlp_bwd_fm': (C.c_int, [_fp, C.c_int, _fp, _fp, _fpp, _fpp, C.POINTER(C.c_int), _fpp]),
+    'mip360_view_branch_bwd_fm': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, C.c_float, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp,
+                                            C.c_int, _fp]),
     'mip360_view_branch_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_float, _fp, C.c_int,
                                         _fp, C.c_int, _fp]),
     'mip360_pack_weight_fm': (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int]),
@@ -662,6 +664,8 @@ class TrainableMLP(object):
                 self.w_fm[D + 1] = fmz(BOTTLENECK, W)
                 self.w_fm[D + 2] = fmz(VIEW_WIDTH, BOTTLENECK + DIR_LD)       # the view branch as one launch (mip360_view_branch_fm)
                 self.w_fm[D + 3] = fmz(32, VIEW_WIDTH)                        # (3 live rows)
+                self.wb_fm[D + 2] = fmz(BOTTLENECK + DIR_LD, VIEW_WIDTH)      # ... and its backward (mip360_view_branch_bwd_fm)
+                self.wb_fm[D + 3] = fmz(VIEW_WIDTH, 32)
         self.repack()
 
     def kernel(self, t, buf=None):
@@ -707,6 +711,8 @@ class TrainableMLP(object):
                     bwd_col0 = BOTTLENECK if not self.cfg['disable_rgb'] else 0
                 elif t == D + 1:
                     bwd_fm, ld_bwd_fm, bwd_rows = self.wb_fm['heads'], self.head_k, self.W
+                elif t in (D + 2, D + 3) and t in self.wb_fm:
+                    bwd_fm, ld_bwd_fm, bwd_rows = self.wb_fm[t], self.wb[t].shape[1], self.wb[t].shape[0]
             fwd = self.w[t]
             if skip_rm and (t < D or t == D + 1):                # (the density head's vector and the view branch stay current)
                 fwd, bwd = None, None
@@ -952,20 +958,31 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
         _check(lib().mip360_outer_masked_fm(_stream(), rows, W, _p(d_raw), _p(tm.w[D]), _p(saved['masks'][D - 1]), _p(dz), W),
                'mip360_outer_masked_fm')
     else:
-        heads = bf(tm.head_k)                                        # row-major: written by the head / view-branch kernels
         raw_col = BOTTLENECK
         d_pre = bf(32)
-        _check(lib().mip360_head_backward(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)),
-                                          _p(saved.get('rgb')), _p(_f32(g_rgb).reshape(-1, 3)), RGB_PADDING,
-                                          _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
-        h, view_in = saved['h'], saved['view_in']
-        _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G))
         d_hz = bf(VIEW_WIDTH)
-        linear(d_pre, tm.wb[D + 3], None, act=4, out_bf16=d_hz, m=rows, n=VIEW_WIDTH, k=32, aux=h)
-        _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, tm.kernel(D + 2, G), scratch, tm.bias(D + 2, G),
-                     rows_out=BOTTLENECK + DIR_DIM)
-        linear(d_hz, tm.wb[D + 2], None, act=0, out_bf16=heads, m=rows, n=BOTTLENECK, k=VIEW_WIDTH)     # -> heads[:, :256]
-        heads_fm = to_fm(heads)                                      # [rows, head_k]
+        h, view_in = saved['h'], saved['view_in']
+        if fused_view_ok(tm, D, rows) and (D + 3) in tm.wb_fm and tm.head_k == BOTTLENECK + 64:
+            # head gradients, the two small dX layers and the conversion to fm in one launch (mip360_view_branch_bwd_fm)
+            heads_fm = fm_buffer(rows, tm.head_k, dev)
+            _check(lib().mip360_view_branch_bwd_fm(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)), _p(saved['rgb']),
+                                                   _p(_f32(g_rgb).reshape(-1, 3)), RGB_PADDING, _p(h), h.stride(0), _p(tm.wb_fm[D + 3]), 32,
+                                                   _p(tm.wb_fm[D + 2]), VIEW_WIDTH, _p(d_pre), _p(d_hz), d_hz.stride(0), _p(heads_fm)),
+                   'mip360_view_branch_bwd_fm')
+            _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G))
+            _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, tm.kernel(D + 2, G), scratch, tm.bias(D + 2, G),
+                         rows_out=BOTTLENECK + DIR_DIM)
+        else:
+            heads = bf(tm.head_k)                                    # row-major: written by the head / view-branch kernels
+            _check(lib().mip360_head_backward(_stream(), rows, _p(saved['density']), _p(_f32(g_density).reshape(-1)),
+                                              _p(saved.get('rgb')), _p(_f32(g_rgb).reshape(-1, 3)), RGB_PADDING,
+                                              _p(heads), tm.head_k, raw_col, tm.head_k, _p(d_pre)), 'mip360_head_backward')
+            _grad_weight(h, d_pre, VIEW_WIDTH, 3, tm.kernel(D + 3, G), scratch, tm.bias(D + 3, G))
+            linear(d_pre, tm.wb[D + 3], None, act=4, out_bf16=d_hz, m=rows, n=VIEW_WIDTH, k=32, aux=h)
+            _grad_weight(view_in, d_hz, BOTTLENECK + DIR_LD, VIEW_WIDTH, tm.kernel(D + 2, G), scratch, tm.bias(D + 2, G),
+                         rows_out=BOTTLENECK + DIR_DIM)
+            linear(d_hz, tm.wb[D + 2], None, act=0, out_bf16=heads, m=rows, n=BOTTLENECK, k=VIEW_WIDTH)     # -> heads[:, :256]
+            heads_fm = to_fm(heads)                                  # [rows, head_k]
         _grad_weight_fm(trunk, t_col0, t_ld, heads_fm, tm.head_k, rows, trunk_k, BOTTLENECK, tm.kernel(D + 1, G), scratch,
                         tm.bias(D + 1, G))
         if scratch[0].numel() < ks * (trunk_k + 1):

@@ -236,3 +236,44 @@ def test_grad_weight_fm_multi_equals_the_single_problem_launches(M):
     with pytest.raises(M.Mip360Error):
         M._check(M.lib().mip360_grad_weight_fm_multi(M._stream(), 4, m, 300, ci(n_ins), ci([W] * 4), cp([M._p(t) for t in h_fm]), ci(n_ins),
                                                      cp([M._p(t) for t in dz_fm]), ci([W] * 4), cp([M._p(t) for t in slabs])), 'multi')
+
+
+def test_view_branch_bwd_fm_equals_the_launches_it_replaces(M):
+    """mip360_view_branch_bwd_fm against mip360_head_backward + mip360_linear_bf16 act 4 + mip360_linear_bf16 + mip360_to_fm: d_pre and
+    the d-raw-density column bit for bit (same per-row arithmetic), d_hz / d_bott up to the summation order of 3 / 128 products."""
+    rs = np.random.RandomState(23)
+    rows = 2048
+    density = (rs.rand(rows) * 3).astype(np.float32)
+    g_density = (rs.randn(rows) * 0.01).astype(np.float32)
+    rgb = rs.rand(rows, 3).astype(np.float32)
+    g_rgb = (rs.randn(rows, 3) * 0.01).astype(np.float32)
+    h = np.maximum(round_bf16(rs.randn(rows, 128).astype(np.float32)), 0)
+    wb3 = round_bf16(np.concatenate([(rs.randn(128, 3) / 11).astype(np.float32), np.zeros((128, 29), np.float32)], 1))     # [in 128, out 3 -> 32]
+    wb2 = round_bf16((rs.randn(288, 128) / 17).astype(np.float32))                                                           # [in 288, out 128]
+    head_k = 320
+    t_den, t_gden, t_rgb, t_grgb, t_h = T(density), T(g_density), T(rgb), T(g_rgb), bf(h)      # (kept alive across the launches)
+    wb3_fm, wb2_fm, t_wb3, t_wb2 = M.to_fm(bf(wb3)), M.to_fm(bf(wb2)), bf(wb3), bf(wb2)
+    d_pre = torch.empty(rows, 32, dtype=torch.bfloat16, device=dev())
+    d_hz = torch.empty(rows, 128, dtype=torch.bfloat16, device=dev())
+    heads_fm = M.fm_buffer(rows, head_k, dev())
+    M._check(M.lib().mip360_view_branch_bwd_fm(M._stream(), rows, M._p(t_den), M._p(t_gden), M._p(t_rgb), M._p(t_grgb), M.RGB_PADDING,
+                                               M._p(t_h), 128, M._p(wb3_fm), 32, M._p(wb2_fm), 128, M._p(d_pre), M._p(d_hz),
+                                               128, M._p(heads_fm)), 'view_branch_bwd_fm')
+    # the launches it replaces
+    heads = torch.empty(rows, head_k, dtype=torch.bfloat16, device=dev())
+    want_pre = torch.empty(rows, 32, dtype=torch.bfloat16, device=dev())
+    M._check(M.lib().mip360_head_backward(M._stream(), rows, M._p(t_den), M._p(t_gden), M._p(t_rgb), M._p(t_grgb), M.RGB_PADDING,
+                                          M._p(heads), head_k, 256, head_k, M._p(want_pre)), 'head_backward')
+    want_hz = torch.empty(rows, 128, dtype=torch.bfloat16, device=dev())
+    M.linear(want_pre, t_wb3, None, act=4, out_bf16=want_hz, m=rows, n=128, k=32, aux=t_h)
+    M.linear(want_hz, t_wb2, None, act=0, out_bf16=heads, m=rows, n=256, k=128)
+    np.testing.assert_array_equal(N(d_pre), N(want_pre))
+    gz, wz = N(d_hz), N(want_hz)
+    assert ((gz == 0) == (h == 0) | (gz == 0)).all() and (gz[h == 0] == 0).all()
+    np.testing.assert_allclose(gz, wz, rtol=2 ** -7, atol=1e-7)
+    got = N(M.from_fm(heads_fm, rows, head_k))
+    want = N(heads)
+    np.testing.assert_array_equal(got[:, 256:], want[:, 256:])                    # d raw density, then zeros
+    np.testing.assert_allclose(got[:, :256], want[:, :256], rtol=2 ** -6, atol=2e-6)
+    ref = (gz.astype(np.float64) @ wb2[:256].astype(np.float64).T)
+    np.testing.assert_allclose(got[:, :256], ref, rtol=2 ** -7, atol=1e-6)
