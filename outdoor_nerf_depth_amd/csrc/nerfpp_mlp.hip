@@ -45,6 +45,8 @@ namespace nerfpp { namespace probe {
 constexpr int DBG = 0;                 // component-removal bits (probes only)
 constexpr bool NO_DMA = false, NO_MFMA = false;
 constexpr int LDS_PREFETCH = 4;        // weight fragments in flight ahead of the MFMA that consumes them
+constexpr int LDS_PREFETCH_SPLIT = 4;  // two-plane precisions: two-plane weight fragments in flight ahead of their 3 (2) MFMAs
+constexpr int CHAIN_GROUP = 4;         // two-plane precisions: out-blocks whose dependent MFMA chains are interleaved (1 = one after the other)
 constexpr int HOOK_ORDER = 1;          // saves issued after a block's MFMAs by every wave
 constexpr int WAVES_P1 = 8;            // waves per workgroup of the bf16 kernels (256-sample tiles)
 constexpr int LOADER_SLEEP = 0;        // (probes: idle cycles / 64 added to the loader wave per weight block)
@@ -263,6 +265,32 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
           if (ob % probe::LDS_REUSE == 0) w = *(const bf16x8*)(l + (kl * NOB + ob) * FRAG_BYTES);
           acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b[blk * KPB + kl].v[0], acc[ob], 0, 0, 0);
         }
+      } else if constexpr (P >= 2 && probe::CHAIN_GROUP > 1 && NOB % probe::CHAIN_GROUP == 0) {
+        // split-bf16 / fp16x2w: the 3 (2) MFMAs of an out-block are a dependent chain on its accumulator; the chains of CHAIN_GROUP
+        // out-blocks interleaved keep the order inside each chain (bit-identical) and give every MFMA an independent predecessor
+        constexpr int G = probe::CHAIN_GROUP;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ob += G) {
+          const char* f0 = l + (kl * NOB + ob) * 2 * FRAG_BYTES;
+          bf16x8 wh[G], wl[G];
+#pragma unroll
+          for (int g = 0; g < G; ++g) { wh[g] = *(const bf16x8*)(f0 + 2 * g * FRAG_BYTES); wl[g] = *(const bf16x8*)(f0 + (2 * g + 1) * FRAG_BYTES); }
+          const Frag<P>& bb = b[blk * KPB + kl];
+          if constexpr (P == 2) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[ob + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[g], bb.v[0], acc[ob + g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[ob + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[g], bb.v[1], acc[ob + g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[ob + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[g], bb.v[0], acc[ob + g], 0, 0, 0);
+          } else {
+            const f16x8 bf = __builtin_bit_cast(f16x8, bb.v[0]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[ob + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh[g]), bf, acc[ob + g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[ob + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl[g]), bf, acc[ob + g], 0, 0, 0);
+          }
+        }
       } else {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
@@ -270,6 +298,21 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
       }
     }
     if (probe::HOOK_ORDER == 1 || (probe::HOOK_ORDER == 0 && pipe.wave < 4)) hook(blk);
+    if constexpr (P >= 2 && probe::LDS_PREFETCH_SPLIT > 0) {
+      // split-bf16: a unit = the two planes of a weight fragment (2 LDS reads) and its 3 MFMAs; LDS_PREFETCH_SPLIT units in flight
+      const int live_kl = LIVE - blk * KPB < KPB ? (LIVE - blk * KPB < 0 ? 0 : LIVE - blk * KPB) : KPB;
+      const int D = probe::LDS_PREFETCH_SPLIT, N = NOB * live_kl;
+      if (N < D) continue;
+#pragma unroll
+      for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int i = 0; i < N - D; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, P == 2 ? 3 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) __builtin_amdgcn_sched_group_barrier(0x008, P == 2 ? 3 : 2, 0);
+    }
     if constexpr (P == 1 && probe::LDS_PREFETCH > 0) {
       // shape the block's schedule: LDS_PREFETCH weight fragments in flight ahead of the MFMA
       // that consumes them (LDS latency is ~2-4 MFMA slots; the default schedule keeps only 1-2 ahead)

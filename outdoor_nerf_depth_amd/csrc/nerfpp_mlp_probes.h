@@ -14,6 +14,8 @@
 //   NERFPP_WAVES_P1        waves per workgroup of the bf16 kernels (default 8; 4 = 128-sample tiles)
 //   NERFPP_LDS_REUSE=n     one weight-fragment LDS read per n MFMAs (build with NERFPP_LDS_PREFETCH=0): what would halving the
 //                          LDS reads per MFMA -- 64-row waves -- buy?
+//   NERFPP_CHAIN_GROUP=g   two-plane precisions: the dependent MFMA chains (3 per out-block in split-bf16) of g out-blocks interleaved
+//                          (shipped: 4; 1 = one chain after the other, the round-4 order); NERFPP_LDS_PREFETCH_SPLIT: their prefetch depth
 //   NERFPP_SKIP_H=mask     bit l: the bf16 training forward does not write H_l (its sign words still go out) -- garbage gradients;
 //                          -1: the mask is read per launch from the environment variable NERFPP_SKIP_H_RT (nerfpp_api.hip)
 //   NERFPP_LOADER_SLEEP=n  the loader wave idles 64 n cycles per weight block (does added latency cost time, or only cycles?)
@@ -66,6 +68,14 @@ constexpr int LDS_PREFETCH = NERFPP_LDS_PREFETCH;
 constexpr int HOOK_ORDER = NERFPP_HOOK_ORDER;
 constexpr int WAVES_P1 = NERFPP_WAVES_P1;
 constexpr int LOADER_SLEEP = NERFPP_LOADER_SLEEP;
+#ifndef NERFPP_LDS_PREFETCH_SPLIT
+#define NERFPP_LDS_PREFETCH_SPLIT 4
+#endif
+constexpr int LDS_PREFETCH_SPLIT = NERFPP_LDS_PREFETCH_SPLIT;
+#ifndef NERFPP_CHAIN_GROUP
+#define NERFPP_CHAIN_GROUP 4
+#endif
+constexpr int CHAIN_GROUP = NERFPP_CHAIN_GROUP;
 #ifndef NERFPP_SKEW_INFER
 #define NERFPP_SKEW_INFER 0
 #endif
