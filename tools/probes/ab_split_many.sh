@@ -2,7 +2,7 @@
 # alternate several library builds (names under csrc/build/variants) in the split-bf16 modes + one split-bf16 rendered frame, 2 rounds
 for rep in 1 2; do
 for v in "$@"; do
-  export NERFPP_HIP_LIB=$PWD/outdoor_nerf_depth_amd/csrc/build/variants/$v.so
+  if [ $v = NEW ]; then unset NERFPP_HIP_LIB; else export NERFPP_HIP_LIB=$PWD/outdoor_nerf_depth_amd/csrc/build/variants/$v.so; fi
   t=$(python bench.py --precision both --no_cpu_baseline --large_batch 0 --mip360_rays 0 --render_frames 0 --cli_steps 0 --steps 40 --warmup 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
