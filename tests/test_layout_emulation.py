@@ -293,6 +293,19 @@ def test_mip360_library_loads_and_exports_every_declared_symbol():
     assert b'non-null' in lib.mip360_last_error()
     b = M3.pos_basis_t()
     assert b.shape == (3, 21)
+    # the round-5 fused entry points validate their shapes before anything is launched (no GPU needed to see the message)
+    import ctypes as C
+    four = (C.c_void_p * 4)(8, 8, 8, 8)
+    ld4 = (C.c_int * 4)(512, 256, 256, 256)
+    dummy = C.c_void_p(8)
+    assert lib.mip360_prop_mlp_fm(None, 224, dummy, 768, 256, four, ld4, four, None, None, dummy, dummy, 0.0, dummy) == 1      # rows % 256
+    assert b'multiple of 256' in lib.mip360_last_error()
+    assert lib.mip360_prop_mlp_fm(None, 256, dummy, 768, 512, four, ld4, four, None, None, dummy, dummy, 0.0, dummy) == 1      # window past ldx
+    assert lib.mip360_prop_mlp_bwd_fm(None, 100, dummy, dummy, four, four, ld4, four) == 1
+    assert lib.mip360_view_branch_fm(None, 255, 32, dummy, dummy, dummy, 288, dummy, dummy, 128, dummy, 0.001, None, 0, None, 0, dummy) == 1
+    assert lib.mip360_view_branch_bwd_fm(None, 256, dummy, dummy, dummy, dummy, 0.001, dummy, 64, dummy, 32, dummy, 128, dummy, dummy, 128, dummy) == 1   # ld_h < 128
+    assert lib.mip360_grad_weight_fm_multi(None, 9, 256, 8, ld4, ld4, four, ld4, four, ld4, four) == 1                          # more than 8 problems
+    assert lib.mip360_pack_weights_fm_batch(None, 0, None) == 1
 
 
 def test_fragment_major_saved_tensor_layout_is_a_bijection():
