@@ -646,7 +646,7 @@ def main():
     if world == 1 and args.mip360_rays > 0:
         # BASELINE configs[4], labelled extra: the MipNeRF-360 step on its own library (libmip360_hip.so)
         from outdoor_nerf_depth_amd import mip360
-        out['config5_mip360'] = mip360.benchmark_step(device, args.mip360_rays, steps=5, warmup=2)
+        out["config5_mip360"] = mip360.benchmark_step(device, args.mip360_rays, steps=10, warmup=3)
     elif m360 is not None:
         out['config5_mip360'] = m360
     if world == 1 and args.render_frames > 0:
