@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERFPP_ABI_VERSION 7
+#define NERFPP_ABI_VERSION 8
 
 #define NERFPP_OK 0
 #define NERFPP_ERR_ARG 1          /* bad argument (null pointer, size out of range) */
@@ -172,9 +172,11 @@ int64_t nerfpp_workspace_bytes(int n_rays, int n_samples, int precision, int tra
  *               + 2 * (4 * ((f % 16) / 8) + f % 4)
  * (per 32-row tile and 16-column chunk one 1 KiB block = the register image of the wave that produced it); in split-bf16
  * precision the `lo` plane follows at + plane_bytes.  Rows = n_rays * n_samples in (ray, sample) order.
- * Precisions 1 and 3 do not materialise H0 (tensor 1): the weight-gradient job that needs it recomputes it from X per 32-row
- * chunk (ABI 7); the call returns NERFPP_ERR_UNSUPPORTED for it.  (A precision-2 forward with training == 2 leaves its H0
- * planes unwritten for the same reason: every bf16 backward recomputes H0.) */
+ * Precisions 1 and 3 do not materialise H0 (tensor 1) and dZ7 (tensor 19): the weight-gradient jobs that need them recompute
+ * them per 32-row chunk, H0 from X (ABI 7) and dZ7 from [dS | dG] (ABI 8: no longer allocated either); the call returns
+ * NERFPP_ERR_UNSUPPORTED for them.  (A precision-2 forward with training == 2 leaves its H0 planes unwritten, and a precision-1
+ * backward over a precision-2 workspace its dZ7 planes, for the same reason: every bf16 backward recomputes both -- their
+ * contents are then undefined.) */
 int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, int tensor,
                             int64_t* byte_offset, int32_t* ld, int64_t* plane_bytes);
 
@@ -261,6 +263,12 @@ typedef struct {
   const float* depth;              /* [n]   forward output */
   const float* rgb_gt;             /* [n,3] */
   const float* depth_sup;          /* [n]; NULL for NERFPP_LOSS_RGB_ONLY */
+  /* Bad-camera count for the data-parallel step (ABI 8).  NULL, or a device int32 (the counter nerfpp_sample_coarse*
+   * accumulates in `bad`): `grads` then has NERFPP_LEVEL_PARAMS + 1 elements and the slab-sum launch of this call (or of
+   * nerfpp_level_reduce_grads) writes (float)*bad_count -- unscaled -- into grads[NERFPP_LEVEL_PARAMS], where it rides the
+   * gradient all-reduce and serves as nerfpp_adam_step's skip_if_nonzero on every rank (ddp_train_nerf.py:62-63 raises on
+   * the spot; a caller that reads the count later must keep poisoned gradients out of the parameters on ALL ranks). */
+  const int32_t* bad_count;
 } nerfpp_backward_args;
 
 /* loss.backward() for one level (autograd in the reference)         ddp_train_nerf.py:497 */

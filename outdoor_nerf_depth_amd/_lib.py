@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFPP_HIP_LIB') or os.path.join(_HERE, 'libnerfpp_hip.so')   # override: diagnostic builds
 
 OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 PREC_BF16, PREC_SPLIT_BF16 = 1, 2
 # NERFPP_PREC_FP16X2W: a FORWARD precision (weights hi + lo in fp16, activations rounded to fp16 once, two MFMA passes): an
 # intermediate one -- outputs within 1e-4 of float32 at initialisation, 3-4e-4 on trained weights (tests/test_gpu_round5.py).
@@ -45,7 +45,7 @@ class BackwardArgs(C.Structure):
                [(k, _fp) for k in ('ev_bwd_begin', 'ev_bwd_end', 'ev_dw_begin', 'ev_dw_end', 'params')] + \
                [('defer_reduce', C.c_int32), ('fused_loss', C.c_int32), ('loss_type', C.c_int32),
                 ('lambda_depth', C.c_float), ('kl_sigma', C.c_float)] + \
-               [(k, _fp) for k in ('rgb', 'depth', 'rgb_gt', 'depth_sup')]
+               [(k, _fp) for k in ('rgb', 'depth', 'rgb_gt', 'depth_sup', 'bad_count')]
 
 
 # every symbol include/nerfpp_hip.h declares: name -> (restype, argtypes)

@@ -24,7 +24,7 @@ SOURCES = {
     'nerfpp_api.hip': [],
     'nerfpp_comm.hip': [],                         # RCCL entry points (librccl.so.1 bound with dlopen at first use)
 }
-HEADERS = ['nerfpp_common.h', 'nerfpp_kernels.h', 'probe_env.h', 'nerfpp_mlp_probes.h', os.path.join('..', '..', 'include', 'nerfpp_hip.h')]
+HEADERS = ['nerfpp_common.h', 'nerfpp_kernels.h', 'probe_env.h', 'nerfpp_mlp_probes.h', 'nerfpp_mlp_split.h', os.path.join('..', '..', 'include', 'nerfpp_hip.h')]
 # SURVEY 8 f-4 (MipNeRF-360 path): its own shared object and C ABI (include/mip360_hip.h)
 OUT_MIP360 = os.path.join(PKG, 'libmip360_hip.so')
 SOURCES_MIP360 = {

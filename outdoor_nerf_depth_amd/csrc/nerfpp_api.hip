@@ -96,6 +96,7 @@ WsLayout ws_layout(int n_rays, int S, int P, bool training) {
         if (t == T_R || t == T_DR) continue;     // never materialised (remap_fixup_kernel derives their gradients)
         if (t == T_DG) continue;                 // columns 32..159 of the [dS | dG] tensor allocated as T_DS
         if (t == T_H0 && h0_recomputed(P)) continue;   // recomputed from X inside its weight-gradient job (nerfpp_dw.hip: rc_job)
+        if (t == T_DZ0 + 7 && h0_recomputed(P)) continue;   // single-plane workspace = bf16 backward: rc7_job recomputes dZ7 from [dS | dG]
         off = align_up(off + (size_t)L.rows_padded * tensor_ld(net, t) * 2 * a_planes(P), 256);
       }
       L.slabs[net] = off; off = align_up(off + (size_t)L.ksplit * gslab_floats(net) * 4, 256);
@@ -294,6 +295,8 @@ int nerfpp_workspace_tensor(int n_rays, int n_samples, int precision, int net, i
   REQUIRE(byte_offset && ld && plane_bytes, "non-null outputs");
   if (tensor == T_H0 && h0_recomputed(precision))
     return fail(NERFPP_ERR_UNSUPPORTED, "nerfpp_workspace_tensor: H0 is not materialised at precision %d (its weight-gradient job recomputes it from X)", precision);
+  if (tensor == T_DZ0 + 7 && h0_recomputed(precision))
+    return fail(NERFPP_ERR_UNSUPPORTED, "nerfpp_workspace_tensor: dZ7 is not materialised at precision %d (its weight-gradient job recomputes it from [dS | dG])", precision);
   const WsLayout L = ws_layout(n_rays, n_samples, precision, true);
   const int l = tensor_ld(net, tensor);
   *byte_offset = tensor == T_DG ? (int64_t)L.tensor[net][T_DS] + (DG_COL0 / 16) * FRAG_BYTES : (int64_t)L.tensor[net][tensor];
@@ -376,9 +379,7 @@ static void weight_grads(hipStream_t st, const nerfpp_backward_args* a, const Ws
   }
   dw.rows = L.rows;
   dw.rows_padded = L.rows_padded;
-  const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
   dw.h0_from_x = a->precision == 1 ? 1 : 0;      // every bf16 backward: X (hi plane) is in every workspace, W0 in its own pack
-  (void)WP;
   const PackLayout PL = pack_layout(a->precision);
   for (int net = 0; net < N_NET; ++net) {
     dw.fwd_w[net] = (const char*)a->packed + PL.fwd[net];
@@ -400,9 +401,7 @@ static bool defer_dw() {
 // split-K slabs -> flat gradient (fixed summation order, x grad_scale), then the derived remap / colour-head gradients
 static void reduce_grads(hipStream_t st, const nerfpp_backward_args* a, const WsLayout& L, const TblLayout& T) {
   char* ws = (char*)a->workspace;
-  const int WP = a->workspace_precision ? a->workspace_precision : a->precision;
   const DwPlan plan = dw_plan(L.rows, a->precision == 1);
-  (void)WP;
   const float* slabs[N_NET];
   int64_t slab_floats[N_NET];
   const int32_t* utbl[N_NET];
@@ -415,7 +414,7 @@ static void reduce_grads(hipStream_t st, const nerfpp_backward_args* a, const Ws
   }
   // (diagnostic builds: NERFPP_REDUCE_SKIP = 1 drops the slab sum, 2 the fix-up, 3 both -- what does each cost the step?)
   static const int skip = PROBE_GETENV("NERFPP_REDUCE_SKIP") ? atoi(PROBE_GETENV("NERFPP_REDUCE_SKIP")) : 0;
-  if (!(skip & 1)) launch_unpack_grads(st, slabs, slab_floats, plan, utbl, m_out, a->grad_scale, a->grads);
+  if (!(skip & 1)) launch_unpack_grads(st, slabs, slab_floats, plan, utbl, m_out, a->grad_scale, a->grads, a->bad_count);
   if (!(skip & 2)) launch_remap_fixup(st, a->grads, a->params, m_out[0], m_out[1]);
 }
 

@@ -107,7 +107,7 @@ void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t
                        const int64_t* n, float* const* derived);
 void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats,
                          const nerfpp::DwPlan& plan, const int32_t* const* tbl, float* const* m_out, float scale,
-                         float* grads_lvl);
+                         float* grads_lvl, const int32_t* bad_count);
 void launch_remap_fixup(hipStream_t st, float* grads_lvl, const float* params_lvl, const float* m0, const float* m1);
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                  double beta1, double beta2, double eps, const float* skip);

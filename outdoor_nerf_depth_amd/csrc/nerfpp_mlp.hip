@@ -32,6 +32,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 #include "nerfpp_common.h"
 #include "nerfpp_kernels.h"
 
@@ -53,6 +54,10 @@ constexpr int LOADER_SLEEP = 0;        // (probes: idle cycles / 64 added to the
 constexpr int LDS_REUSE = 1;           // (probes: MFMAs per weight-fragment read)
 constexpr int SKIP_H = 0;              // (probes: bit l = the training forward does not write H_l out)
 constexpr int SKEW_INFER = 0;          // weight blocks by which waves NW/2.. lag waves 0..NW/2-1 (inference forward, bf16)
+constexpr int EXP = 0;                 // (probes: timing experiments with garbage results -- nerfpp_mlp_probes.h)
+constexpr int TRICKLE = 1;             // bit 0 / 1: ring / roles pipe issues a block's weight DMA in pieces between the MFMAs of the step
+constexpr int UNIT_VALU = 4;           // unit-pipelined split-bf16 kernels: VALU instructions dealt out behind each MFMA of a unit (0: the compiler's own order)
+constexpr int SPLIT_V2 = 3;            // bit 0 / 1: the split-bf16 inference / training forward runs the unit-pipelined body (nerfpp_mlp_split.h)
 __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   const u32x4_ vv = {v.x, v.y, v.z, v.w};
@@ -116,6 +121,9 @@ __device__ __forceinline__ void glds16xN_saddr(const char* sbase, uint32_t voff,
 // buys a 4-deep ring next to the doubled hand-off region and encoded-point stash in 160 KiB of LDS
 template <int P, bool TRAIN>
 constexpr int blk_frags_of() { return (P >= 2 && TRAIN) ? 8 : BLK_FRAGS; }
+// the split-bf16 training forward in its unit-pipelined form (nerfpp_mlp_split.h): ring pipe, 2 slots of 16-fragment blocks, no roles
+template <int P, bool TRAIN>
+constexpr bool split_v2_train() { return P == 2 && TRAIN && (probe::SPLIT_V2 & 2) != 0; }
 
 // SKEW > 0: the waves NW/2.. ("lagging") consume block t - SKEW in the step in which the waves 0..NW/2-1 consume block t (one wave
 // of each half per SIMD): a stage's epilogue -- conversion VALU with nothing for the matrix pipe -- of one half then coincides
@@ -142,36 +150,57 @@ struct WeightPipe {
 #pragma unroll
     for (int b = 0; b < AHEAD; ++b) issue();
   }
-  __device__ __forceinline__ void issue() {                    // next block of the stream -> next ring slot
-    const int blk = next_issue, slot = slot_issue;
+  // fragments per block this wave issues (roles: the loader issues them all, the others none)
+  static constexpr int SHARE = MODE == PIPE_ROLES ? BF * P : BF * P / NW;
+  // (not with a 2-slot ring: the block is waited for one step after its DMA goes out and needs the whole step to land --
+  // measured on the unit-pipelined split-bf16 training forward: 1.31 ms at once, 1.37 ms in pieces)
+  static constexpr bool TRICKLE = ((MODE == PIPE_RING ? probe::TRICKLE : probe::TRICKLE >> 1) & 1) != 0 && NBUF - 1 - SKEW >= 2;
+  int pend_blk = -1, pend_slot = 0;                            // TRICKLE: the block whose DMA the current step issues piecewise
+  // fragments [f0, f1) of this wave's share of block `blk` -> ring slot `slot`, up to four per M0 / address set-up
+  __device__ __forceinline__ void issue_frags(int blk, int slot, int f0, int f1) {
+    if constexpr (probe::NO_DMA) return;
+    if (MODE == PIPE_ROLES && wave != 0) return;               // the loader wave issues the whole block
+    const int w0 = MODE == PIPE_ROLES ? 0 : wave * SHARE;
+    const char* sb = g + (size_t)blk * BLK_BYTES + (size_t)w0 * FRAG_BYTES;
+    const uint32_t dst = lds_base + slot * BLK_BYTES + w0 * FRAG_BYTES;
+    if constexpr (MODE == PIPE_ROLES && probe::LOADER_SLEEP > 0) { if (f0 == 0) __builtin_amdgcn_s_sleep(probe::LOADER_SLEEP); }
+#pragma unroll
+    for (int f = f0; f < f1; f += 4) {
+      const int n = f1 - f < 4 ? f1 - f : 4;                   // (compile-time after unrolling)
+      const char* a = sb + f * FRAG_BYTES;
+      const uint32_t d = dst + f * FRAG_BYTES;
+      if (n == 4) glds16xN_saddr<4>(a, (uint32_t)lane * 16u, d);
+      else if (n == 3) glds16xN_saddr<3>(a, (uint32_t)lane * 16u, d);
+      else if (n == 2) glds16xN_saddr<2>(a, (uint32_t)lane * 16u, d);
+      else glds16xN_saddr<1>(a, (uint32_t)lane * 16u, d);
+    }
+  }
+  // claim the next block of the stream and the next ring slot; false past the end of the stream
+  __device__ __forceinline__ bool claim(int& blk, int& slot) {
+    blk = next_issue; slot = slot_issue;
     ++next_issue;
     slot_issue = slot_issue + 1 == NBUF ? 0 : slot_issue + 1;
-    if (blk >= nblk) return;
-    if constexpr (probe::NO_DMA) return;
-    if constexpr (MODE == PIPE_ROLES) {
-      if (wave != 0) return;                                   // the loader wave issues the whole block
-      static_assert(BF * P % 4 == 0, "groups of four fragments");
-      if constexpr (probe::LOADER_SLEEP > 0) __builtin_amdgcn_s_sleep(probe::LOADER_SLEEP);
-#pragma unroll
-      for (int fi = 0; fi < BF * P; fi += 4)
-        glds16xN_saddr<4>(g + (size_t)blk * BLK_BYTES + fi * FRAG_BYTES, (uint32_t)lane * 16u, lds_base + slot * BLK_BYTES + fi * FRAG_BYTES);
-    } else {
-      // every wave fetches a contiguous run of the block's fragments, four per M0 / address set-up
-      constexpr int C = BF * P / NW;
-      static_assert(C == 2 || C % 4 == 0, "per-wave fragment count");
-      const char* sb = g + (size_t)blk * BLK_BYTES + (size_t)wave * C * FRAG_BYTES;
-      const uint32_t dst = lds_base + slot * BLK_BYTES + wave * C * FRAG_BYTES;
-      if constexpr (C == 2) glds16xN_saddr<2>(sb, (uint32_t)lane * 16u, dst);
-      else {
-#pragma unroll
-        for (int f = 0; f < C; f += 4) glds16xN_saddr<4>(sb + f * FRAG_BYTES, (uint32_t)lane * 16u, dst + f * FRAG_BYTES);
-      }
+    return blk < nblk;
+  }
+  __device__ __forceinline__ void issue() {                    // next block of the stream -> next ring slot, all at once
+    int blk, slot;
+    if (!claim(blk, slot)) return;
+    static_assert(SHARE == 2 || SHARE % 4 == 0, "per-wave fragment count");
+    issue_frags(blk, slot, 0, SHARE);
+  }
+  // TRICKLE: piece i of n of the block claimed at this step's barrier (call n times per step, between the step's MFMAs: a
+  // DMA instruction that follows another one back to back waits for the texture addresser to take its predecessor)
+  __device__ __forceinline__ void trickle(int i, int n) {
+    if constexpr (TRICKLE) {
+      if (pend_blk < 0) return;
+      issue_frags(pend_blk, pend_slot, SHARE * i / n, SHARE * (i + 1) / n);
     }
   }
   // wait until block `step` has landed, leaving up to AHEAD-1 younger blocks in flight.  Valid because
   // every VMEM op the waiting wave has outstanding is a load (they retire in order); extra loads in
   // between (sign words, rays) only make the count conservative.
   __device__ __forceinline__ void wait_counted() {
+    if constexpr ((probe::EXP & 1) != 0) return;                 // (probes: the weight DMA is never waited for)
     const int younger = nblk - 1 - step < AHEAD - 1 ? nblk - 1 - step : AHEAD - 1;
     if (AHEAD >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_BLK) : "memory");
     else if (AHEAD >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_BLK) : "memory");
@@ -182,7 +211,7 @@ struct WeightPipe {
     probe::stamp(0, cur, wave, lane, stamp_off);                 // arrival at the block boundary
     if constexpr (MODE == PIPE_RING) {
       wait_counted();
-      __builtin_amdgcn_s_barrier();
+      if constexpr ((probe::EXP & 2) == 0) __builtin_amdgcn_s_barrier();
     } else {
       // only the loader has DMA to wait for; everybody: LDS writes of the hand-off region must have landed
       if (wave == 0) wait_counted();
@@ -190,7 +219,8 @@ struct WeightPipe {
       __builtin_amdgcn_s_barrier();
     }
     probe::stamp(1, cur, wave, lane, stamp_off);                 // released by the barrier
-    issue();
+    if constexpr (TRICKLE) { int b_, s_; pend_blk = claim(b_, s_) ? b_ : -1; pend_slot = s_; }
+    else issue();
     ++step;
   }
   __device__ __forceinline__ bool lagging() const { return SKEW > 0 && wave >= NW / 2; }
@@ -255,9 +285,16 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
     // there is nothing to wait for and "after the MFMAs" for every wave (1) measures 1.4 % faster in the forward
     // (0.633 vs 0.642 ms at N_rand 1024), "before" (2) the same as (0).
     if (probe::HOOK_ORDER == 2 || (probe::HOOK_ORDER == 0 && pipe.wave >= 4)) hook(blk);
+    // (TRICKLE pipes: the DMA of the block this step's barrier freed a slot for goes out in UPB * KPB pieces between the MFMAs)
+    constexpr bool CHAINS = P >= 2 && probe::CHAIN_GROUP > 1 && NOB % probe::CHAIN_GROUP == 0 && !(probe::LDS_REUSE > 1 && P == 1);
+    constexpr int UPB = CHAINS ? NOB / probe::CHAIN_GROUP : (NOB == 8 ? 2 : 1);       // trickle points per k-chunk
 #pragma unroll
     for (int kl = 0; kl < KPB; ++kl) {
-      if (blk * KPB + kl >= LIVE) continue;          // (compile-time after unrolling)
+      if (blk * KPB + kl >= LIVE) {                  // (compile-time after unrolling)
+#pragma unroll
+        for (int u = 0; u < UPB; ++u) pipe.trickle(kl * UPB + u, KPB * UPB);
+        continue;
+      }
       if constexpr (probe::LDS_REUSE > 1 && P == 1) {      // (probes: one weight-fragment read per LDS_REUSE MFMAs -- garbage results)
         bf16x8 w{};
 #pragma unroll
@@ -265,7 +302,9 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
           if (ob % probe::LDS_REUSE == 0) w = *(const bf16x8*)(l + (kl * NOB + ob) * FRAG_BYTES);
           acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b[blk * KPB + kl].v[0], acc[ob], 0, 0, 0);
         }
-      } else if constexpr (P >= 2 && probe::CHAIN_GROUP > 1 && NOB % probe::CHAIN_GROUP == 0) {
+#pragma unroll
+        for (int u = 0; u < UPB; ++u) pipe.trickle(kl * UPB + u, KPB * UPB);
+      } else if constexpr (CHAINS) {
         // split-bf16 / fp16x2w: the 3 (2) MFMAs of an out-block are a dependent chain on its accumulator; the chains of CHAIN_GROUP
         // out-blocks interleaved keep the order inside each chain (bit-identical) and give every MFMA an independent predecessor
         constexpr int G = probe::CHAIN_GROUP;
@@ -290,11 +329,15 @@ __device__ __forceinline__ void stage_gemm(Pipe& pipe, f32x16 (&acc)[NOB], const
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[ob + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl[g]), bf, acc[ob + g], 0, 0, 0);
           }
+          pipe.trickle(kl * UPB + ob / G, KPB * UPB);
         }
       } else {
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
+        for (int ob = 0; ob < NOB; ++ob) {
           mfma_p<P>(acc[ob], l + (kl * NOB + ob) * w_planes(P) * FRAG_BYTES, b[blk * KPB + kl]);
+          if (UPB == 2 && (ob & 3) == 3) pipe.trickle(kl * 2 + (ob >> 2), KPB * 2);
+        }
+        if (UPB == 1) pipe.trickle(kl, KPB);
       }
     }
     if (probe::HOOK_ORDER == 1 || (probe::HOOK_ORDER == 0 && pipe.wave < 4)) hook(blk);
@@ -439,6 +482,13 @@ __device__ __forceinline__ uint4 acc_to_frags_relu_bits(const f32x16 (&acc)[NOB]
         }
         const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         h[2 * ob + hh].v[0] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, d), zero));
+      } else if constexpr ((probe::EXP & 4) != 0) {
+        // (probes: no conversion work at all -- the accumulator bits go on as the operand; what would a hidden epilogue buy?)
+        u32x4 d0, d1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { d0[w] = __float_as_uint(acc[ob][8 * hh + w]) & 0x3f803f80u; d1[w] = __float_as_uint(acc[ob][8 * hh + 4 + w]) & 0x3f803f80u; }
+        h[2 * ob + hh].v[0] = __builtin_bit_cast(bf16x8, d0);
+        h[2 * ob + hh].v[1] = __builtin_bit_cast(bf16x8, d1);
       } else if constexpr (!PK) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) set_slot<P>(h[2 * ob + hh], t, fmaxf(acc[ob][8 * hh + t], 0.f));
@@ -623,6 +673,10 @@ __device__ __forceinline__ void mask_to_frags(const f32x16 (&acc)[NOB], const ui
 template <int NET>
 __device__ __forceinline__ void sample_point(const MlpGeom& gm, size_t row, int S, float (&x)[4], float (&vd)[3],
                                              float* depth_real) {
+  // No implicit FMA contraction in the point / encoding arithmetic: which mul + add pairs the compiler fuses depends on the code
+  // around the inlined copy, and the stage-at-a-time and the unit-pipelined split-bf16 bodies (nerfpp_mlp_split.h) then differ in
+  // the last bit of a few encoded values.  Uncontracted float32 is also what the reference's torch ops compute.
+#pragma clang fp contract(off)
   const int ray = (int)(row / S);
   const float ox = gm.ray_o[ray * 3], oy = gm.ray_o[ray * 3 + 1], oz = gm.ray_o[ray * 3 + 2];
   const float dx = gm.ray_d[ray * 3], dy = gm.ray_d[ray * 3 + 1], dz = gm.ray_d[ray * 3 + 2];
@@ -661,6 +715,7 @@ __device__ __forceinline__ void sample_point(const MlpGeom& gm, size_t row, int 
 // (Precision 3 rounds the features to fp16 -- 2.4e-4 at |v| ~ 1 -- an order of magnitude above the hardware path's error.)
 template <int P>
 __device__ __forceinline__ void pe_sincos(float arg, float* sn, float* cs) {
+#pragma clang fp contract(off)          // (the FMAs below are explicit)
   if constexpr (P != 2) {
     const float r = __builtin_amdgcn_fractf(arg * 0.15915494309189535f);
     *sn = __builtin_amdgcn_sinf(r);
@@ -695,6 +750,7 @@ __device__ __forceinline__ void pe_sincos(float arg, float* sn, float* cs) {
 // positional encoding of this lane-half's share (nerfpp_common.h: pe_ref_of_lane_slot)
 template <int NET, int P>
 __device__ __forceinline__ void encode_point(const float (&x)[4], int hi, Frag<P> (&pe)[kpe(NET)]) {
+#pragma clang fp contract(off)
   constexpr int D = pe_dim(NET), NV = kpe(NET) * 8;
   float v[NV];
 #pragma unroll
@@ -720,6 +776,7 @@ __device__ __forceinline__ void encode_point(const float (&x)[4], int hi, Frag<P
 
 template <int P>
 __device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P> (&df)[2]) {
+#pragma clang fp contract(off)
   float v[16];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
@@ -744,12 +801,14 @@ __device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P>
 // LDS carve-up shared by kernel and launcher
 template <int NET, int P, int NW, bool TRAIN>
 struct FwdLds {
-  static constexpr int MODE = !TRAIN ? PIPE_RING : PIPE_ROLES;
+  static constexpr bool V2T = split_v2_train<P, TRAIN>();
+  static constexpr int MODE = (!TRAIN || V2T) ? PIPE_RING : PIPE_ROLES;
   static constexpr bool ROLES = MODE == PIPE_ROLES;
-  static constexpr int BF = blk_frags_of<P, TRAIN>();
+  static constexpr int BF = V2T ? BLK_FRAGS : blk_frags_of<P, TRAIN>();
   // ring depth: as deep as the 160 KiB of LDS allow
   static constexpr int SKEW = (MODE == PIPE_RING && P == 1 && NW >= 2) ? probe::SKEW_INFER : 0;
-  static constexpr int NBUF = MODE == PIPE_RING ? (P == 1 ? 4 + SKEW : 3) : 4;
+  // (V2T: every wave stores AND fetches, so a block is waited for with a full vmcnt drain -- one block ahead, two slots)
+  static constexpr int NBUF = V2T ? 2 : MODE == PIPE_RING ? (P == 1 ? 4 + SKEW : 3) : 4;
   static constexpr int W = NBUF * BF * w_planes(P) * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STASH = REGION + (ROLES ? region_bytes(P) : 0);
@@ -1164,14 +1223,26 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a, const int bid)
   probe::dump_stamps(LD::TOTAL, wave, lane);
 }
 
+}  // namespace nerfpp
+#include "nerfpp_mlp_split.h"
+namespace nerfpp {
+
 // Both nets of a cascade level in ONE launch: the fg net's tiles first, the bg net's as CUs free up.  They are independent
 // (ddp_model.py:86-120 evaluates the two MLPs on different points), so one launch has one start-up and one tail where two
 // launches had two (profiles/r04_pair_launch.md: ~20 us per launch boundary at N_rand = 1024, 12 MLP / weight-gradient
 // launches per step before, 6 now).  tiles0 = 0 or grid = tiles0 runs one net alone (probes: the two-launch form).
 template <int P, int NW, bool TRAIN>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void mlp_fwd_pair_kernel(MlpFwdArgs a0, MlpFwdArgs a1, int tiles0) {
-  if ((int)blockIdx.x < tiles0) mlp_fwd_body<0, P, NW, TRAIN>(a0, (int)blockIdx.x);
-  else mlp_fwd_body<1, P, NW, TRAIN>(a1, (int)blockIdx.x - tiles0);
+  if constexpr (P == 2 && ((probe::SPLIT_V2 >> (TRAIN ? 1 : 0)) & 1) != 0) {
+    // (training: one body per save mode -- both planes of the saved tensors, or the hi planes alone for a bf16 backward)
+    const bool fg = (int)blockIdx.x < tiles0;
+    const bool hi_only = TRAIN && !(fg ? a0.save_lo : a1.save_lo);
+    if (fg) { if (hi_only) mlp_fwd_body_split<0, NW, TRAIN, TRAIN>(a0, (int)blockIdx.x); else mlp_fwd_body_split<0, NW, TRAIN, false>(a0, (int)blockIdx.x); }
+    else { if (hi_only) mlp_fwd_body_split<1, NW, TRAIN, TRAIN>(a1, (int)blockIdx.x - tiles0); else mlp_fwd_body_split<1, NW, TRAIN, false>(a1, (int)blockIdx.x - tiles0); }
+  } else {
+    if ((int)blockIdx.x < tiles0) mlp_fwd_body<0, P, NW, TRAIN>(a0, (int)blockIdx.x);
+    else mlp_fwd_body<1, P, NW, TRAIN>(a1, (int)blockIdx.x - tiles0);
+  }
 }
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_pair_kernel(MlpBwdArgs a0, MlpBwdArgs a1, int tiles0) {

@@ -22,7 +22,8 @@
 //   NERFPP_STAMPS=k        per-block cycle stamps (s_memtime at arrival at / release from every block barrier, per wave) of
 //                          workgroups 0-3 and 400-403 (fg tiles) of kernel instantiation k (NERFPP_MLP_PART numbering: 2 = bf16
 //                          training forward, 4 = bf16 backward), kept in LDS and copied out at the end of the kernel;
-//                          read back with nerfpp_probe_stamps() (tools/probes/stamps_probe.py)
+//                          read back with nerfpp_probe_stamps() (tools/probes/stamps_probe.py); 1 / 3 / 5 = the split-bf16 inference
+//                          forward / training forward / backward (4 waves)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -80,6 +81,22 @@ constexpr int CHAIN_GROUP = NERFPP_CHAIN_GROUP;
 #define NERFPP_SKEW_INFER 0
 #endif
 constexpr int SKEW_INFER = NERFPP_SKEW_INFER;
+#ifndef NERFPP_EXP
+#define NERFPP_EXP 0
+#endif
+constexpr int EXP = NERFPP_EXP;                   // timing experiments, garbage results: 1 the weight DMA is never waited for (ring pipe), 2 no block barrier (ring pipe), 4 the split-bf16 epilogue without its conversion work
+#ifndef NERFPP_TRICKLE
+#define NERFPP_TRICKLE 1
+#endif
+constexpr int TRICKLE = NERFPP_TRICKLE;           // bit 0 / 1: the ring / roles pipe issues a block's weight DMA in pieces between the step's MFMAs
+#ifndef NERFPP_UNIT_VALU
+#define NERFPP_UNIT_VALU 4
+#endif
+constexpr int UNIT_VALU = NERFPP_UNIT_VALU;       // unit-pipelined split-bf16 kernels: VALU instructions dealt out behind each MFMA of a unit (0: the compiler's own order)
+#ifndef NERFPP_SPLIT_V2
+#define NERFPP_SPLIT_V2 3
+#endif
+constexpr int SPLIT_V2 = NERFPP_SPLIT_V2;         // bit 0 / 1: the split-bf16 inference / training forward runs the unit-pipelined body (0: the stage-at-a-time bodies)
 constexpr int SKIP_H = NERFPP_SKIP_H;             // bit l: the bf16 training forward leaves H_l unsaved (what would one-layer recompute in dw_kernel buy?)
 constexpr int LDS_REUSE = NERFPP_LDS_REUSE;       // 2: one weight-fragment read per two MFMAs (what 64-row waves would need); with NERFPP_LDS_PREFETCH=0
 
@@ -120,9 +137,17 @@ __device__ __forceinline__ void store16(char* gptr, const uint4 v) {
 
 
 #if defined(NERFPP_STAMPS) && defined(NERFPP_MLP_PART) && NERFPP_STAMPS == NERFPP_MLP_PART
-constexpr int STAMP_BLKS = 96, STAMP_WGS = 8;
-constexpr int STAMP_BYTES = 8 * STAMP_BLKS * 2 * 4;
-static __device__ uint32_t g_stamps[STAMP_WGS][8][STAMP_BLKS][2];
+// (split-bf16 kernels: 4 waves; their training kernels stream 8-fragment blocks -- 134 / 124 per fg tile)
+#if NERFPP_STAMPS == 3 || NERFPP_STAMPS == 5
+constexpr int STAMP_BLKS = 152, STAMP_WAVES = 4;
+#elif NERFPP_STAMPS == 1
+constexpr int STAMP_BLKS = 96, STAMP_WAVES = 4;
+#else
+constexpr int STAMP_BLKS = 96, STAMP_WAVES = 8;
+#endif
+constexpr int STAMP_WGS = 8;
+constexpr int STAMP_BYTES = STAMP_WAVES * STAMP_BLKS * 2 * 4;
+static __device__ uint32_t g_stamps[STAMP_WGS][STAMP_WAVES][STAMP_BLKS][2];
 extern __shared__ __attribute__((aligned(16))) char probe_smem[];
 __device__ __forceinline__ void stamp(int which, int blk, int wave, int lane, uint32_t lds_off) {
   if (blk >= STAMP_BLKS) return;

@@ -82,9 +82,11 @@ struct UnpackArgs {
   float* m_out[N_NET];
   DwPlan plan;                    // slabs filled per job
 };
-__global__ void unpack_grads_kernel(UnpackArgs a, float scale, float* __restrict__ grads) {
+__global__ void unpack_grads_kernel(UnpackArgs a, float scale, float* __restrict__ grads, const int32_t* __restrict__ bad_count) {
   const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= LEVEL_PARAMS) return;
+  // the bad-camera count of the step goes with the gradients (nerfpp_backward_args::bad_count): one element behind them
+  if (gi == 0 && bad_count != nullptr) grads[LEVEL_PARAMS] = (float)*bad_count;
   const int net = gi >= FG_PARAMS;
   const int i = (int)(gi - (net ? FG_PARAMS : 0));
   const int32_t src = __builtin_nontemporal_load(a.tbl[net] + i);
@@ -217,13 +219,13 @@ void launch_pack_level(hipStream_t st, const float* params, int P, const int32_t
   else hipLaunchKernelGGL(pack_level_kernel<3>, dim3(blk), dim3(256), 0, st, params, sg);
 }
 void launch_unpack_grads(hipStream_t st, const float* const* slabs, const int64_t* slab_floats, const DwPlan& plan,
-                         const int32_t* const* tbl, float* const* m_out, float scale, float* grads_lvl) {
+                         const int32_t* const* tbl, float* const* m_out, float scale, float* grads_lvl, const int32_t* bad_count) {
   UnpackArgs a{};
   a.plan = plan;
   for (int net = 0; net < N_NET; ++net) {
     a.slabs[net] = slabs[net]; a.slab_floats[net] = slab_floats[net]; a.tbl[net] = tbl[net]; a.m_out[net] = m_out[net];
   }
-  hipLaunchKernelGGL(unpack_grads_kernel, dim3((LEVEL_PARAMS + 255) / 256), dim3(256), 0, st, a, scale, grads_lvl);
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3((LEVEL_PARAMS + 255) / 256), dim3(256), 0, st, a, scale, grads_lvl, bad_count);
 }
 void launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                  double beta1, double beta2, double eps, const float* skip) {

@@ -297,13 +297,15 @@ class LevelEngine(object):
         return blk.reshape(rows_p, ld)[:rows].float()
 
     def backward(self, g_rgb, g_depth, g_fg_weights=None, grad_scale=1.0, out=None, events=None, defer_reduce=False,
-                 fused_loss=None):
+                 fused_loss=None, bad_count=None):
         """Gradient of the loss w.r.t. the flat parameters given dL/d rgb, dL/d depth and (KL)
         dL/d fg_weights, for the last training-mode forward.  defer_reduce: stop after the weight-gradient
         GEMMs; `reduce_grads()` (on any stream ordered after this call) then fills the returned tensor.
         fused_loss: instead of g_* (pass None), dict(loss_type, lambda_depth, kl_sigma, ret, rgb_gt, depth_sup): the
         loss head of ddp_train_nerf.py:481-493 is differentiated inside the compositing backward (same arithmetic as
-        loss_and_grads, which then only serves the logged scalars and can run off the critical path)."""
+        loss_and_grads, which then only serves the logged scalars and can run off the critical path).
+        bad_count: optional int32 device tensor [1] (the `bad` counter of sample_coarse); `out` must then have LEVEL_PARAMS + 1
+        elements and the slab-sum launch writes float(bad_count) behind the gradients (nerfpp_backward_args.bad_count)."""
         if self._fwd is None:
             raise L.NerfppError('backward() needs a preceding forward(training=True)')
         n, S, ray_d, fg_far, fg_z, bg_z = self._fwd
@@ -317,7 +319,10 @@ class LevelEngine(object):
             t = L.LOSS_TYPES[f['loss_type']]
             keep = (_f32(f['ret']['rgb'], (n, 3)), _f32(f['ret']['depth'], (n,)), _f32(f['rgb_gt'], (n, 3)),
                     _f32(f['depth_sup'], (n,)) if t != L.LOSS_RGB_ONLY else None)
-        grads = out if out is not None else torch.empty(L.LEVEL_PARAMS, device=self.device)
+        n_out = L.LEVEL_PARAMS + (1 if bad_count is not None else 0)
+        grads = out if out is not None else torch.empty(n_out, device=self.device)
+        if grads.numel() < n_out or not grads.is_contiguous() or grads.dtype != torch.float32:
+            raise L.NerfppError('backward(): `out` needs %d contiguous float32 elements' % n_out)
         a = L.BackwardArgs()
         a.n_rays, a.n_samples, a.precision = n, S, self.bwd_precision
         a.workspace_precision = self.precision
@@ -337,6 +342,11 @@ class LevelEngine(object):
         if events is not None:          # (bwd begin, bwd end, dw begin, dw end)
             a.ev_bwd_begin, a.ev_bwd_end, a.ev_dw_begin, a.ev_dw_end = [e.cuda_event for e in events]
         a.defer_reduce = int(bool(defer_reduce))
+        if bad_count is not None:
+            if bad_count.dtype != torch.int32 or bad_count.numel() != 1 or bad_count.device != self.device:
+                raise L.NerfppError('bad_count: one int32 on the engine\'s device')
+            a.bad_count = bad_count.data_ptr()
+            keep = (keep, bad_count)
         L.check(L.lib().nerfpp_level_backward(_stream(), C.byref(a)), 'nerfpp_level_backward')
         # the reduction reads nothing of the batch: keep only what nerfpp_level_reduce_grads looks at alive
         self._bwd_args = (a, grads) if defer_reduce else None

@@ -94,8 +94,9 @@ class NerfppTrainer(object):
         1/world_size in the reduction, so a SUM all-reduce yields the mean, ddp_train_nerf.py:323), Adam, re-pack."""
         eng = self.engines[m]
         eng.reduce_grads()
+        # the slab sum wrote float(bad_cameras) -- cumulative since the last check_cameras() -- behind the gradients
+        # (nerfpp_backward_args.bad_count; until round 6 a torch copy_ launch per level and step)
         flag = self.grads[m][L.LEVEL_PARAMS:L.LEVEL_PARAMS + 1]
-        flag.copy_(self.bad_cameras)                      # int32 count -> float, cumulative since the last check_cameras()
         if self.world_size > 1 or self.comm is not None:
             import torch.distributed as dist
             if self.autoexpo is not None:
@@ -227,7 +228,7 @@ class NerfppTrainer(object):
                                                 self.kl_sigma, fg_z, far)[0]
                         loss_done = torch.cuda.Event()
                         loss_done.record()
-                eng.backward(None, None, None, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS],
+                eng.backward(None, None, None, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS + 1], bad_count=self.bad_cameras,
                              events=ev['bwd'] if ev else None, defer_reduce=True,
                              fused_loss=dict(loss_type=self.loss_type, lambda_depth=self.lambda_depth, kl_sigma=self.kl_sigma,
                                              ret=ret, rgb_gt=batch['rgb'], depth_sup=depth_sup))
@@ -265,12 +266,12 @@ class NerfppTrainer(object):
                     if torch.is_tensor(t):
                         t.record_stream(stream)               # (allocated on this stream, read on the level's)
                 with torch.cuda.stream(stream):
-                    eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS],
+                    eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS + 1], bad_count=self.bad_cameras,
                                  defer_reduce=True)
                     self._update_begin(m)
                 scalars.append(sc)
                 continue
-            eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS],
+            eng.backward(g_rgb, g_depth, g_w, grad_scale=1.0 / self.world_size, out=self.grads[m][:L.LEVEL_PARAMS + 1], bad_count=self.bad_cameras,
                          events=ev['bwd'] if ev else None, defer_reduce=True)
             scalars.append(sc)
             self._update_begin(m)
