@@ -56,8 +56,9 @@ SURVEY_ALGO_BYTES_PER_RAY = 18.8e3   # inputs + outputs + amortised
 # sum over jobs of (dZ cols + input cols) * 2 B, fg + bg
 EXEC_OVER_ALGO = {'mlp_fwd': 1.0 - 2 * 65536.0 / (593408 + 604160), 'mlp_bwd': 1.0 - 2 * 65536.0 / (2 * 557696), 'dw': 1.0}
 DW_BYTES_PER_ROW = (4576 + 4640) * 2        # columns the jobs of nerfpp_common.h: build_all_jobs read per row (fg + bg), bf16
-# a bf16 backward: job L1 reads the encoded point (64 / 96 columns) instead of H0 (256) and recomputes it (nerfpp_dw.hip: rc_job)
-DW_BYTES_PER_ROW_BF16 = (4576 - 192 + 4640 - 160) * 2
+# a bf16 backward: job L1 reads the encoded point (64 / 96 columns) instead of H0 (256) and recomputes it (nerfpp_dw.hip: rc_job);
+# job L7 reads [dS | dG] (160 columns) and one 16-byte sign word per lane (32 B per row) instead of dZ7 (256) (rc7_job)
+DW_BYTES_PER_ROW_BF16 = (4576 - 192 - 96 + 4640 - 160 - 96) * 2 + 2 * 32
 FLOP_PER_RAY_RENDER = 0.613e9    # forward only, both levels
 SETUP_STEPS = 12                 # untimed steps run when a trainer is set up, before the W warm-up steps (see run_mode)
 # HBM bytes per LEVEL-1 launch group at N_rand = 1024, bf16: PARSED at start-up from the rocprofv3 --pmc passes committed
@@ -147,6 +148,11 @@ def parse():
     p.add_argument('--n_rand', type=int, default=1024, help='rays per GPU per step (reference forces 1024)')
     p.add_argument('--precision', choices=['both', 'bf16', 'split'], default='both')
     p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--grad_comm', choices=['torch', 'rccl_abi', 'both'], default='both',
+                   help='N > 1: transport of the gradient all-reduce -- torch.distributed (backend nccl = RCCL), the library\'s own RCCL '
+                        'entry point (nerfpp_allreduce_mean), or both one after the other in the same job (the headline is torch; the '
+                        'second is reported under config.grad_comm_rccl_abi).  Over gloo (test hook) only torch exists')
+    p.add_argument('--rccl_channels', type=int, default=-1, help='-1: NCCL_MAX_NCHANNELS=4 (one node), 0: RCCL\'s own choice, N: N')
     p.add_argument('--large_batch', type=int, default=8192, help='also report this N_rand (0 = skip)')
     p.add_argument('--mip360_rays', type=int, default=4096, help='also time the MipNeRF-360 step (config 5) at this many rays (0 = skip)')
     # BASELINE.json configs[1] by default (gt / mse / 0.1); configs[2] = mono_crop / kl, configs[3] = stereo_crop / l1
@@ -171,9 +177,24 @@ def _free_port():
     return port
 
 
-def rccl_env_defaults():
-    from outdoor_nerf_depth_amd.dist_utils import RCCL_ENV_DEFAULTS
-    return dict(RCCL_ENV_DEFAULTS)
+def rccl_env_defaults(channels=-1):
+    """environment defaults of an N > 1 run (one node by construction: this script spawns / is launched with one rank per local
+    GPU): the channel cap (dist_utils.py) and RCCL's INIT lines to a per-process file, from which the channel count the
+    communicators actually got is read back (config.rccl_channels_in_effect)"""
+    from outdoor_nerf_depth_amd.dist_utils import RCCL_ENV_DEFAULTS, rccl_debug_file_env
+    env = {} if channels == 0 else dict(RCCL_ENV_DEFAULTS) if channels < 0 else \
+        {'NCCL_MAX_NCHANNELS': str(channels), 'NCCL_MIN_NCHANNELS': str(min(2, channels))}
+    env.update(rccl_debug_file_env('nerfpp_bench'))
+    return env
+
+
+def _channels_arg():
+    for i, a in enumerate(sys.argv):
+        if a == '--rccl_channels' and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith('--rccl_channels='):
+            return int(a.split('=', 1)[1])
+    return -1
 
 
 def spawn_ranks(n):
@@ -189,7 +210,7 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        for k, v in rccl_env_defaults().items():
+        for k, v in rccl_env_defaults(_channels_arg()).items():
             env.setdefault(k, v)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -218,14 +239,14 @@ def spawn_ranks(n):
         time.sleep(0.2)
 
 
-def run_mode(args, precision, rank, world, device, batches):
+def run_mode(args, precision, rank, world, device, batches, comm=None):
     import torch
     from outdoor_nerf_depth_amd.trainer import NerfppTrainer, ALGO_MACS
     from outdoor_nerf_depth_amd.synthetic import SyntheticKitti
 
     scale = float(SyntheticKitti().depth_scale)
     tr = NerfppTrainer(device, precision=precision, use_depth=True, depth_loss_type=args.depth_loss_type,
-                       lambda_depth=args.lambda_depth, depth_scale=scale, world_size=world, seed=(rank + 1) * 777)
+                       lambda_depth=args.lambda_depth, depth_scale=scale, world_size=world, seed=(rank + 1) * 777, comm=comm)
     K, W = args.steps, args.warmup
     # live kernel taps: HIP events recorded by the library around the level-1 kernel groups (both nets), on the
     # launch stream, inside the timed region.  An event record costs ~6 us of queue time, so only every TAP-th
@@ -255,6 +276,7 @@ def run_mode(args, precision, rank, world, device, batches):
     torch.cuda.synchronize()
     if world > 1:
         tr.wait_taps = []                        # exposed (un-hidden) part of the side-stream update incl. the all-reduce
+        tr.comm_taps = []                        # (level, begin, end) events around every gradient all-reduce, on its stream
     t0 = time.perf_counter()
     last = None
     for i in range(K):
@@ -266,17 +288,21 @@ def run_mode(args, precision, rank, world, device, batches):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    per_rank, exposed = None, None
+    per_rank, exposed, allreduce_ms = None, None, None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # diagnosis of a scaling run: every rank's own ms per step and the update time its main stream had to wait for
-        mine = torch.tensor([1e3 * own / K, sum(a.elapsed_time(b) for a, b in tr.wait_taps) / K], device=device, dtype=torch.float64)
+        # diagnosis of a scaling run: every rank's own ms per step, the update time its main stream had to wait for, and the
+        # duration of its gradient all-reduces (median over the timed steps) per cascade level, as its GPU saw them
+        ar = [[a_.elapsed_time(b_) for m_, a_, b_ in tr.comm_taps if m_ == lvl] for lvl in range(2)]
+        mine = torch.tensor([1e3 * own / K, sum(a.elapsed_time(b) for a, b in tr.wait_taps) / K] +
+                            [float(np.median(x)) if x else -1.0 for x in ar], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [round(float(x[0]), 4) for x in allr]
         exposed = [round(float(x[1]), 4) for x in allr]
+        allreduce_ms = {'level0': [round(float(x[2]), 4) for x in allr], 'level1': [round(float(x[3]), 4) for x in allr]}
     tr.check_cameras()
     loss = [float(s[0]) for s in last]
     assert all(np.isfinite(loss)), 'non-finite loss %r' % (loss,)
@@ -308,7 +334,7 @@ def run_mode(args, precision, rank, world, device, batches):
     tied = [k for k in order if share[k] >= 0.98 * top]
     dominant = tied[0]
     return dict(elapsed=elapsed, ms_per_step=1e3 * elapsed / K, value=n * K * world / elapsed, loss=loss,
-                per_rank_ms_per_step=per_rank, exposed_update_ms_per_step=exposed,
+                per_rank_ms_per_step=per_rank, exposed_update_ms_per_step=exposed, allreduce_ms=allreduce_ms,
                 value_per_gpu=n * K / elapsed, kernels=kernels, dominant=dominant, co_dominant=tied, share_ms=share,
                 pmc_ok=(n == 1024 and precision == 1 and PMC_TRAFFIC is not None))
 
@@ -485,7 +511,9 @@ def cli_loop(args, kernel_only_ms):
         trainer.flush()
         torch.cuda.synchronize()
         same_state['ms'] = 1e3 * (time.perf_counter() - t0) / 200
-    for name, extra in (('device_sampler', []), ('host_sampler', ['--host_sampling'])):
+    # (the loop in the CLI's DEFAULT precision too -- split-bf16 since round 5, 0.4x the bf16 rate: what a user who passes no
+    # --precision gets)
+    for name, extra in (('device_sampler', []), ('host_sampler', ['--host_sampling']), ('device_sampler_default_precision', ['--precision', 'split'])):
         tmp = tempfile.mkdtemp(prefix='nerfpp_cli_')
         cap = Cap()
         C.setup_logger()
@@ -496,7 +524,7 @@ def cli_loop(args, kernel_only_ms):
             a = C.config_parser().parse_args(
                 ['--expname', 'bench', '--basedir', tmp, '--synthetic', '--synthetic_frames', str(args.cli_frames), '--world_size', '1',
                  '--cascade_samples', '64,128', '--N_rand_override', str(args.n_rand), '--N_iters', str(args.cli_steps),
-                 '--i_print', '100', '--i_weights', '100000000', '--i_test', '100000000', '--precision', 'bf16', '--use_depth',
+                 '--i_print', '100', '--i_weights', '100000000', '--i_test', '100000000'] + ([] if '--precision' in extra else ['--precision', 'bf16']) + ['--use_depth',
                  '--depth_sup_type', args.depth_sup_type, '--depth_loss_type', args.depth_loss_type,
                  '--lambda_depth', str(args.lambda_depth)] + extra)
             C.validate_args(a)
@@ -518,8 +546,13 @@ def cli_loop(args, kernel_only_ms):
                      'ms_per_step_by_log_line': [round(1e3 * t, 4) for t in late],
                      'kernel_only_same_state_ms': ref,
                      'overhead_pct': None if ref is None else 100.0 * (ms / ref - 1.0),
-                     'overhead_vs_fresh_pct': 100.0 * (ms / kernel_only_ms - 1.0)}
+                     'overhead_vs_fresh_pct': None if 'default_precision' in name else 100.0 * (ms / kernel_only_ms - 1.0)}
     return out
+
+
+def _channels_in_effect():
+    from outdoor_nerf_depth_amd.dist_utils import rccl_channels_in_effect
+    return rccl_channels_in_effect()
 
 
 def main():
@@ -549,7 +582,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        for k, v in rccl_env_defaults().items():          # (under torchrun: before the communicator exists)
+        for k, v in rccl_env_defaults(args.rccl_channels).items():          # (under torchrun: before the communicator exists)
             os.environ.setdefault(k, v)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
@@ -569,8 +602,31 @@ def main():
     res = {}
     if world > 1 and args.precision == 'both':
         args.precision = 'bf16'                  # the scaling runs measure the headline precision only
+    abi_run, abi_error = None, None
     if args.precision in ('both', 'bf16'):
-        res['bf16'] = run_mode(args, L.PREC_BF16, rank, world, device, batches)
+        want = args.grad_comm if (world > 1 and backend == 'nccl') else 'torch'
+        if want in ('torch', 'both'):
+            res['bf16'] = run_mode(args, L.PREC_BF16, rank, world, device, batches)
+        if want in ('rccl_abi', 'both'):
+            # the same job through the library's own RCCL entry point (a second communicator, built over the first): a failure
+            # here must not cost the scaling run its torch number -- it is reported, not raised, when both were asked for
+            comm = None
+            try:
+                from outdoor_nerf_depth_amd.dist_utils import RcclComm
+                comm = RcclComm(rank, world)
+                abi_run = run_mode(args, L.PREC_BF16, rank, world, device, batches, comm=comm)
+            except Exception as e:                       # noqa: BLE001 (reported in the JSON line)
+                if want == 'rccl_abi':
+                    raise
+                abi_error = '%s: %s' % (type(e).__name__, e)
+            finally:
+                if comm is not None:
+                    try:
+                        comm.destroy()
+                    except Exception:                    # noqa: BLE001
+                        pass
+            if want == 'rccl_abi':
+                res['bf16'] = abi_run
     if args.precision in ('both', 'split'):
         res['split'] = run_mode(args, L.PREC_SPLIT_BF16, rank, world, device, batches)
     m360 = None
@@ -598,13 +654,24 @@ def main():
                                                              args.lambda_depth, args.n_rand),
                    'n_rand_per_gpu': args.n_rand, 'parallelism': 'dp%d (ray batches, RCCL grad all-reduce)' % world,
                    'setup_steps': SETUP_STEPS,
-                   'dist_backend': (('%s, %s' % (backend, ' '.join('%s=%s' % (k, os.environ.get(k)) for k in sorted(rccl_env_defaults()))))
+                   'dist_backend': (('%s, %s' % (backend, ' '.join('%s=%s' % (k, os.environ.get(k)) for k in ('NCCL_MAX_NCHANNELS', 'NCCL_MIN_NCHANNELS'))))
                                     if world > 1 else None),
                    # N > 1 diagnostics: each rank's own clock over the timed steps (ms per step, before the closing
                    # barrier) and the time per step its main stream waited for the side-stream parameter update (slab
                    # sum -> all-reduce -> Adam -> re-pack) that the next level's forward did not hide
                    'per_rank_ms_per_step': r['per_rank_ms_per_step'],
-                   'exposed_update_ms_per_step': r['exposed_update_ms_per_step']},
+                   'exposed_update_ms_per_step': r['exposed_update_ms_per_step'],
+                   # ... the duration of the 4.81 MB gradient all-reduce of each cascade level on every rank (ms, median over the
+                   # timed steps; HIP events on the stream it is issued on), the transport it went through, and the channel counts
+                   # RCCL's own INIT log reports for the communicators of rank 0 (null: gloo, or NCCL_DEBUG set by the caller)
+                   'grad_comm': (None if world == 1 else 'rccl_abi' if (args.grad_comm == 'rccl_abi' and backend == 'nccl') else 'torch'),
+                   'allreduce_ms': r['allreduce_ms'],
+                   'rccl_channels_in_effect': _channels_in_effect() if world > 1 else None,
+                   'grad_comm_rccl_abi': (None if abi_run is None or args.grad_comm != 'both' else
+                                          {'value': abi_run['value'], 'ms_per_step': abi_run['ms_per_step'],
+                                           'per_rank_ms_per_step': abi_run['per_rank_ms_per_step'],
+                                           'exposed_update_ms_per_step': abi_run['exposed_update_ms_per_step'],
+                                           'allreduce_ms': abi_run['allreduce_ms']}) if abi_error is None else {'error': abi_error}},
         'roofline': roofline(r),
         'final_loss': r['loss'],
         'gates': {
@@ -665,6 +732,11 @@ def main():
                                  'what': 'outdoor_nerf_depth_amd.ddp_train_nerf.ddp_train_nerf(), bf16, %d frames, device sampler, '
                                          'mean over the last 400 of %d steps' % (args.cli_frames, args.cli_steps)}
             out['trained_state_ms'] = d['kernel_only_same_state_ms']
+        d2 = out['cli_loop'].get('device_sampler_default_precision')
+        if d2:
+            out['end_to_end_default_precision'] = {'value': d2['rays_per_s'], 'unit': 'rays/s', 'ms_per_step': d2['ms_per_step'],
+                                                   'what': 'the same loop with the CLI default --precision split (split-bf16 everywhere: '
+                                                           'outputs, loss and gradients at float32 grade)'}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

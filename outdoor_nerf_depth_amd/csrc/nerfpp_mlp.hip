@@ -57,7 +57,7 @@ constexpr int SKEW_INFER = 0;          // weight blocks by which waves NW/2.. la
 constexpr int EXP = 0;                 // (probes: timing experiments with garbage results -- nerfpp_mlp_probes.h)
 constexpr int TRICKLE = 1;             // bit 0 / 1: ring / roles pipe issues a block's weight DMA in pieces between the MFMAs of the step
 constexpr int UNIT_VALU = 4;           // unit-pipelined split-bf16 kernels: VALU instructions dealt out behind each MFMA of a unit (0: the compiler's own order)
-constexpr int SPLIT_V2 = 3;            // bit 0 / 1: the split-bf16 inference / training forward runs the unit-pipelined body (nerfpp_mlp_split.h)
+constexpr int SPLIT_V2 = 7;            // bit 0 / 1 / 2: the split-bf16 inference forward / training forward / backward runs the unit-pipelined body (nerfpp_mlp_split.h)
 __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   const u32x4_ vv = {v.x, v.y, v.z, v.w};
@@ -478,7 +478,8 @@ __device__ __forceinline__ uint4 acc_to_frags_relu_bits(const f32x16 (&acc)[NOB]
         for (int w = 0; w < 4; ++w) {
           const int j = (ob & 1) * 8 + hh * 4 + w;
           // shift + ONE v_and_or_b32 per dword (left to itself the compiler pairs the ORs with v_or3_b32: 2.6 per dword)
-          asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(m[ob >> 1]) : "v"(d[w] >> j), "s"(0x80008000u >> j));
+          if constexpr ((probe::DBG & 128) == 0)        // (probes: no sign words -- the backward of such a forward is garbage)
+            asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(m[ob >> 1]) : "v"(d[w] >> j), "s"(0x80008000u >> j));
         }
         const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         h[2 * ob + hh].v[0] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, d), zero));
@@ -535,6 +536,23 @@ template <int NOB>
 __device__ __forceinline__ void init_bias_lds(f32x16 (&acc)[NOB], uint32_t lds_off_bytes, int hi) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   LDS_AS char* base = (LDS_AS char*)smem;
+  if constexpr ((probe::EXP & 16) != 0) {
+    // (probes, garbage results: what would the bias cost as a 17th k-chunk -- zero accumulators (free: the first MFMA takes the
+    // inline constant) and, with EXP bit 5, one more MFMA per out-block fed by ONE 1 KiB fragment read instead of four reads)
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
+      if constexpr ((probe::EXP & 32) != 0) {
+        const bf16x8 w = *(const bf16x8*)(smem + (lds_off_bytes & ~1023u) % 8192 + ob * 1024 + (threadIdx.x & 63) * 16);
+        bf16x8 one;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) one[t] = (__bf16)(t == 0 ? 1.f : 0.f);
+        acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, one, acc[ob], 0, 0, 0);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob) {
 #pragma unroll
@@ -802,7 +820,8 @@ __device__ __forceinline__ void encode_dir(const float (&vd)[3], int hi, Frag<P>
 template <int NET, int P, int NW, bool TRAIN>
 struct FwdLds {
   static constexpr bool V2T = split_v2_train<P, TRAIN>();
-  static constexpr int MODE = (!TRAIN || V2T) ? PIPE_RING : PIPE_ROLES;
+  // (probes, EXP bit 3: the training forward on the ring pipe -- only meaningful with the saves compiled out, NERFPP_DBG & 2)
+  static constexpr int MODE = (!TRAIN || V2T || (probe::EXP & 8) != 0) ? PIPE_RING : PIPE_ROLES;
   static constexpr bool ROLES = MODE == PIPE_ROLES;
   static constexpr int BF = V2T ? BLK_FRAGS : blk_frags_of<P, TRAIN>();
   // ring depth: as deep as the 160 KiB of LDS allow
@@ -893,10 +912,11 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
     if constexpr (!TRAIN) return;
     if (tail) zero_invalid(frags, valid);
     if constexpr (ROLES) {
+      if constexpr ((probe::DBG & 128) != 0) return;
       if (loader) *(uint4*)(region + RMASK + lane * 16) = bits;
       else mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
     } else {
-      mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
+      if constexpr ((probe::DBG & 128) == 0) mask_out[(size_t)mask_stage * nblk32 * 64] = bits;
       save_frags<16, P>(base, plane_rows * 256, 256, wrow0, lane, frags, NPS);
     }
   };
@@ -926,8 +946,10 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs& a, const int bid)
           if (wave <= H && blk >= 2 && blk < 2 + Q && Q * (wave - 1) + blk - 2 < 16)
             handoff_flush_chunks<P>(region, lane, base, plane_rows * 256, 256, tile_row0, Q * (wave - 1) + blk - 2, 1, NPS);
         }
-        if (partner && blk == 1)
-          mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
+        if constexpr ((probe::DBG & 128) == 0) {
+          if (partner && blk == 1)
+            mask_out[(size_t)mask_stage * nblk32 * 64 - 64] = *(const uint4*)(region + RMASK + lane * 16);
+        }
       }
     }
   };
@@ -1246,8 +1268,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void mlp_fwd_pair_kerne
 }
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64, (P == 1 ? 2 : 1)) void mlp_bwd_pair_kernel(MlpBwdArgs a0, MlpBwdArgs a1, int tiles0) {
-  if ((int)blockIdx.x < tiles0) mlp_bwd_body<0, P, NW>(a0, (int)blockIdx.x);
-  else mlp_bwd_body<1, P, NW>(a1, (int)blockIdx.x - tiles0);
+  if constexpr (P == 2 && (probe::SPLIT_V2 & 4) != 0) {
+    if ((int)blockIdx.x < tiles0) mlp_bwd_body_split<0, NW>(a0, (int)blockIdx.x);
+    else mlp_bwd_body_split<1, NW>(a1, (int)blockIdx.x - tiles0);
+  } else {
+    if ((int)blockIdx.x < tiles0) mlp_bwd_body<0, P, NW>(a0, (int)blockIdx.x);
+    else mlp_bwd_body<1, P, NW>(a1, (int)blockIdx.x - tiles0);
+  }
 }
 
 }  // namespace nerfpp
@@ -1273,7 +1300,7 @@ static void launch_bwd_t(hipStream_t st, const MlpBwdArgs& a0, const MlpBwdArgs&
   constexpr int NW = MLP_WAVES(P);
   const int tile = NW * 32;
   const int t0 = which == 2 ? 0 : (int)((a0.rows + tile - 1) / tile), t1 = which == 1 ? 0 : (int)((a1.rows + tile - 1) / tile);
-  constexpr size_t lds = BwdLds<P, NW>::TOTAL + probe::STAMP_BYTES;
+  constexpr size_t lds = ((P == 2 && (probe::SPLIT_V2 & 4) != 0) ? (size_t)BwdLdsV2<NW>::TOTAL : (size_t)BwdLds<P, NW>::TOTAL) + probe::STAMP_BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((mlp_bwd_pair_kernel<P, NW>), dim3(t0 + t1), dim3(NW * 64), lds, st, a0, a1, t0);
 }

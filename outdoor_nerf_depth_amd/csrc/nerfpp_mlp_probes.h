@@ -5,7 +5,8 @@
 //
 //   NERFPP_DBG bits: 1 drops the activation stores, 2 the saves altogether, 4 plain instead of
 //     non-temporal stores, 16 drops the loader hand-off, 32 folds every activation store into a 2 MiB window of out_raw
-//     (forward kernel; no HBM write traffic), 64 keeps the address math of the saves but drops the store instructions
+//     (forward kernel; no HBM write traffic), 64 keeps the address math of the saves but drops the store instructions,
+//     128 drops the ReLU sign words (gather + stores; bf16 forward)
 //   NERFPP_DBG_NO_DMA      no weight DMA (LDS holds stale bytes)
 //   NERFPP_DBG_NO_MFMA     no MFMAs (the weight fragment reads stay)
 //   NERFPP_STORE_FLAVOR    1 sc1 | 2 sc0 sc1 | 3 sc1 nt | 4 sc0 sc1 nt   (default: nt)
@@ -84,7 +85,7 @@ constexpr int SKEW_INFER = NERFPP_SKEW_INFER;
 #ifndef NERFPP_EXP
 #define NERFPP_EXP 0
 #endif
-constexpr int EXP = NERFPP_EXP;                   // timing experiments, garbage results: 1 the weight DMA is never waited for (ring pipe), 2 no block barrier (ring pipe), 4 the split-bf16 epilogue without its conversion work
+constexpr int EXP = NERFPP_EXP;                   // timing experiments, garbage results: 1 the weight DMA is never waited for (ring pipe), 2 no block barrier (ring pipe), 4 the split-bf16 epilogue without its conversion work, 8 the training forward on the ring pipe (with NERFPP_DBG & 2: no saves), 16 zero accumulators instead of the bias reads, 32 (with 16) one extra MFMA per out-block and stage (the bias as a 17th k-chunk)
 #ifndef NERFPP_TRICKLE
 #define NERFPP_TRICKLE 1
 #endif
@@ -94,9 +95,9 @@ constexpr int TRICKLE = NERFPP_TRICKLE;           // bit 0 / 1: the ring / roles
 #endif
 constexpr int UNIT_VALU = NERFPP_UNIT_VALU;       // unit-pipelined split-bf16 kernels: VALU instructions dealt out behind each MFMA of a unit (0: the compiler's own order)
 #ifndef NERFPP_SPLIT_V2
-#define NERFPP_SPLIT_V2 3
+#define NERFPP_SPLIT_V2 7
 #endif
-constexpr int SPLIT_V2 = NERFPP_SPLIT_V2;         // bit 0 / 1: the split-bf16 inference / training forward runs the unit-pipelined body (0: the stage-at-a-time bodies)
+constexpr int SPLIT_V2 = NERFPP_SPLIT_V2;         // bit 0 / 1 / 2: the split-bf16 inference forward / training forward / backward runs the unit-pipelined body (0: the stage-at-a-time bodies)
 constexpr int SKIP_H = NERFPP_SKIP_H;             // bit l: the bf16 training forward leaves H_l unsaved (what would one-layer recompute in dw_kernel buy?)
 constexpr int LDS_REUSE = NERFPP_LDS_REUSE;       // 2: one weight-fragment read per two MFMAs (what 64-row waves would need); with NERFPP_LDS_PREFETCH=0
 

@@ -372,4 +372,169 @@ __device__ __forceinline__ void mlp_fwd_body_split(const MlpFwdArgs& a, const in
   probe::dump_stamps(LD::TOTAL, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// backward (dX chain), same construction: units, lazy epilogue (dH accumulators -> raw copy -> masked hi / lo chunks of dZ, one
+// chunk per k-chunk ahead of the MFMAs that consume it), ring pipe with a 2-slot ring of 16-fragment blocks, no wave roles: every
+// wave loads its own ReLU sign words (16 B per lane and stage, one stage ahead) and stores the chunks of its own dZ tiles right
+// behind their conversion.  Same MFMA chains and conversions as mlp_bwd_body<NET, 2, NW>: bit-identical dZ tensors.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int NW>
+struct BwdLdsV2 {
+  static constexpr int BF = BLK_FRAGS, NBUF = 2;
+  static constexpr int W = NBUF * BF * 2 * FRAG_BYTES;
+  static constexpr int TOTAL = W;
+};
+
+// chunk c = 2 ob + hh of dZ: the accumulator registers 8 hh .. 8 hh + 7 of out-block ob, masked by the forward's sign words
+// (arithmetic of mask_to_frags<.., 2>)
+__device__ __forceinline__ void conv_chunk_mask(const float (&raw_ob)[16], int ob, int hh, const uint4 bits, Frag<2>& out) {
+  const uint32_t act[4] = {~bits.x, ~bits.y, ~bits.z, ~bits.w};       // bit set = unit active
+  u32x4 dh, dl;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float a = raw_ob[8 * hh + 2 * w], b = raw_ob[8 * hh + 2 * w + 1];
+    const int j = (ob & 1) * 8 + hh * 4 + w;
+    const uint32_t keep = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, act[ob >> 1] << j) >> (s16x2){15, 15});
+    const uint32_t hi = pack2<1>(a, b);
+    const uint32_t lo = pack2<1>(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+    dh[w] = hi & keep;
+    dl[w] = lo & keep;
+  }
+  out.v[0] = __builtin_bit_cast(bf16x8, dh);
+  out.v[1] = __builtin_bit_cast(bf16x8, dl);
+}
+
+template <int NET, int NW>
+__device__ __forceinline__ void mlp_bwd_body_split(const MlpBwdArgs& a, const int bid) {
+  constexpr int P = 2;
+  using LD = BwdLdsV2<NW>;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5;
+  const size_t row_raw = (size_t)bid * (NW * 32) + wave * 32 + (lane & 31);
+  const bool valid = row_raw < (size_t)a.rows;
+  const size_t row = valid ? row_raw : (size_t)a.rows - 1;
+  const size_t plane_rows = a.rows_padded;
+  const size_t wrow0 = (size_t)bid * (NW * 32) + wave * 32;
+  const size_t nblk32 = a.rows_padded / 32;
+  const uint4* mask_in = a.masks + (wrow0 / 32) * 64 + lane;             // + stage * nblk32 * 64
+
+  WeightPipe<P, NW, PIPE_RING, LD::NBUF, LD::BF> pipe;
+  pipe.stamp_off = LD::TOTAL;
+  pipe.init(a.w_stream, BWD_FRAGS / LD::BF, wave, lane);
+  UnitFeed<decltype(pipe), true> feed(pipe);
+  constexpr int GUN = BWD_FRAGS / 4;
+
+  float4 d = ((const float4*)a.d_out)[row];
+  if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);                        // rows past the end: zero gradients, zero dZ everywhere
+  uint4 mk8 = mask_in[(size_t)8 * nblk32 * 64], mk7 = mask_in[(size_t)7 * nblk32 * 64];
+  {
+    // dP [rows, 32] and dS [rows, 32] (chunks 0, 1 of [dS | dG]) come straight from d_out
+    Frag<P> t[2];
+    t[0] = zero_frag<P>(); t[1] = zero_frag<P>();
+    if (hi == 0) { set_slot<P>(t[0], 0, d.x); set_slot<P>(t[0], 1, d.y); set_slot<P>(t[0], 2, d.z); }
+    save_frags<2, P>(a.ws.t[T_DP], plane_rows * 32, 32, wrow0, lane, t);
+    t[0] = zero_frag<P>();
+    if (hi == 0) set_slot<P>(t[0], 0, d.w);
+    save_frags<2, P>(a.ws.t[T_DS], plane_rows * DSG_LD, DSG_LD, wrow0, lane, t);
+  }
+  auto store = [&](__bf16* base, int ld, int c, const Frag<P>& f) __attribute__((always_inline)) {
+    store_chunk<P>(base, plane_rows * ld, ld, wrow0, lane, c, f);
+  };
+  auto zero_ob = [&](f32x16& acc_ob) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_ob[r] = 0.f;
+  };
+
+  feed.fetch(0);
+  float raw[8][16];
+  // B0: dG = Wrgb1^T dP (one live k-chunk), masked by G > 0 (sign words 8)
+  Frag<P> dg[8];
+  {
+    Frag<P> in0 = zero_frag<P>();
+    if (hi == 0) { set_slot<P>(in0, 0, d.x); set_slot<P>(in0, 1, d.y); set_slot<P>(in0, 2, d.z); }
+    f32x16 acc4[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) zero_ob(acc4[ob]);
+    stage_units<4, 4, 1, bs_frag_off(BS_DG) / 4, GUN>(feed, acc4,
+      [&](int) -> const Frag<P>& { return in0; },
+      [&](int i) __attribute__((always_inline)) {
+        if (i == 1) {                                                     // (units 1-3 are block padding: no MFMAs)
+#pragma unroll
+          for (int ob = 0; ob < 4; ++ob) raw_copy_ob(acc4[ob], raw[ob]);
+          conv_chunk_mask(raw[0], 0, 0, mk8, dg[0]);
+          store(a.ws.t[T_DG], DSG_LD, 0, dg[0]);
+        }
+      });
+  }
+  // B2: dH7 = Wc^T dG + wsigma dsigma (8 dG chunks, the dsigma chunk, one chunk of padding), masked by H7 > 0
+  f32x16 acc[8];
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) zero_ob(acc[ob]);
+  Frag<P> dsig = zero_frag<P>();
+  if (hi == 0) set_slot<P>(dsig, 0, d.w);
+  auto retire = [&](int ob0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ob = ob0; ob < ob0 + 4; ++ob) { raw_copy_ob(acc[ob], raw[ob]); zero_ob(acc[ob]); }
+  };
+  Frag<P> dza[16], dzb[16];
+  float raw4[4][16];                                                       // (B0's raw values live through B2 while `raw` takes B2's)
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) raw4[ob][e] = raw[ob][e];
+  stage_units<8, 10, 9, bs_frag_off(BS_DH7) / 4, GUN>(feed, acc,
+    [&](int kc) -> const Frag<P>& { return kc < 8 ? dg[kc < 8 ? kc : 0] : dsig; },
+    [&](int i) __attribute__((always_inline)) {
+      const int kc = i >> 1, half = i & 1;
+      if (half == 0 && kc + 1 <= 7) {
+        const int c = kc + 1;
+        conv_chunk_mask(raw4[c >> 1], c >> 1, c & 1, mk8, dg[c]);
+        store(a.ws.t[T_DG], DSG_LD, c, dg[c]);
+      }
+      if (i == 19) {                                                       // (kc = 9 is padding: out-blocks 0-3 have long been final)
+        retire(0);
+        conv_chunk_mask(raw[0], 0, 0, mk7, dza[0]);
+        store(a.ws.t[T_DZ0 + 7], 256, 0, dza[0]);
+      }
+    });
+  // B3 .. B9: dH_{l-1} = W_l^T dZ_l, l = 7 .. 1; dZ_l is converted lazily from the previous stage's raw copy with sign words l
+  auto trunk = [&](auto l_c, Frag<P> (&zin)[16], Frag<P> (&zout)[16], const uint4 mk_in, uint4& mk_out) __attribute__((always_inline)) {
+    constexpr int l = decltype(l_c)::value;
+    constexpr int GU0 = bs_frag_off(10 - l) / 4;
+    __bf16* const base_in = a.ws.t[T_DZ0 + l];
+    stage_units<8, 16, 16, GU0, GUN>(feed, acc,
+      [&](int kc) -> const Frag<P>& { return zin[kc]; },
+      [&](int i) __attribute__((always_inline)) {
+        const int kc = i >> 1, half = i & 1;
+        if (i == 0) { retire(4); mk_out = mask_in[(size_t)(l - 1) * nblk32 * 64]; }   // (this unit's MFMAs go to out-blocks 0-3)
+        if (half == 0 && kc + 1 <= 15) {
+          const int c = kc + 1;
+          conv_chunk_mask(raw[c >> 1], c >> 1, c & 1, mk_in, zin[c]);
+          store(base_in, 256, c, zin[c]);
+        }
+        if (i == 31) {
+          retire(0);
+          conv_chunk_mask(raw[0], 0, 0, mk_out, zout[0]);
+          store(a.ws.t[T_DZ0 + l - 1], 256, 0, zout[0]);
+        }
+      });
+  };
+  uint4 mka = mk7, mkb;
+  trunk(IC(7), dza, dzb, mka, mkb);
+  trunk(IC(6), dzb, dza, mkb, mka);
+  trunk(IC(5), dza, dzb, mka, mkb);
+  trunk(IC(4), dzb, dza, mkb, mka);
+  trunk(IC(3), dza, dzb, mka, mkb);
+  trunk(IC(2), dzb, dza, mkb, mka);
+  trunk(IC(1), dza, dzb, mka, mkb);
+  // dZ0: no stage consumes it -- the rest of the tile is converted and written here (chunk 0: the last unit above)
+  retire(4);
+#pragma unroll
+  for (int c = 1; c < 16; ++c) {
+    conv_chunk_mask(raw[c >> 1], c >> 1, c & 1, mkb, dzb[c]);
+    store(a.ws.t[T_DZ0], 256, c, dzb[c]);
+  }
+  probe::dump_stamps(LD::TOTAL, wave, lane);
+}
+
 }  // namespace nerfpp

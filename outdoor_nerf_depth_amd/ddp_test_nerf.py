@@ -32,7 +32,7 @@ def ddp_test_nerf(rank, args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ['MASTER_PORT'] = str(args.port)
         from .dist_utils import apply_rccl_env_defaults
-        apply_rccl_env_defaults()
+        apply_rccl_env_defaults(world, None if getattr(args, 'rccl_channels', -1) < 0 else args.rccl_channels)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     cascade = tuple(int(x.strip()) for x in args.cascade_samples.split(','))
     # forward only: bf16, the two-pass fp16x2w forward (1e-4 outputs), or split-bf16 (also for split_fwd: the same forward)

@@ -146,6 +146,11 @@ def config_parser():
     p.add_argument('--grad_comm', choices=['torch', 'rccl_abi'], default='torch',
                    help="gradient all-reduce: torch.distributed (backend nccl = RCCL), or the library's own RCCL entry point "
                         '(nerfpp_allreduce_mean; the communicator id travels over the torch process group)')
+    p.add_argument('--rccl_channels', type=int, default=-1,
+                   help='cap on the RCCL channels of the gradient all-reduce (NCCL_MAX_NCHANNELS; every channel holds a CU that an '
+                        'MLP tile cannot use).  -1 (default): 4 when all ranks run on one node, RCCL\'s own choice across nodes; '
+                        "0: never touch RCCL's environment; N > 0: N, also across nodes.  NCCL_* variables set by the caller always win; "
+                        'the values in effect are logged on every rank')
     p.add_argument('--synthetic', action='store_true', help='KITTI-shaped procedural scene, no datadir')
     p.add_argument('--synthetic_hw', type=str, default=None, help="'H,W' of the synthetic frames (default 375,1242)")
     p.add_argument('--synthetic_frames', type=int, default=295)
@@ -349,9 +354,9 @@ def ddp_train_nerf(rank, args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ['MASTER_PORT'] = str(args.port)
         from .dist_utils import apply_rccl_env_defaults
-        eff = apply_rccl_env_defaults()          # few channels: a CU RCCL holds is a CU a tile cannot use (dist_utils.py)
-        if rank == 0:
-            logger.info('RCCL: ' + ' '.join('%s=%s' % kv for kv in sorted(eff.items())))
+        # few channels: a CU RCCL holds is a CU a tile cannot use (dist_utils.py); process-global, so only on one node by default
+        eff = apply_rccl_env_defaults(world, None if args.rccl_channels < 0 else args.rccl_channels)
+        logger.info('rank %d RCCL environment: %s' % (rank, ' '.join('%s=%s' % kv for kv in sorted(eff.items())) or "RCCL's defaults"))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL (gloo upstream, :298)
 
     # batch sizes by GPU memory                                      ddp_train_nerf.py:364-373
@@ -414,6 +419,11 @@ def ddp_train_nerf(rank, args):
                             depth_sigma=args.depth_sigma, depth_scale=depth_scale, world_size=world,
                             optim_autoexpo=args.optim_autoexpo, img_names=img_names,
                             lambda_autoexpo=args.lambda_autoexpo, seed=(rank + 1) * 777, comm=comm)   # :406-408
+    if rank == 0:
+        # (the default is the slowest mode -- say so at start-up, with the alternatives and what they cost / keep)
+        logger.info('precision = %s%s.  Relative throughput on one MI355X (bench.py, round 6): bf16 1.0, fp16_fwd 0.81, split_fwd 0.67, '
+                    'split 0.40; split / split_fwd keep rendered RGB, depth and loss within 1e-4 of the float32 reference (split also the '
+                    'gradients), bf16 is at bf16 grade (1e-2) -- see --help' % (args.precision, ' (the default)' if args.precision == 'split' else ''))
     ckpt, start = find_latest_checkpoint(args)
     if ckpt is not None:
         logger.info('Reloading from: {}'.format(ckpt))

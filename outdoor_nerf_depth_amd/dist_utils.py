@@ -12,11 +12,60 @@ import torch
 RCCL_ENV_DEFAULTS = {'NCCL_MAX_NCHANNELS': '4', 'NCCL_MIN_NCHANNELS': '2'}
 
 
-def apply_rccl_env_defaults():
-    """Call before init_process_group('nccl') / RcclComm(): returns the values in effect."""
-    for k, v in RCCL_ENV_DEFAULTS.items():
+def single_node(world_size=None):
+    """True when every rank of the job runs on this host (torchrun exports LOCAL_WORLD_SIZE; the spawn launchers of this
+    package are single-node by construction)."""
+    world = int(world_size if world_size is not None else os.environ.get('WORLD_SIZE', '1'))
+    local = os.environ.get('LOCAL_WORLD_SIZE')
+    return local is None or int(local) >= world
+
+
+def apply_rccl_env_defaults(world_size=None, channels=None):
+    """Call before init_process_group('nccl') / RcclComm(): returns the values in effect ({} = RCCL's own defaults).
+    The channel cap is tuned for ONE xGMI node (see above) and is process-global -- it also binds every other RCCL communicator
+    of the process -- so it is applied only when the job fits one node; `channels` (the CLIs' --rccl_channels): 0 = leave RCCL
+    alone, N > 0 = NCCL_MAX_NCHANNELS = N (min(2, N) as the minimum) also across nodes.  A caller's own NCCL_* settings win."""
+    if channels is not None and int(channels) == 0:
+        return {k: os.environ[k] for k in RCCL_ENV_DEFAULTS if k in os.environ}
+    if channels is not None and int(channels) > 0:
+        want = {'NCCL_MAX_NCHANNELS': str(int(channels)), 'NCCL_MIN_NCHANNELS': str(min(2, int(channels)))}
+    elif single_node(world_size):
+        want = RCCL_ENV_DEFAULTS
+    else:
+        want = {}
+    for k, v in want.items():
         os.environ.setdefault(k, v)
-    return {k: os.environ[k] for k in RCCL_ENV_DEFAULTS}
+    return {k: os.environ[k] for k in RCCL_ENV_DEFAULTS if k in os.environ}
+
+
+def rccl_debug_file_env(tag='nerfpp'):
+    """Environment that makes RCCL write its INIT lines to a per-process file (unless the caller configured NCCL_DEBUG
+    already): the channel count a communicator actually got is only visible there (no public query)."""
+    if 'NCCL_DEBUG' in os.environ:
+        return {}
+    import tempfile
+    return {'NCCL_DEBUG': 'INFO', 'NCCL_DEBUG_SUBSYS': 'INIT',
+            'NCCL_DEBUG_FILE': os.path.join(tempfile.gettempdir(), '%s_rccl_%%h_%%p.log' % tag)}
+
+
+def rccl_channels_in_effect():
+    """Parse this process's RCCL debug file (rccl_debug_file_env) for the channel counts of its communicators: a list of
+    {'coll': n, 'p2p': m} in creation order, or None when there is no file / no such line (gloo, NCCL_DEBUG set by the caller)."""
+    import re
+    import socket
+    path = os.environ.get('NCCL_DEBUG_FILE')
+    if not path:
+        return None
+    path = path.replace('%h', socket.gethostname()).replace('%p', str(os.getpid()))
+    try:
+        with open(path) as f:
+            text = f.read()
+    except OSError:
+        return None
+    found = []
+    for m in re.finditer(r'(\d+) coll channels(?:, (\d+) collnet channels)?(?:, (\d+) nvls channels)?, (\d+) p2p channels', text):
+        found.append({'coll': int(m.group(1)), 'p2p': int(m.group(4))})
+    return found or None
 
 
 def allreduce_mean_(flat, world_size, prescaled=False):

@@ -294,6 +294,7 @@ def prop_mlp_fm(enc_buf, x_col0, ldx, rows, w_fm, ldw, bias, wd, bd, density, h=
 
 
 # MIP360_NO_DEFER_DW=1: the NerfMLP's trunk weight gradients stay one launch per layer between the dX layers (A/B runs)
+DEFER_DW_MAX_BYTES = 8 << 30         # dZ bytes the deferred weight-gradient launch may keep alive (mlp_backward_fm)
 USE_DEFER_DW = os.environ.get('MIP360_NO_DEFER_DW') is None
 # MIP360_NO_MULTI_DW=1: the PropMLP's four weight-gradient GEMMs stay four launches (A/B runs)
 USE_MULTI_DW = os.environ.get('MIP360_NO_MULTI_DW') is None
@@ -905,7 +906,9 @@ def _grad_weight_fm_multi(tm, items, rows, scratch):
     on the chip together the layers need ksplit ~ 256 / tiles row slices: 48 for the PropMLP's 5 tiles, 2 for the NerfMLP's 128."""
     W, G, n = tm.W, tm.grads, len(items)
     tiles = sum((it[4] // 256) * (W // 256) for it in items)
-    ks = max(1, min(256 // tiles, rows // 32))
+    # row slices per tile: enough to fill the 256 CUs once; more than 256 tiles fill them by themselves (one slice: the tiles
+    # then take several rounds), and a slice is at least one 32-row chunk
+    ks = 1 if tiles >= 256 else max(1, min(256 // tiles, rows // 32))
     while ks > 1 and (tiles * ks) % 8:                       # whole XCD rounds (the launch deals workgroups XCD-major)
         ks -= 1
     sizes = [ks * (it[4] * W + W) for it in items]
@@ -992,7 +995,13 @@ def mlp_backward_fm(tm, saved, rows, g_density, g_rgb, scratch):
                                                _p(scratch[0]), _p(tm.kernel(D, G)), 1.0, _p(tm.bias(D, G))), 'mip360_grad_weight_col_fm')
         # dZ of the last trunk layer: both heads in one GEMM, masked by relu'(H_{D-1})
         linear_fm(heads_fm, tm.wb_fm['heads'], None, 2, rows, W, tm.head_k, dz, saved['masks'][D - 1])
+    # The deferred form keeps all D dZ tensors alive until its one launch (D x rows x W x 2 B: 2.1 GB at 131 072 rows of the
+    # 1024-wide NerfMLP) next to slab scratch for all layers: only while that is a small share of the free memory (ADVICE r05:
+    # a larger batch or width must fall back to the per-layer launches instead of raising peak memory sharply)
     defer = USE_DEFER_DW and D <= 8 and all(saved['inputs'][i][3] % 256 == 0 for i in range(D))
+    if defer:
+        retained = (D - 1) * rows * W * 2
+        defer = retained <= DEFER_DW_MAX_BYTES and retained <= torch.cuda.mem_get_info(dev)[0] // 4
     pending = []
     for i in reversed(range(D)):
         x, x_col0, x_ld, x_k = saved['inputs'][i]

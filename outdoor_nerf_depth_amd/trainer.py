@@ -87,6 +87,10 @@ class NerfppTrainer(object):
         # the main stream's wait for the side-stream update -- the part of [slab sum, all-reduce, Adam, re-pack] that the
         # next level's sampling + forward did NOT hide
         self.wait_taps = None
+        # diagnostic (bench.py, N > 1): when a list, every gradient all-reduce appends (level, begin, end) timing events recorded
+        # around it on the stream it is issued on -- the duration of the collective as the GPU saw it (queueing behind the slab
+        # sum included in `begin`'s position, not in the interval)
+        self.comm_taps = None
 
     # -- parameter update ----------------------------------------------------------------------------
     def _update(self, m, step):
@@ -109,10 +113,17 @@ class NerfppTrainer(object):
                     self.comm.allreduce_mean(self._ae_grad[m].view(-1), prescaled=True)
                 else:
                     dist.all_reduce(self._ae_grad[m])
+            tap = None
+            if self.comm_taps is not None:
+                tap = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                tap[0].record()
             if self.comm is not None:
                 self.comm.allreduce_mean(self.grads[m], prescaled=True)      # grads carry 1 / world_size already (grad_scale)
             else:
                 dist.all_reduce(self.grads[m])
+            if tap is not None:
+                tap[1].record()
+                self.comm_taps.append((m, tap[0], tap[1]))
         ops.adam_step(eng.params, self.grads[m][:L.LEVEL_PARAMS], self.exp_avg[m], self.exp_avg_sq[m], step, lr=self.lrate,
                       skip=flag)
         eng.repack()

@@ -279,6 +279,18 @@ def test_bench_gpus_8_shared_gpu_smoke():
     assert all(0 < t <= r['ms_per_step'] * 1.001 for t in per_rank)          # the reported time is the slowest rank's
     assert all(e >= 0 for e in exposed)
     assert all(np.isfinite(r['final_loss']))
+    # first-contact diagnostics of a scaling run: the gradient all-reduce of each cascade level timed on
+    # every rank, the transport named, the channel counts read back from RCCL's INIT log where there is an RCCL
+    ar = r['config']['allreduce_ms']
+    assert sorted(ar) == ['level0', 'level1'] and all(len(v) == 8 and all(t > 0 for t in v) for v in ar.values())
+    assert r['config']['grad_comm'] == 'torch'
+    if r['config']['dist_backend'].startswith('nccl'):
+        ch = r['config']['rccl_channels_in_effect']
+        assert ch and all(c['coll'] >= 1 for c in ch), ch
+        second = r['config']['grad_comm_rccl_abi']                            # --grad_comm both is the default
+        assert second and ('error' in second or (second['value'] > 0 and len(second['allreduce_ms']['level1']) == 8)), second
+    else:
+        assert r['config']['rccl_channels_in_effect'] is None and r['config']['grad_comm_rccl_abi'] is None
 
 
 def _worker_render8(rank, world, port, out_path, H, W):

@@ -170,16 +170,26 @@ def test_training_trajectory_psnr_against_reference(mode):
     and with each depth term of the BASELINE configs (gt + mse, stereo_crop + l1, mono_crop + kl); the HIP trainer replays the
     same batches and uniforms in every precision mode.
     Gates, all modes: the logged rgb loss follows the reference's over the first 100 steps (EARLY_GATE), the logged depth loss
-    over the first 50 (DEPTH_EARLY_GATE).
-    rgb-only and gt + mse: every precision ends within max(0.05 dB, k x the reference's own float64-float32 spread) of the
-    float32 reference in render PSNR and in the mean in-loop PSNR of the last 25 steps (north_star's PSNR clause); k = 2 for
-    split-bf16, 3 for the bf16-gradient modes (PSNR_SPREADS above).
-    stereo_crop + l1 and mono_crop + kl: at step 200 these runs are in the steep part of training (25 -> 35 dB between steps 200
-    and 1000) and ANY perturbation moves the PSNR AT A FIXED STEP by tenths of a dB to 2 dB in either direction -- split-bf16,
-    which reproduces the reference's arithmetic to 1e-5, ends -0.70 / -0.24 dB (kl) and +0.02 / -0.03 dB (l1) from it, the
-    bf16-gradient modes -2 ... +1.6 dB depending on the seed (tools/probes/traj_seeds.py, profiles/r04_traj_seeds.md: sign of
-    the gap varies, gone by step 1000).  No single-run PSNR gate there: the early-step gate pins every mode to the reference's
-    trajectory, and test_bf16_gradient_modes_match_split_bf16_over_seeds gates the PSNR statistically."""
+    over the first 50 (DEPTH_EARLY_GATE) -- the deterministic part: every mode starts ON the reference's trajectory.
+    rgb-only: every precision ends within max(0.05 dB, k x the reference's own float64-float32 spread) of the float32
+    reference in render PSNR and in the mean in-loop PSNR of the last 25 steps (north_star's PSNR clause); k = 2 for split-bf16,
+    3 for the bf16-gradient modes (PSNR_SPREADS above).  Measured: <= 0.005 dB.
+    With a depth term the PSNR at a FIXED STEP of ONE run is a chaotic readout: the reference's own float64 run ends
+    0.09-0.14 dB from its float32 run, and every change of a summation order inside a kernel re-draws the HIP gaps -- split-bf16
+    on gt + mse read +0.11 / +0.17 dB (round 4), +0.125 / +0.205 (round 5), +0.055 / +0.102 (round 6) against a 2-spread gate of
+    0.209 / 0.253: a gate that sits at 40-80 % of itself depending on which bits moved is a coin, not a test.
+    stereo_crop + l1 and mono_crop + kl are worse: at step 200 they are in the steep part of training (25 -> 35 dB between
+    steps 200 and 1000) and any perturbation moves the fixed-step PSNR by tenths of a dB to 2 dB in either direction.
+    So with a depth term the PSNR clause is NOT gated on this single run; it is gated where it can be resolved:
+      * split-bf16 against the imported reference's own runs, paired over the 4 seeds of tests/golden/trajectory_seeds.npz at
+        1000 steps (tests/test_gpu_round5.py::test_split_bf16_matches_the_reference_seeds: |median gap| <= 0.05 dB + 2 SE, no gap
+        beyond 3 sigma of a difference of two reference runs).  Measured on the round-6 kernels, gt + mse: render median +0.046 dB,
+        tail median +0.002 dB against gates of 0.164 / 0.178 dB -- margins 3.6x / 100x; largest single gap 0.226 / 0.194 dB against
+        0.424 / 0.535 (1.9x / 2.8x);
+      * the bf16-gradient modes against split-bf16, paired over 8 seeds at 1000 steps
+        (test_bf16_gradient_modes_match_split_bf16_over_seeds below; 32 seeds and BASELINE's shape: tools/probes/traj_seeds*.py).
+    What stays here for gt + mse is a SANITY bound of 5 x the reference's float64-float32 spread (0.52 / 0.63 dB; every
+    measured gap of every mode and round is <= 0.28 dB: >= 2x margin) -- it catches a broken loss term, it is not the clause."""
     import trajectory_common as TC
     g = np.load(os.path.join(GOLD, 'trajectory.npz'))
     ref_psnr = float(g[mode + '.f32.render_psnr'])
@@ -208,9 +218,13 @@ def test_training_trajectory_psnr_against_reference(mode):
     f64_tail = float(np.mean(TC.psnr(g[mode + '.f64.tail_rgb_mse'][:, 1])))
     steep = mode in ('l1', 'kl')
     tols = {name: psnr_tolerances(g, mode, name) for name in ('split_bf16', 'split_fwd', 'bf16')}
+    if mode == 'mse':            # a depth term: sanity bound only (docstring); the clause is gated by the paired multi-seed tests
+        tols = {name: (max(0.05, 5.0 * f64_gap), max(0.05, 5.0 * abs(f64_tail - ref_tail))) for name in tols}
     report['gate'] = {'tolerances_db_render_tail': tols, 'spreads': PSNR_SPREADS, 'reference_f64_gap_db': f64_gap,
                       'reference_f64_tail_gap_db': f64_tail - ref_tail, 'early': EARLY_GATE,
-                      'psnr_gated': [] if steep else ['split_bf16', 'split_fwd', 'bf16']}
+                      'psnr_gated': [] if steep else ['split_bf16', 'split_fwd', 'bf16'],
+                      'psnr_gate_kind': 'none (steep part of training)' if steep else 'sanity bound, 5 x the float64-float32 spread' if mode == 'mse'
+                                        else 'clause: k x the float64-float32 spread'}
     _dump('trajectory_%s.json' % mode, report)
     for name in ('split_bf16', 'split_fwd', 'bf16'):
         for key in ('logged_rgb_mse_rel_dev', 'logged_rgb0_mse_rel_dev'):

@@ -272,7 +272,12 @@ def test_split_bf16_matches_the_reference_seeds(mode):
     (i) every run's early part is ON the reference's trajectory (logged rgb loss at steps 25 ... 100 within EARLY_GATE);
     (ii) the paired gaps of the in-loop tail PSNR and of the final render PSNR are inside the reference's own spread:
          |median gap| <= 0.05 dB + 2 SE with SE >= sigma_ref / sqrt(n) (the seed spread of the reference is what n runs of ANY
-         faithful implementation scatter by), and no single gap beyond 3 sigma_ref.
+         faithful implementation scatter by), and no single gap beyond 3 sigma of a DIFFERENCE of two such runs,
+         3 sqrt(2) max(sigma_ref, 0.1 dB) (round 6: until then 3 sigma_ref, i.e. 2.1 sigma of what it bounds -- a bound that eight
+         chaotic readouts cross by chance every few kernel revisions).
+         Measured on the round-6 kernels: gt + mse medians +0.046 (render) / +0.002 dB (tail) against gates 0.164 / 0.178, largest
+         single gaps 0.226 / 0.194 against 0.424 / 0.535; mono_crop + kl medians +0.136 / +0.037 against 0.573 / 0.393, largest gaps
+         0.608 / 0.267 against 1.62 / 0.905: every margin >= 1.9x.
     This is what validates split-bf16 as the reference's stand-in in the multi-seed precision tests (tests/test_gpu_round4.py)."""
     import trajectory_common as TC
     import test_gpu_round4 as R4
@@ -302,4 +307,4 @@ def test_split_bf16_matches_the_reference_seeds(mode):
     for gap, sig in ((gap_r, sig_r), (gap_t, sig_t)):
         se = max(R4.median_se(gap), sig / np.sqrt(n))
         assert abs(np.median(gap)) <= 0.05 + 2.0 * se, report
-        assert np.abs(gap).max() <= 3.0 * max(sig, 0.1), report
+        assert np.abs(gap).max() <= 3.0 * np.sqrt(2.0) * max(sig, 0.1), report

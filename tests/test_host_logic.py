@@ -304,3 +304,38 @@ def test_committed_pmc_profile_matches_kernel_sources():
     assert 'stale' not in t, t['stale']
     assert t['dw_L1'] > 1e9 and t['mlp_fwd_L1'] > 1e8 and t['mlp_bwd_L1'] > 1e8
     assert bench.kernel_sources_sha256() in t['source']
+
+
+def test_rccl_env_defaults_single_node_only_and_channel_log_parser(tmp_path, monkeypatch):
+    """ADVICE r05 / VERDICT r05 item 5: the channel cap is process-global and tuned for one xGMI node -- applied by default only
+    when every rank is local, overridable (--rccl_channels), never over the caller's own NCCL_* settings; and the channel count a
+    communicator actually got is read back from RCCL's INIT log."""
+    for k in ('NCCL_MAX_NCHANNELS', 'NCCL_MIN_NCHANNELS', 'LOCAL_WORLD_SIZE', 'WORLD_SIZE', 'NCCL_DEBUG', 'NCCL_DEBUG_FILE'):
+        monkeypatch.delenv(k, raising=False)
+    assert D.single_node(8)                                                   # no launcher environment: this package's own spawn
+    assert D.apply_rccl_env_defaults(8) == {'NCCL_MAX_NCHANNELS': '4', 'NCCL_MIN_NCHANNELS': '2'}
+    for k in ('NCCL_MAX_NCHANNELS', 'NCCL_MIN_NCHANNELS'):
+        monkeypatch.delenv(k)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')                               # 2 nodes x 8: RCCL keeps its own defaults
+    assert not D.single_node(16) and D.apply_rccl_env_defaults(16) == {}
+    assert D.apply_rccl_env_defaults(16, channels=6) == {'NCCL_MAX_NCHANNELS': '6', 'NCCL_MIN_NCHANNELS': '2'}
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '12')                            # the caller's value wins
+    assert D.apply_rccl_env_defaults(8, channels=3)['NCCL_MAX_NCHANNELS'] == '12'
+    for k in ('NCCL_MAX_NCHANNELS', 'NCCL_MIN_NCHANNELS'):
+        monkeypatch.delenv(k, raising=False)
+    assert D.apply_rccl_env_defaults(8, channels=0) == {}                     # 0: hands off
+    # the INIT log
+    env = D.rccl_debug_file_env('t')
+    assert env['NCCL_DEBUG'] == 'INFO' and env['NCCL_DEBUG_SUBSYS'] == 'INIT' and '%h' in env['NCCL_DEBUG_FILE'] and '%p' in env['NCCL_DEBUG_FILE']
+    assert D.rccl_channels_in_effect() is None                                # no NCCL_DEBUG_FILE
+    path = str(tmp_path / 'rccl_%h_%p.log')
+    monkeypatch.setenv('NCCL_DEBUG_FILE', path)
+    assert D.rccl_channels_in_effect() is None                                # no such file
+    real = path.replace('%h', socket.gethostname()).replace('%p', str(os.getpid()))
+    with open(real, 'w') as f:
+        f.write('host:1:1 [0] NCCL INFO comm 0x1 rank 0 nranks 8 cudaDev 0 busId 1000 - Init START\n'
+                'host:1:1 [0] NCCL INFO 4 coll channels, 0 collnet channels, 0 nvls channels, 8 p2p channels, 2 p2p channels per peer\n'
+                'host:1:1 [0] NCCL INFO 2 coll channels, 4 p2p channels, 1 p2p channels per peer\n')
+    assert D.rccl_channels_in_effect() == [{'coll': 4, 'p2p': 8}, {'coll': 2, 'p2p': 4}]
+    monkeypatch.setenv('NCCL_DEBUG', 'WARN')                                  # the caller configured RCCL's logging: not ours to redirect
+    assert D.rccl_debug_file_env('t') == {}

@@ -49,6 +49,11 @@ def dump(a):
             g_depth = (torch.rand(ret['depth'].shape, generator=g) * 1e-3).to(dev)
             grads = eng.backward(g_rgb, g_depth, None)
             out[tag + 'grads'] = grads.cpu().numpy()
+            if name == 'split':                                     # what the split-bf16 dX chain wrote: dZ0..dZ7, [dS | dG], dP
+                for net in (0, 1):
+                    for t in list(range(12, 20)) + [21, 23]:
+                        for plane in (0, 1):
+                            out[tag + 'ws_n%d_t%d_p%d' % (net, t, plane)] = eng.saved_tensor(net, t, plane).cpu().numpy()
     np.savez(a.out, **out)
     print('wrote', a.out, len(out), 'arrays')
 
