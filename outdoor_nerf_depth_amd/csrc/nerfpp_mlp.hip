@@ -16,7 +16,12 @@
 //              3 = (forward kernels only) fp16x2w: weights hi + lo in fp16, activations rounded to fp16 once, 2 passes of
 //                  v_mfma_f32_32x32x16_f16 -- an intermediate precision (nerfpp_common.h: precision ids).
 //
-// Weight-pipe modes (WeightPipe<P, NW, MODE, NBUF, BF>): blocks of BF fragments x P planes (16 KiB in every training kernel)
+// Split-bf16 (P = 2) since round 6: the kernels that SHIP are mlp_fwd_body_split / mlp_bwd_body_split (nerfpp_mlp_split.h: 12-MFMA
+// units read one unit ahead, lazily converted epilogue, ring pipe without wave roles in training) -- same arithmetic, bit-identical
+// results.  The P = 2 paths of mlp_fwd_body / mlp_bwd_body below are their stage-at-a-time predecessors: compiled only into the
+// diagnostic build (-DNERFPP_PROBES -DNERFPP_SPLIT_V2=0) that tools/probes/split_dump.py compares the shipped kernels against.
+//
+// Weight-pipe modes (WeightPipe<P, NW, MODE, NBUF, BF>): blocks of BF fragments x P planes (16 KiB in the bf16 training kernels)
 // through an LDS ring, four fragments per DMA set-up (glds16xN_saddr), COUNTED vmcnt waits, one raw s_barrier per block.
 //   PIPE_RING    : inference forward (no stores in flight): every wave fetches its share of a block; all outstanding VMEM
 //                  ops of a wave are same-type loads, in order, so "at most k blocks' worth outstanding" is exact.
