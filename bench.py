@@ -550,6 +550,42 @@ def cli_loop(args, kernel_only_ms):
     return out
 
 
+def second_transport(args, L, rank, world, device, batches, out):
+    """--grad_comm both: the timed bf16 steps once more with the gradient all-reduce going through the library's own RCCL entry
+    point (nerfpp_allreduce_mean on a communicator of its own).  A failure or a hang here must not cost the scaling run its
+    torch.distributed number: errors are reported in config.grad_comm_rccl_abi, and a watchdog on EVERY rank ends the process
+    (rank 0 after printing the line it already has) if the phase has not finished in NERFPP_BENCH_ABI_TIMEOUT_S (default 180 s)."""
+    import threading
+
+    def bail():
+        if out is not None:
+            out['config']['grad_comm_rccl_abi'] = {'error': 'timed out (watchdog): the rccl_abi transport did not finish'}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    dog = threading.Timer(float(os.environ.get('NERFPP_BENCH_ABI_TIMEOUT_S', '180')), bail)
+    dog.daemon = True
+    dog.start()
+    result = None
+    comm = None
+    try:
+        from outdoor_nerf_depth_amd.dist_utils import RcclComm
+        comm = RcclComm(rank, world)
+        r = run_mode(args, L.PREC_BF16, rank, world, device, batches, comm=comm)
+        result = {'value': r['value'], 'ms_per_step': r['ms_per_step'], 'per_rank_ms_per_step': r['per_rank_ms_per_step'],
+                  'exposed_update_ms_per_step': r['exposed_update_ms_per_step'], 'allreduce_ms': r['allreduce_ms']}
+    except Exception as e:                           # noqa: BLE001 (reported in the JSON line)
+        result = {'error': '%s: %s' % (type(e).__name__, e)}
+    finally:
+        if comm is not None:
+            try:
+                comm.destroy()
+            except Exception:                        # noqa: BLE001
+                pass
+        dog.cancel()
+    if out is not None:
+        out['config']['grad_comm_rccl_abi'] = result
+
+
 def _channels_in_effect():
     from outdoor_nerf_depth_amd.dist_utils import rccl_channels_in_effect
     return rccl_channels_in_effect()
@@ -602,31 +638,19 @@ def main():
     res = {}
     if world > 1 and args.precision == 'both':
         args.precision = 'bf16'                  # the scaling runs measure the headline precision only
-    abi_run, abi_error = None, None
+    abi_second = False                       # --grad_comm both: the library's own RCCL entry point as a SECOND run, last of all
     if args.precision in ('both', 'bf16'):
         want = args.grad_comm if (world > 1 and backend == 'nccl') else 'torch'
-        if want in ('torch', 'both'):
+        if want == 'rccl_abi':
+            from outdoor_nerf_depth_amd.dist_utils import RcclComm
+            comm = RcclComm(rank, world)
+            res['bf16'] = run_mode(args, L.PREC_BF16, rank, world, device, batches, comm=comm)
+            comm.destroy()
+        else:
             res['bf16'] = run_mode(args, L.PREC_BF16, rank, world, device, batches)
-        if want in ('rccl_abi', 'both'):
-            # the same job through the library's own RCCL entry point (a second communicator, built over the first): a failure
-            # here must not cost the scaling run its torch number -- it is reported, not raised, when both were asked for
-            comm = None
-            try:
-                from outdoor_nerf_depth_amd.dist_utils import RcclComm
-                comm = RcclComm(rank, world)
-                abi_run = run_mode(args, L.PREC_BF16, rank, world, device, batches, comm=comm)
-            except Exception as e:                       # noqa: BLE001 (reported in the JSON line)
-                if want == 'rccl_abi':
-                    raise
-                abi_error = '%s: %s' % (type(e).__name__, e)
-            finally:
-                if comm is not None:
-                    try:
-                        comm.destroy()
-                    except Exception:                    # noqa: BLE001
-                        pass
-            if want == 'rccl_abi':
-                res['bf16'] = abi_run
+            # (test hook: NERFPP_BENCH_FORCE_ABI_SECOND=1 runs the second-transport phase over gloo on a shared GPU too -- RCCL
+            # refuses two ranks on one device, so what that exercises is the phase's failure and watchdog paths)
+            abi_second = want == 'both' or (world > 1 and bool(os.environ.get('NERFPP_BENCH_FORCE_ABI_SECOND')))
     if args.precision in ('both', 'split'):
         res['split'] = run_mode(args, L.PREC_SPLIT_BF16, rank, world, device, batches)
     m360 = None
@@ -637,6 +661,8 @@ def main():
         m360 = mip360.benchmark_step(device, args.mip360_rays, steps=5, warmup=2, seed=rank, world_size=world)
     if rank != 0:
         if world > 1:
+            if abi_second:
+                second_transport(args, L, rank, world, device, batches, None)
             dist.destroy_process_group()
         return
     main_key = 'bf16' if 'bf16' in res else 'split'
@@ -667,11 +693,7 @@ def main():
                    'grad_comm': (None if world == 1 else 'rccl_abi' if (args.grad_comm == 'rccl_abi' and backend == 'nccl') else 'torch'),
                    'allreduce_ms': r['allreduce_ms'],
                    'rccl_channels_in_effect': _channels_in_effect() if world > 1 else None,
-                   'grad_comm_rccl_abi': (None if abi_run is None or args.grad_comm != 'both' else
-                                          {'value': abi_run['value'], 'ms_per_step': abi_run['ms_per_step'],
-                                           'per_rank_ms_per_step': abi_run['per_rank_ms_per_step'],
-                                           'exposed_update_ms_per_step': abi_run['exposed_update_ms_per_step'],
-                                           'allreduce_ms': abi_run['allreduce_ms']}) if abi_error is None else {'error': abi_error}},
+                   'grad_comm_rccl_abi': None},        # (--grad_comm both: filled in by second_transport() below)
         'roofline': roofline(r),
         'final_loss': r['loss'],
         'gates': {
@@ -742,6 +764,10 @@ def main():
             out['config']['end_to_end_default_precision'] = dict(out['end_to_end_default_precision'])
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
+    if world > 1 and abi_second:
+        # everything the line needs is in `out`; the second transport has never run on more than one GPU (no box in six rounds),
+        # so it runs LAST and under a watchdog: should it hang, every rank abandons it and rank 0 still prints the line
+        second_transport(args, L, rank, world, device, batches, out)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

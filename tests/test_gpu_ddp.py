@@ -252,6 +252,30 @@ def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
     assert bad.returncode != 0 and 'WORLD_SIZE=1' in (bad.stderr + bad.stdout)
 
 
+def test_bench_second_transport_cannot_cost_the_line():
+    """Round 6: `bench.py --gpus N` runs the job a second time through the library's own RCCL entry point (--grad_comm both) -- a
+    path that has never run on more than one GPU.  It runs last, and neither a failure nor a hang there may cost the run its
+    torch.distributed number.  On a 1-GPU box both are provoked: two ranks on one device make nerfpp_rccl_comm_init fail (RCCL
+    refuses) or block; the line must come out either way, with the reason in config.grad_comm_rccl_abi."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('provokes the failure paths by sharing one device')
+    import json
+    hook = {'NERFPP_SHARE_GPU': '1', 'NERFPP_DIST_BACKEND': 'gloo', 'NERFPP_BENCH_FORCE_ABI_SECOND': '1'}
+    for extra, expect in (({'NERFPP_BENCH_ABI_TIMEOUT_S': '60'}, None), ({'NERFPP_BENCH_ABI_TIMEOUT_S': '0.05'}, 'timed out')):
+        out = _run_bench(['--gpus', '2', '--mip360_rays', '0'], dict(hook, **extra), timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+        assert len(lines) == 1, out.stdout[-2000:]
+        r = json.loads(lines[0])
+        assert r['n_gpus'] == 2 and r['value'] > 0
+        second = r['config']['grad_comm_rccl_abi']
+        assert second is not None and 'error' in second, second
+        if expect:
+            assert expect in second['error'], second
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # round 3 (VERDICT r02 item 7): the 8-rank code paths on a 1-GPU box -- bench.py --gpus 8 and the ragged inference
 # sharding of a 375 x 1242 frame over 8 ranks -- over gloo with every rank on cuda:0 (numbers from such a run mean
