@@ -62,6 +62,8 @@ constexpr int SKEW_INFER = 0;          // weight blocks by which waves NW/2.. la
 constexpr int EXP = 0;                 // (probes: timing experiments with garbage results -- nerfpp_mlp_probes.h)
 constexpr int TRICKLE = 1;             // bit 0 / 1: ring / roles pipe issues a block's weight DMA in pieces between the MFMAs of the step
 constexpr int UNIT_VALU = 4;           // unit-pipelined split-bf16 kernels: VALU instructions dealt out behind each MFMA of a unit (0: the compiler's own order)
+constexpr int V2T_NBUF = 3;            // ring slots of the unit-pipelined split-bf16 training forward (nerfpp_mlp_split.h)
+constexpr int V2T_NBUF_BWD = 3;        // ... and of the dX chain
 constexpr int SPLIT_V2 = 7;            // bit 0 / 1 / 2: the split-bf16 inference forward / training forward / backward runs the unit-pipelined body (nerfpp_mlp_split.h)
 __device__ __forceinline__ void store16(char* gptr, const uint4 v) {       // activation saves: non-temporal 16-byte stores
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
@@ -831,8 +833,8 @@ struct FwdLds {
   static constexpr int BF = V2T ? BLK_FRAGS : blk_frags_of<P, TRAIN>();
   // ring depth: as deep as the 160 KiB of LDS allow
   static constexpr int SKEW = (MODE == PIPE_RING && P == 1 && NW >= 2) ? probe::SKEW_INFER : 0;
-  // (V2T: every wave stores AND fetches, so a block is waited for with a full vmcnt drain -- one block ahead, two slots)
-  static constexpr int NBUF = V2T ? 2 : MODE == PIPE_RING ? (P == 1 ? 4 + SKEW : 3) : 4;
+  // (V2T: every wave stores AND fetches -- probe::V2T_NBUF slots, see nerfpp_mlp_split.h on what a counted wait guarantees there)
+  static constexpr int NBUF = V2T ? probe::V2T_NBUF : MODE == PIPE_RING ? (P == 1 ? 4 + SKEW : 3) : 4;
   static constexpr int W = NBUF * BF * w_planes(P) * FRAG_BYTES;
   static constexpr int REGION = W;
   static constexpr int STASH = REGION + (ROLES ? region_bytes(P) : 0);

@@ -94,6 +94,14 @@ constexpr int TRICKLE = NERFPP_TRICKLE;           // bit 0 / 1: the ring / roles
 #define NERFPP_UNIT_VALU 4
 #endif
 constexpr int UNIT_VALU = NERFPP_UNIT_VALU;       // unit-pipelined split-bf16 kernels: VALU instructions dealt out behind each MFMA of a unit (0: the compiler's own order)
+#ifndef NERFPP_V2T_NBUF
+#define NERFPP_V2T_NBUF 3
+#endif
+#ifndef NERFPP_V2T_NBUF_BWD
+#define NERFPP_V2T_NBUF_BWD 3
+#endif
+constexpr int V2T_NBUF = NERFPP_V2T_NBUF;         // ring slots of the unit-pipelined split-bf16 training forward (2: full drain per block; 3: counted wait, DMA in pieces)
+constexpr int V2T_NBUF_BWD = NERFPP_V2T_NBUF_BWD; // ... and of the dX chain (2, 3 or 4)
 #ifndef NERFPP_SPLIT_V2
 #define NERFPP_SPLIT_V2 7
 #endif

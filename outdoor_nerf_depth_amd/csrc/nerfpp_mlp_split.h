@@ -22,11 +22,15 @@
 //     epilogue thus sits between MFMAs (<= 5 issue slots per MFMA are free) instead of in a phase where the matrix pipe idles.
 //   * Training: NO wave roles.  Every wave fetches its quarter of each weight block and writes the chunks of its own tile
 //     straight after converting them (two 1 KiB wave-stores per chunk, spread over the consuming stage by construction).  Stores
-//     and weight DMA share vmcnt and retire out of order, so a block is waited for with a FULL drain -- which is why the ring is
-//     2 slots of 16-fragment blocks, one block ahead: the drain at a block's end covers the DMA issued a whole block earlier
-//     and stores that are at least a unit old.  (The roles pipe -- loader wave, LDS hand-off region, helper waves -- existed to
-//     avoid that drain when a stage's 32 wave-stores went out in one burst; with lazy conversion there is no burst.)  Half the
-//     barriers of the 8-fragment roles pipe, no hand-off traffic, 33 KiB less LDS, one instruction stream for all waves.
+//     and weight DMA share vmcnt and retire out of order WITH RESPECT TO EACH OTHER, but loads retire in order among loads: with
+//     the newest block's 8 DMA instructions as the youngest loads of the wave, `vmcnt(8)` leaves at most 8 operations outstanding
+//     -- if they are those 8 loads everything older has retired, and if some of those 8 have retired then every OLDER load has too.
+//     So the block before the newest is guaranteed either way; what the wait additionally drains is the wave's stores, which by
+//     then are at least a unit old.  3-slot ring of 16-fragment blocks (two blocks ahead, DMA in pieces between the MFMAs), half
+//     the barriers of the 8-fragment roles pipe, no hand-off traffic, 33 KiB less LDS, one instruction stream for all waves.
+//     (The roles pipe -- loader wave, LDS hand-off region, helper waves -- existed to avoid a full drain when a stage's 32
+//     wave-stores went out in one burst; with lazy conversion there is no burst.  A 2-slot ring with a full drain was the first
+//     form: 3 % slower per step.)
 #pragma once
 
 namespace nerfpp {
@@ -126,7 +130,7 @@ __device__ __forceinline__ void conv_chunk_relu(const float (&raw_ob)[16], int o
     const float a = raw_ob[8 * hh + 2 * w], b = raw_ob[8 * hh + 2 * w + 1];
     const uint32_t d = pack2<1>(a, b);
     const int j = (ob & 1) * 8 + hh * 4 + w;
-    m[ob >> 1] |= (d >> j) & (0x80008000u >> j);
+    if constexpr ((probe::DBG & 128) == 0) m[ob >> 1] |= (d >> j) & (0x80008000u >> j);      // (probes: DBG 128 = no sign words)
     const uint32_t lo = pack2<1>(a - __uint_as_float(d << 16), b - __uint_as_float(d & 0xffff0000u));
     const uint32_t neg = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, d) >> (s16x2){15, 15});
     dh[w] = d & ~neg;
@@ -150,6 +154,11 @@ __device__ __forceinline__ void raw_copy_ob(const f32x16& acc_ob, float (&raw_ob
 
 // the bias of one out-block (LDS copy of the bias stream) into its accumulator registers
 __device__ __forceinline__ void init_bias_ob(f32x16& acc_ob, uint32_t lds_off_bytes, int ob, int hi) {
+  if constexpr ((probe::EXP & 64) != 0) {          // (probes, garbage results: zero accumulators instead of the bias reads)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_ob[r] = 0.f;
+    return;
+  }
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   LDS_AS char* base = (LDS_AS char*)smem;
 #pragma unroll
@@ -375,14 +384,16 @@ __device__ __forceinline__ void mlp_fwd_body_split(const MlpFwdArgs& a, const in
 // ------------------------------------------------------------------------------------------------------------------------------
 // backward (dX chain), same construction: units, lazy epilogue (dH accumulators -> raw copy -> masked hi / lo chunks of dZ, one
 // chunk per k-chunk ahead of the MFMAs that consume it), ring pipe with a 2-slot ring of 16-fragment blocks, no wave roles: every
-// wave loads its own ReLU sign words (16 B per lane and stage, one stage ahead) and stores the chunks of its own dZ tiles right
-// behind their conversion.  Same MFMA chains and conversions as mlp_bwd_body<NET, 2, NW>: bit-identical dZ tensors.
+// wave DMAs its own ReLU sign words (1 KiB per wave and stage, one stage ahead, into a 2-slot LDS area: ALL loads of a wave are
+// then LDS-DMA loads, which retire in order -- what the counted vmcnt waits of the ring rely on) and stores the chunks of its own
+// dZ tiles right behind their conversion.  Same MFMA chains and conversions as mlp_bwd_body<NET, 2, NW>: bit-identical dZ tensors.
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int NW>
 struct BwdLdsV2 {
-  static constexpr int BF = BLK_FRAGS, NBUF = 2;
+  static constexpr int BF = BLK_FRAGS, NBUF = probe::V2T_NBUF_BWD;
   static constexpr int W = NBUF * BF * 2 * FRAG_BYTES;
-  static constexpr int TOTAL = W;
+  static constexpr int MASKS = W;                      // 2 slots x NW KiB of ReLU sign words (every wave DMAs its own 1 KiB per stage)
+  static constexpr int TOTAL = MASKS + 2 * NW * 1024;
 };
 
 // chunk c = 2 ob + hh of dZ: the accumulator registers 8 hh .. 8 hh + 7 of out-block ob, masked by the forward's sign words
@@ -416,7 +427,17 @@ __device__ __forceinline__ void mlp_bwd_body_split(const MlpBwdArgs& a, const in
   const size_t plane_rows = a.rows_padded;
   const size_t wrow0 = (size_t)bid * (NW * 32) + wave * 32;
   const size_t nblk32 = a.rows_padded / 32;
-  const uint4* mask_in = a.masks + (wrow0 / 32) * 64 + lane;             // + stage * nblk32 * 64
+  const char* mask_g = (const char*)(a.masks + (wrow0 / 32) * 64);        // this wave's 1 KiB of sign words; + stage * nblk32 * 1024
+  const uint32_t lds0 = lds_base_addr();
+  // sign words of `mstage` -> LDS slot (one 1 KiB DMA); read back once the wave's counted waits have covered it
+  auto mask_dma = [&](int mstage, int slot) __attribute__((always_inline)) {
+    glds16xN_saddr<1>(mask_g + (size_t)mstage * nblk32 * 1024, (uint32_t)lane * 16u, lds0 + LD::MASKS + (slot * NW + wave) * 1024);
+  };
+  auto mask_get = [&](int slot) __attribute__((always_inline)) -> uint4 {
+    return *(const uint4*)(smem + LD::MASKS + (slot * NW + wave) * 1024 + lane * 16);
+  };
+  mask_dma(8, 0);
+  mask_dma(7, 1);
 
   WeightPipe<P, NW, PIPE_RING, LD::NBUF, LD::BF> pipe;
   pipe.stamp_off = LD::TOTAL;
@@ -426,7 +447,6 @@ __device__ __forceinline__ void mlp_bwd_body_split(const MlpBwdArgs& a, const in
 
   float4 d = ((const float4*)a.d_out)[row];
   if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);                        // rows past the end: zero gradients, zero dZ everywhere
-  uint4 mk8 = mask_in[(size_t)8 * nblk32 * 64], mk7 = mask_in[(size_t)7 * nblk32 * 64];
   {
     // dP [rows, 32] and dS [rows, 32] (chunks 0, 1 of [dS | dG]) come straight from d_out
     Frag<P> t[2];
@@ -445,7 +465,8 @@ __device__ __forceinline__ void mlp_bwd_body_split(const MlpBwdArgs& a, const in
     for (int r = 0; r < 16; ++r) acc_ob[r] = 0.f;
   };
 
-  feed.fetch(0);
+  feed.fetch(0);                          // (its counted wait covers the two sign-word DMAs above: they are older than block 0)
+  const uint4 mk8 = mask_get(0), mk7 = mask_get(1);
   float raw[8][16];
   // B0: dG = Wrgb1^T dP (one live k-chunk), masked by G > 0 (sign words 8)
   Frag<P> dg[8];
@@ -498,6 +519,7 @@ __device__ __forceinline__ void mlp_bwd_body_split(const MlpBwdArgs& a, const in
       }
     });
   // B3 .. B9: dH_{l-1} = W_l^T dZ_l, l = 7 .. 1; dZ_l is converted lazily from the previous stage's raw copy with sign words l
+  // (sign words l - 1 go to the LDS slot that held sign words l + 1: slot l & 1)
   auto trunk = [&](auto l_c, Frag<P> (&zin)[16], Frag<P> (&zout)[16], const uint4 mk_in, uint4& mk_out) __attribute__((always_inline)) {
     constexpr int l = decltype(l_c)::value;
     constexpr int GU0 = bs_frag_off(10 - l) / 4;
@@ -506,7 +528,8 @@ __device__ __forceinline__ void mlp_bwd_body_split(const MlpBwdArgs& a, const in
       [&](int kc) -> const Frag<P>& { return zin[kc]; },
       [&](int i) __attribute__((always_inline)) {
         const int kc = i >> 1, half = i & 1;
-        if (i == 0) { retire(4); mk_out = mask_in[(size_t)(l - 1) * nblk32 * 64]; }   // (this unit's MFMAs go to out-blocks 0-3)
+        if (i == 0) retire(4);                                             // (this unit's MFMAs go to out-blocks 0-3)
+        if (i == 2) mask_dma(l - 1, l & 1);                                // (sign words l + 1 were last read in the previous stage)
         if (half == 0 && kc + 1 <= 15) {
           const int c = kc + 1;
           conv_chunk_mask(raw[c >> 1], c >> 1, c & 1, mk_in, zin[c]);
@@ -514,6 +537,7 @@ __device__ __forceinline__ void mlp_bwd_body_split(const MlpBwdArgs& a, const in
         }
         if (i == 31) {
           retire(0);
+          mk_out = mask_get(l & 1);                                        // (issued 29 units = 7 counted block waits ago)
           conv_chunk_mask(raw[0], 0, 0, mk_out, zout[0]);
           store(a.ws.t[T_DZ0 + l - 1], 256, 0, zout[0]);
         }
