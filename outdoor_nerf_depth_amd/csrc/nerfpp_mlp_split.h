@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_chunk_relu(const float (&raw_ob)[16], int o
     const float a = raw_ob[8 * hh + 2 * w], b = raw_ob[8 * hh + 2 * w + 1];
     const uint32_t d = pack2<1>(a, b);
     const int j = (ob & 1) * 8 + hh * 4 + w;
-    if constexpr ((probe::DBG & 128) == 0) m[ob >> 1] |= (d >> j) & (0x80008000u >> j);      // (probes: DBG 128 = no sign words)
+    m[ob >> 1] |= (d >> j) & (0x80008000u >> j);
     const uint32_t lo = pack2<1>(a - __uint_as_float(d << 16), b - __uint_as_float(d & 0xffff0000u));
     const uint32_t neg = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, d) >> (s16x2){15, 15});
     dh[w] = d & ~neg;
