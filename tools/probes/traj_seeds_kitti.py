@@ -37,7 +37,8 @@ from outdoor_nerf_depth_amd.ddp_train_nerf import render_single_image, mse2psnr 
 from outdoor_nerf_depth_amd.trainer import NerfppTrainer                       # noqa: E402
 
 CONFIGS = {'mse': dict(depth_sup_type='gt', depth_loss_type='mse', lambda_depth=0.1, trainskip=1),
-           'kl': dict(depth_sup_type='mono_crop', depth_loss_type='kl', lambda_depth=0.1, trainskip=8)}
+           'kl': dict(depth_sup_type='mono_crop', depth_loss_type='kl', lambda_depth=0.1, trainskip=8),
+           'l1': dict(depth_sup_type='stereo_crop', depth_loss_type='l1', lambda_depth=0.1, trainskip=1)}      # config 4's depth term
 PRECS = (('split_bf16', L.PREC_SPLIT_BF16), ('split_fwd', L.PREC_SPLIT_FWD), ('bf16', L.PREC_BF16))
 
 
