@@ -22,7 +22,8 @@ def dump(a):
     dev = torch.device('cuda:0')
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     out = {}
-    for n_rays, S in ((a.n_rays, a.S), (37, 64)):                       # a full batch and a ragged one (tile tails)
+    shapes = [tuple(int(v) for v in x.split('x')) for x in a.shapes.split(',')] if a.shapes else [(a.n_rays, a.S), (37, 64)]
+    for n_rays, S in shapes:                                            # default: a full batch and a ragged one (tile tails)
         b = SyntheticKitti().random_batch(n_rays, np.random.RandomState(3))
         ray_o, ray_d = T(b['ray_o']), T(b['ray_d'])
         rs = np.random.RandomState(7)                                  # explicit perturbation uniforms: the same inputs in every run
@@ -82,6 +83,7 @@ if __name__ == '__main__':
     p.add_argument('--out', default='split_dump.npz')
     p.add_argument('--n_rays', type=int, default=256)
     p.add_argument('--S', type=int, default=192)
+    p.add_argument('--shapes', default='', help="comma list of RAYSxSAMPLES, e.g. '1x2,17x31,4096x192' (default: n_rays x S and 37x64)")
     p.add_argument('--compare', nargs=2)
     a = p.parse_args()
     if a.compare:
