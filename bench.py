@@ -33,6 +33,8 @@ cpu_baseline        : oracle/nerfpp_torch_cpu.py (PyTorch-CPU restatement of the
 render              : SURVEY 8 f-2: one 375x1242 frame through render_single_image, whole call and MLP kernels alone
 cli_loop            : the drop-in training loop itself (ddp_train_nerf(): per-step frame choice, ray-batch sampling, log lines)
                       with the device sampler and with the reference's host sampler, ms per step beside the kernel-only figure
+power               : socket power, power cap and shader clock (amdgpu hwmon) while the end_to_end loop ran: the MLP kernels hold
+                      the socket at its cap and the clock gives way (profiles/r06_power_trace.md); null where hwmon is not readable
 """
 import argparse
 import json
@@ -461,6 +463,71 @@ def render_leg(args, device, precision, label):
                     'algorithmic figure in split-bf16)'}
 
 
+class PowerSampler(object):
+    """Socket power and shader clock (amdgpu hwmon files of the PCI device HIP device 0 sits on) sampled every 50 ms by a thread
+    while a leg runs: the MLP kernels hold the socket at its power cap with the clock throttled (profiles/r06_power_trace.md), and a
+    box with a different cap or clock shows up here.  Never raises: `summary()` is None where the files are not readable."""
+
+    def __init__(self):
+        import threading
+        self.files, self.rows, self.on, self.thread = {}, [], False, None
+        try:
+            import ctypes
+            import glob
+            hip = ctypes.CDLL('libamdhip64.so')
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, 0) != 0:
+                return
+            self.pci = buf.value.decode().lower()
+            for d in sorted(glob.glob('/sys/bus/pci/devices/%s/hwmon/hwmon*' % self.pci)):
+                for key, name in (('power_uw', 'power1_input'), ('power_uw', 'power1_average'), ('cap_uw', 'power1_cap'), ('sclk_hz', 'freq1_input')):
+                    f = os.path.join(d, name)
+                    if key not in self.files and os.path.exists(f):
+                        self.files[key] = f
+            if 'power_uw' in self.files:
+                self.thread = threading.Thread(target=self._run, daemon=True)
+        except Exception:
+            self.files, self.thread = {}, None
+
+    def _run(self):
+        while self.on:
+            row = {}
+            for k, f in self.files.items():
+                try:
+                    with open(f) as fh:
+                        row[k] = int(fh.read())
+                except Exception:
+                    pass
+            self.rows.append((time.perf_counter(), row))
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.thread is not None:
+            self.on = True
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.on = False
+        if self.thread is not None:
+            self.thread.join(timeout=2.0)
+        return False
+
+    def summary(self, t_from, t_to):
+        """mean over the samples taken in [t_from, t_to] (time.perf_counter())"""
+        rows = [r for t, r in self.rows if t_from <= t <= t_to]
+        if not rows:
+            return None
+        out = {'samples': len(rows), 'pci': getattr(self, 'pci', None)}
+        for k, name, div in (('power_uw', 'socket_w', 1e6), ('cap_uw', 'cap_w', 1e6), ('sclk_hz', 'sclk_mhz', 1e6)):
+            v = [r[k] for r in rows if k in r]
+            if v:
+                out[name] = round(float(np.mean(v)) / div, 1)
+                if k != 'cap_uw':
+                    out[name + '_max'] = round(float(np.max(v)) / div, 1)
+        return out
+
+
 def cli_loop(args, kernel_only_ms):
     """the drop-in loop itself -- `ddp_train_nerf()` of outdoor_nerf_depth_amd/ddp_train_nerf.py
     (reference: ddp_train_nerf.py:417-431 per-step frame choice + random_sample + H2D, here device_sampler.py +
@@ -477,12 +544,13 @@ def cli_loop(args, kernel_only_ms):
     class Cap(logging.Handler):
         def __init__(self):
             logging.Handler.__init__(self)
-            self.rows = []
+            self.rows, self.at = [], {}
 
         def emit(self, record):
             m = re.search(r'step: (\d+) .* iter_time: ([0-9.eE+-]+)', record.getMessage())
             if m:
                 self.rows.append((int(m.group(1)), float(m.group(2))))
+                self.at[int(m.group(1))] = time.perf_counter()
 
     import torch
     out = {'steps': args.cli_steps, 'i_print': 100,
@@ -516,6 +584,7 @@ def cli_loop(args, kernel_only_ms):
     for name, extra in (('device_sampler', []), ('host_sampler', ['--host_sampling']), ('device_sampler_default_precision', ['--precision', 'split'])):
         tmp = tempfile.mkdtemp(prefix='nerfpp_cli_')
         cap = Cap()
+        power = None
         C.setup_logger()
         lg = logging.getLogger(C.__package__ or 'outdoor_nerf_depth_amd')
         lg.addHandler(cap)
@@ -531,7 +600,10 @@ def cli_loop(args, kernel_only_ms):
             a.world_size = 1
             a.on_finish = on_finish
             same_state.clear()
-            C.ddp_train_nerf(0, a)
+            with PowerSampler() as ps:
+                C.ddp_train_nerf(0, a)
+            marks = sorted(st for st in cap.at if st >= 300)            # the log lines of steps 300 ... last: the steps `late` averages
+            power = ps.summary(cap.at[marks[0]], cap.at[marks[-1]]) if len(marks) >= 2 else None
         finally:
             lg.removeHandler(cap)
             lg.setLevel(level)
@@ -546,7 +618,8 @@ def cli_loop(args, kernel_only_ms):
                      'ms_per_step_by_log_line': [round(1e3 * t, 4) for t in late],
                      'kernel_only_same_state_ms': ref,
                      'overhead_pct': None if ref is None else 100.0 * (ms / ref - 1.0),
-                     'overhead_vs_fresh_pct': None if 'default_precision' in name else 100.0 * (ms / kernel_only_ms - 1.0)}
+                     'overhead_vs_fresh_pct': None if 'default_precision' in name else 100.0 * (ms / kernel_only_ms - 1.0),
+                     'power': power}
     return out
 
 
@@ -756,6 +829,11 @@ def main():
             out['trained_state_ms'] = d['kernel_only_same_state_ms']
             # (also inside `config`, one of the objects the driver's record echoes as a whole: VERDICT r05 item 8)
             out['config']['end_to_end'] = dict(out['end_to_end'])
+            if d.get('power'):
+                # socket power / shader clock while that loop ran (hwmon): the kernels hold the socket at its cap, the clock gives way
+                out['power'] = dict(d['power'], during='the end_to_end loop (bf16), between its log lines of step 300 and of the last step',
+                                    default_precision_loop=(out['cli_loop'].get('device_sampler_default_precision') or {}).get('power'))
+                out['config']['power'] = {k: out['power'].get(k) for k in ('socket_w', 'cap_w', 'sclk_mhz')}
         d2 = out['cli_loop'].get('device_sampler_default_precision')
         if d2:
             out['end_to_end_default_precision'] = {'value': d2['rays_per_s'], 'unit': 'rays/s', 'ms_per_step': d2['ms_per_step'],

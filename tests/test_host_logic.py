@@ -339,3 +339,28 @@ def test_rccl_env_defaults_single_node_only_and_channel_log_parser(tmp_path, mon
     assert D.rccl_channels_in_effect() == [{'coll': 4, 'p2p': 8}, {'coll': 2, 'p2p': 4}]
     monkeypatch.setenv('NCCL_DEBUG', 'WARN')                                  # the caller configured RCCL's logging: not ours to redirect
     assert D.rccl_debug_file_env('t') == {}
+
+
+def test_bench_power_sampler_is_harmless_without_hwmon(tmp_path):
+    """bench.PowerSampler (socket power / shader clock beside the end_to_end loop) never raises: no GPU or no readable hwmon
+    files -> summary None; with files (a fake hwmon directory here) -> watts and MHz over the requested window only."""
+    import time
+    import bench
+    with bench.PowerSampler() as ps:
+        pass
+    assert ps.summary(0.0, float('inf')) is None or isinstance(ps.summary(0.0, float('inf')), dict)
+    ps = bench.PowerSampler()
+    (tmp_path / 'power1_input').write_text('1366000000\n')
+    (tmp_path / 'power1_cap').write_text('1400000000\n')
+    (tmp_path / 'freq1_input').write_text('1931000000\n')
+    ps.files = {'power_uw': str(tmp_path / 'power1_input'), 'cap_uw': str(tmp_path / 'power1_cap'), 'sclk_hz': str(tmp_path / 'freq1_input'),
+                'gone': str(tmp_path / 'missing')}
+    import threading
+    ps.thread = threading.Thread(target=ps._run, daemon=True)
+    t0 = time.perf_counter()
+    with ps:
+        time.sleep(0.2)
+    t1 = time.perf_counter()
+    got = ps.summary(t0, t1)
+    assert got['socket_w'] == 1366.0 and got['cap_w'] == 1400.0 and got['sclk_mhz'] == 1931.0 and got['samples'] >= 2
+    assert ps.summary(t1 + 1.0, t1 + 2.0) is None
