@@ -122,13 +122,19 @@ def main():
             ('split-bf16 forward + backward + weight gradients', fwd_bwd(engines['split'])),
             ('torch bf16 GEMM 8192^3 (hipBLASLt)', lambda: torch.mm(x, x)),
             ('1 GiB memset (HBM writes)', lambda: big.zero_())]
-    for name, f in legs:
+    from outdoor_nerf_depth_amd import mip360
+    once = {'MipNeRF-360 training step, 4096 rays (config 5; 300 steps, joined + deferred updates)':
+            lambda: mip360.benchmark_step(dev, 4096, steps=300, warmup=3)}
+    for name, f in legs + [(k, None) for k in once]:
         s = Sampler(files)
         torch.cuda.synchronize()
         t0 = time.time()
         s.start()
         n = 0
-        if f is None:
+        if name in once:
+            res = once[name]()
+            n = 600
+        elif f is None:
             time.sleep(a.seconds)
         else:
             while time.time() - t0 < a.seconds:
@@ -139,9 +145,11 @@ def main():
         t1 = time.time()
         s.on = False
         s.join()
-        smi = smi_sample() if f is None else None
+        smi = smi_sample() if name == 'idle' else None
         rows = [r for t, r in s.rows if t - t0 > 1.0]                # after a second of warm-up
-        leg = {'leg': name, 'launches': n, 'ms_per_launch': (t1 - t0) * 1e3 / n if n else None, 'samples': len(rows)}
+        if name in once:                                             # (set-up at both ends: the middle 60 % of the call)
+            rows = [r for t, r in s.rows if t0 + 0.2 * (t1 - t0) <= t <= t0 + 0.8 * (t1 - t0)]
+        leg = {'leg': name, 'launches': n, 'ms_per_launch': (res.get('ms_per_step') if name in once else (t1 - t0) * 1e3 / n) if n else None, 'samples': len(rows)}
         for k in files:
             if k == 'pci':
                 continue
