@@ -27,7 +27,8 @@ parity_mode         : split-bf16 everywhere (3 MFMA passes): the mode the 1e-4 p
 gates               : which test gate each of those numbers has passed
 roofline            : SURVEY 8(d): algorithmic dense-layer FLOP (1.797 GFLOP per ray-step) against the dense
                       bf16 MFMA peak -- whole step and dominant kernel group, timed live with HIP events on
-                      the launch stream; the HBM view of the weight-gradient GEMM as a sub-object
+                      the launch stream; the HBM view of the weight-gradient GEMM as a sub-object; and, as context for
+                      the nominal peak, what hipBLASLt's 8192^3 bf16 GEMM gets from the same socket (vendor_gemm_same_socket)
 cpu_baseline        : oracle/nerfpp_torch_cpu.py (PyTorch-CPU restatement of the path, the way the reference
                       runs on CPU) on the host cores: N_rand 1024, 2 warm-up + 5 timed steps, median
 render              : SURVEY 8 f-2: one 375x1242 frame through render_single_image, whole call and MLP kernels alone
@@ -420,6 +421,33 @@ def cpu_baseline(args):
                        % (n, n_warm, len(timed), torch.get_num_threads()))
 
 
+def vendor_gemm(device):
+    """What a sustained MFMA-dense kernel gets from THIS socket: torch.mm (hipBLASLt) on bf16 8192^3, 60 launches after 20
+    warm-up launches (~70 ms: the clock has settled under the power cap by then).  Context for `roofline.peak`, which is the
+    nominal 2.5 PFLOP/s at 2400 MHz; profiles/r06_power_trace.md.  None on any failure."""
+    try:
+        import torch
+        if torch.device(device).type != 'cuda':
+            return None
+        n = 8192
+        x = torch.randn(n, n, device=device, dtype=torch.bfloat16)
+        y = torch.randn(n, n, device=device, dtype=torch.bfloat16)
+        for _ in range(20):
+            torch.mm(x, y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(60):
+            torch.mm(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 60
+        tf = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
+        return {'what': 'torch.mm bf16 8192 x 8192 x 8192 (hipBLASLt) on this GPU, 60 launches back to back', 'ms': ms,
+                'tflops': tf, 'frac_of_peak': tf / PEAK_BF16_TFLOPS}
+    except Exception as e:              # context only: never costs the line
+        return {'error': repr(e)}
+
+
 def render_leg(args, device, precision, label):
     """SURVEY 8 f-2, the inference half of the metric: `render_single_image` (ddp_train_nerf.py:133-249) on one
     375x1242 frame -- deterministic sampling, both cascade levels (64 + 128 samples), fg + bg nets, chunked -- timed as the
@@ -780,6 +808,8 @@ def main():
                            '5e-2 RMS of the float64 reference (tests/test_gpu_parity.py)',
         },
     }
+    if world == 1:
+        out['roofline']['vendor_gemm_same_socket'] = vendor_gemm(device)
     if world == 1 and args.precision == 'both':
         # split-bf16 forward (rendered RGB / depth / loss within 1e-4 of float32) + bf16 backward over its hi planes
         h = run_mode(args, L.PREC_SPLIT_FWD, rank, world, device, batches)
